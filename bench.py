@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: glimpse-patches/sec of the JoliNeedle rollout hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[2]/[3], the configuration the metric is quoted on):
+gpt-nano + yolox-nano patch encoder, 448 px patches, seq-len 20, --enable-stop, batch 64
+agents per GPU on synthetic 4480x4480 fp32 images with 1-3 random boxes, one rank per GPU
+(weak scaling: configs[3] is 512 = 8 x 64).  One "step" = env build + one whole-batch
+rollout of 20 glimpse steps (forced non-STOP actions so that S == T: a fixed amount of
+work) + the REINFORCE loss.  Inputs are resident in HBM before timing.
+
+Prints ONE JSON line on rank 0 (schema in the task contract) with `roofline` for the nano
+PAFPN conv stack (HIP events around the conv section of every glimpse step, on the stream
+the kernels run on) and `cpu_baseline` (the CPU oracle timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+# SURVEY.md §8(d) / BASELINE.md §2: conv activation traffic of the nano PAFPN @448, layer-wise,
+# BN+SiLU fused, concat/upsample/focus free: 17.44 M elements per patch, fp32 storage.
+NANO_448_ELEMS_PER_PATCH = 17.44e6
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def synth_inputs(B, G, P, seed, device):
+    gen = torch.Generator(device=device).manual_seed(seed)
+    images = torch.rand((B, 3, G * P, G * P), device=device, generator=gen)
+    g = torch.Generator().manual_seed(seed)
+    bboxes = torch.zeros((B, 3, 4), dtype=torch.long)
+    for b in range(B):
+        for k in range(int(torch.randint(1, 4, (1,), generator=g))):
+            w, h = (int(torch.randint(32, P, (1,), generator=g)) for _ in range(2))
+            x = int(torch.randint(0, G * P - w, (1,), generator=g))
+            y = int(torch.randint(0, G * P - h, (1,), generator=g))
+            bboxes[b, k] = torch.tensor([x, y, x + w, y + h])
+    start = torch.randint(0, G, (B, 2), generator=g)
+    return images, bboxes, start
+
+
+def cpu_baseline(P, T, seed):
+    """CPU oracle (pure PyTorch fp32 restatement, oracle/) on the host cores: a bounded sample of
+    the same workload — B=4 agents, T glimpse steps, 4480x4480 images would need 1 GB/agent on the
+    host, so the sample uses a 3x3 grid (patch content is what costs; the grid size does not)."""
+    from oracle import env_ref, rollout_ref
+    from oracle.gpt_ref import build_gpt_ref
+    torch.manual_seed(seed)
+    B, G = 4, 3
+    oracle = build_gpt_ref(1, patch_size=P, block_size=T, with_detector=False, image_processor=None).eval()
+    images = torch.rand(B, 3, G * P, G * P)
+    bboxes = torch.tensor([[[10, 10, 200, 200]]] * B)
+    forced = torch.randint(0, 8, (B, T))
+    start = torch.randint(0, G, (B, 2))
+    times = []
+    for it in range(3):
+        env = env_ref.EnvRef(images, bboxes, P, T, 1, True)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            ro = rollout_ref.rollout(oracle, env, forced_actions=forced, start_positions=start)
+            rollout_ref.reinforce_metrics(ro, 0.01, rollout_ref.ReturnNormaliser())
+        times.append(time.perf_counter() - t0)
+    best = sorted(times)[1] if len(times) >= 3 else min(times)
+    return {"value": round(B * T / best, 2), "unit": "glimpse-patches/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"B=4 agents x T={T} steps, {P}px patches, 3x3-patch images, forced actions, "
+            f"forward rollout + loss, median of 3 ({best:.2f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="agents per GPU")
+    ap.add_argument("--seq-len", type=int, default=20)
+    ap.add_argument("--patch-size", type=int, default=448)
+    ap.add_argument("--grid", type=int, default=10, help="image side in patches")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import jolineedle_amd as ja
+    from tests.helpers import model_config
+
+    B, T, P, G = args.batch, args.seq_len, args.patch_size, args.grid
+    torch.manual_seed(12345)
+    model = ja.GPT(model_config(patch_size=P, block_size=T, with_detector=False, image_processor=None),
+                   max_batch=B, device=f"cuda:{local_rank}")
+    model.sync_weights()
+    cfg = ja.CfgNode(max_seq_len=T, entropy_weight=0.01, stop_enabled=True, reward_norm=True, seed=12345 + rank)
+    trainer = ja.ReinforceTrainer(cfg, model)
+    images, bboxes, start = synth_inputs(B, G, P, 12345 + rank, dev)
+    forced = torch.randint(0, 8, (B, T), generator=torch.Generator().manual_seed(777 + rank)).to(dev)
+    eng = model.engine()
+    eng.lib.jn_set_profiling(eng.handle, 1)
+
+    def one_step():
+        env = ja.NeedleGeneralEnv(images, bboxes, P, T, 1, True, engine=eng)
+        ro = trainer.rollout(env, forced_actions=forced, start_positions=start, keep_patches=False)
+        m = trainer.compute_metrics(ro)
+        return ro["rewards"].shape[1], m["loss"]
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    import ctypes as C
+    for _ in range(args.warmup):
+        one_step()
+    sync()
+    t0 = time.perf_counter()
+    patches, conv_ms = 0, 0.0
+    for _ in range(args.steps):
+        S, loss = one_step()
+        patches += B * S
+        ms = C.c_float()
+        eng.lib.jn_last_timing(eng.handle, 1, C.byref(ms))
+        conv_ms += ms.value
+    sync()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed, float(patches)], device=dev, dtype=torch.float64)
+    if dist is not None:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, total_patches = float(tmax[0]), float(tsum[1])
+    else:
+        total_patches = float(patches)
+
+    if rank == 0:
+        glimpse_steps = args.steps * T
+        conv_ms_per_launch = conv_ms / glimpse_steps          # one PAFPN pass over B patches
+        algo_bytes = NANO_448_ELEMS_PER_PATCH * (P / 448.0) ** 2 * 4.0 * B
+        achieved = algo_bytes / (conv_ms_per_launch * 1e-3) / 1e9
+        out = {
+            "metric": "glimpse-patches/sec (448px, seq-len 20) REINFORCE step",
+            "value": round(total_patches / elapsed, 1), "unit": "glimpse-patches/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[2]/[3]: REINFORCE rollout, gpt-nano + yolox-nano encoder, {P}px, "
+                                   f"seq-len {T}, --enable-stop, {B} agents/GPU x {world} GPU, "
+                                   f"{G * P}x{G * P} synthetic images, forced non-STOP actions (S=T)",
+                       "global_batch": B * world, "seq_len": T,
+                       "phase": "env build + whole-batch rollout (forward, eval-mode BN) + REINFORCE loss; "
+                                "backward/optimizer step not implemented yet in this round",
+                       "parallelism": f"dp{world} (independent agents per rank, no data-path collective)"},
+            "roofline": {"bound": "hbm", "kernel": "yolox-nano PAFPN conv stack (stem/dw3x3/pw_mfma/spp/upsample, "
+                                                   "one pass over the batch per glimpse step)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "ms_per_launch": round(conv_ms_per_launch, 4),
+                         "algorithmic_bytes_per_launch": int(algo_bytes)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(P, T, 12345)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,198 @@
+/*
+ * jnroll.h — C ABI of libjnroll.so, the MI355X (gfx950) glimpse-rollout engine.
+ *
+ * The reference (jolibrain/jolineedle) has no FFI: its boundary for this path is the
+ * Python operator API.  Each entry point below names the reference
+ * interface it sits under (paths relative to /root/reference).  A reference-side
+ * binding is a ctypes stub, shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C types only; `*_dev` pointers are HIP device pointers owned by the caller
+ *    (e.g. torch tensors' data_ptr()); `stream` is a hipStream_t passed as void*
+ *    (NULL = the legacy default stream).
+ *  - every function returns 0 on success or a negative JN_E* code; jn_last_error()
+ *    gives the message of the calling thread's last failure.  No exceptions cross.
+ *  - no hidden host synchronisation: only functions documented as "synchronises"
+ *    wait for the device.
+ *  - activations are fp32 (the reference is fp32 end to end); tensors exchanged at
+ *    the boundary keep the reference's layouts (NCHW images/patches, [B,T] rows).
+ */
+#ifndef JNROLL_H
+#define JNROLL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JN_ABI_VERSION 1
+
+enum {
+  JN_OK = 0,
+  JN_EINVAL = -1,    /* bad argument / shape / state                     */
+  JN_ENOMEM = -2,    /* device or host allocation failed                 */
+  JN_EHIP = -3,      /* a HIP runtime call failed                        */
+  JN_ENOTFOUND = -4, /* a required state-dict entry is missing           */
+  JN_ESTATE = -5     /* call order violated (e.g. rollout before weights) */
+};
+
+/* Action-selection modes of jn_rollout (src/reinforce.py:73-90). */
+enum { JN_MODE_GREEDY = 0, JN_MODE_SAMPLE = 1, JN_MODE_FORCED = 2 };
+
+/* Which conv network a call addresses. */
+enum { JN_NET_GPT_BACKBONE = 0, JN_NET_DETECTOR = 1 };
+
+typedef struct jn_ctx jn_ctx;
+
+/* Mirrors the fields of the reference's model_config / train_config that shape the
+ * path (main.py:310-388; src/models/gpt.py:162-329).  Zero-initialise, set
+ * struct_size = sizeof(jn_config). */
+typedef struct jn_config {
+  int32_t struct_size;
+  int32_t device;               /* HIP device ordinal                                   */
+  /* decision transformer: gpt.py:190-218 zoo entry already resolved */
+  int32_t n_layer, n_head, n_embd;
+  int32_t block_size;           /* max_seq_len T (tokens = T + 1 with the class token)  */
+  int32_t n_actions;            /* 9 with --enable-stop else 8 (src/env/common.py:48-56) */
+  int32_t patch_size;           /* P                                                    */
+  int32_t use_pos_emb;          /* --use-positional-embedding                           */
+  int32_t no_patch_emb;         /* --no-patch-embedding                                 */
+  int32_t concat_emb;           /* --concat-embeddings                                  */
+  int32_t decoder_pos_encoding; /* --decoder-pos-encoding                               */
+  int32_t pos_emb_size;         /* rows of transformer.wpe (main.py:378)                */
+  /* patch encoder `gpt_backbone` (gpt.py:261-264); width 0 = absent, the detector's
+   * PAFPN encodes patches instead (gpt.py:376-380) */
+  float gpt_bb_depth, gpt_bb_width;
+  int32_t gpt_bb_depthwise;
+  /* detector `yolox` (gpt.py:251-259); with_detector 0 = decision-only context */
+  int32_t with_detector;
+  float det_depth, det_width;
+  int32_t det_depthwise;
+  float det_conf_threshold;     /* --detector-conf-threshold                            */
+  float det_nms_threshold;      /* yolox postprocess default 0.45                       */
+  int32_t max_batch;            /* capacity B of env / rollout workspaces               */
+  int32_t max_det_per_patch;    /* cap of kept boxes per patch (ragged output rows)     */
+} jn_config;
+
+/* One state-dict entry (names of SURVEY.md §5, e.g. "gpt_backbone.backbone.stem.conv.bn.weight"). */
+typedef struct jn_tensor {
+  const char* name;
+  const void* data;   /* HOST pointer, contiguous                      */
+  int32_t dtype;      /* 0 = float32, 1 = int64                        */
+  int32_t ndim;
+  int64_t shape[4];
+} jn_tensor;
+
+typedef struct jn_param_info {
+  char name[160];
+  int32_t dtype;      /* 0 = float32, 1 = int64                        */
+  int32_t ndim;
+  int64_t shape[4];
+  int32_t is_buffer;  /* 1 = registered buffer (running stats, masks)  */
+  int32_t used;       /* 0 = listed for state-dict compatibility only  */
+} jn_param_info;
+
+/* Outputs of one rollout: ReinforceTrainer.rollout's dict (src/reinforce.py:204-215).
+ * All pointers are device memory sized for T = block_size steps; entries past
+ * `n_steps` (read with jn_rollout_steps) are zero/false.  NULL = not wanted. */
+typedef struct jn_rollout_out {
+  float* rewards_dev;        /* [B, T]                                          */
+  float* returns_dev;        /* [B, T]                                          */
+  float* logprobs_dev;       /* [B, T]                                          */
+  float* entropies_dev;      /* [B, T]                                          */
+  uint8_t* masks_dev;        /* [B, T+1]                                        */
+  uint8_t* logit_masks_dev;  /* [B, T]                                          */
+  int64_t* positions_dev;    /* [B, T+1, 2] (y, x)                              */
+  int64_t* actions_dev;      /* [B, T]   actions taken                          */
+  float* logits_dev;         /* [B, T, n_actions] last-token logits per step    */
+  float* final_emb_dev;      /* [B, T+1, n_embd] token embeddings (gpt.py:534)  */
+  float* patches_dev;        /* [B, T+1, 3, P, P] or NULL                       */
+  float* det_boxes_dev;      /* [B, T+1, max_det_per_patch, 7] or NULL          */
+  int32_t* det_counts_dev;   /* [B, T+1] kept boxes per patch (0 = reference None) */
+} jn_rollout_out;
+
+/* ---- lifetime ------------------------------------------------------------------ */
+int jn_abi_version(void);
+const char* jn_last_error(void);
+/* GPT.__init__ (src/models/gpt.py:162-329): builds the layer plan and workspaces. */
+int jn_create(const jn_config* cfg, jn_ctx** out);
+int jn_destroy(jn_ctx* ctx);
+
+/* ---- weights: nn.Module.state_dict()/load_state_dict of GPT (main.py:532-584) ---- */
+int jn_param_count(const jn_ctx* ctx);
+int jn_param_info_at(const jn_ctx* ctx, int index, jn_param_info* out);
+/* Uploads and pre-packs (BN folded for eval, Linear weights transposed).  Entries the
+ * path does not use are ignored; a missing used entry -> JN_ENOTFOUND.  Synchronises. */
+int jn_load_weights(jn_ctx* ctx, const jn_tensor* tensors, size_t n);
+
+/* ---- environment: NeedleGeneralEnv (src/env/general_env.py) ----------------------- */
+/* __init__ :15-82 + convert_bboxes_to_masks :360-379.  images [B,3,H,W] f32 stay owned
+ * by the caller and must outlive the env; bboxes [B,nb,4] int64 xyxy (zero rows = pad). */
+int jn_env_init(jn_ctx* ctx, const float* images_dev, const int64_t* bboxes_dev,
+                int B, int H, int W, int nb, int max_ep_len, int stop_enabled, void* stream);
+/* reset :144-170.  positions [B,2] (y,x) int64 or NULL = uniform draw from `seed`. */
+int jn_env_reset(jn_ctx* ctx, const int64_t* positions_dev, uint64_t seed, void* stream);
+/* step :172-233 + rewards :321-358 + terminated :235-246.  Outputs may be NULL. */
+int jn_env_step(jn_ctx* ctx, const int64_t* actions_dev, float* rewards_dev,
+                uint8_t* terminated_dev, uint8_t* truncated_dev, void* stream);
+/* State views (device pointers into the context, valid until jn_env_init/jn_destroy):
+ * what = 0 positions int64 [B,2]; 1 bbox_masks u8 [B,Gh,Gw]; 2 visited u8 [B,Gh,Gw];
+ * 3 steps int32 [B]; 4 has_stopped u8 [B]. */
+int jn_env_state(jn_ctx* ctx, int what, void** ptr_dev);
+/* `patches` property :285-306 — bit-exact strided copy of the current patches
+ * -> out [B,3,P,P] f32. */
+int jn_env_patches(jn_ctx* ctx, float* out_dev, void* stream);
+/* Stand-alone gather (no context state): out[b] = images[b,:,y*P:(y+1)*P, x*P:(x+1)*P]. */
+int jn_gather_patches(const float* images_dev, const int64_t* positions_dev, float* out_dev,
+                      int B, int C, int H, int W, int P, void* stream);
+
+/* ---- networks ------------------------------------------------------------------- */
+/* YOLOPAFPN.forward as called at src/models/gpt.py:375 / src/models/yolox.py:55 (eval-mode
+ * BN).  patches [N,3,P,P] f32 NCHW; fpn outputs NCHW f32 ([N,c,P/8,P/8], /16, /32),
+ * any may be NULL. */
+int jn_backbone_forward(jn_ctx* ctx, int net, const float* patches_dev, int N,
+                        float* fpn0_dev, float* fpn1_dev, float* fpn2_dev, void* stream);
+/* GPT.embed_patches (src/models/gpt.py:356-384): patches [N,3,P,P] -> [N, n_embd]. */
+int jn_embed_patches(jn_ctx* ctx, const float* patches_dev, int N, float* out_dev, void* stream);
+/* GPT.forward (src/models/gpt.py:481-534), eval mode.  patches [B,T,3,P,P] f32 (NULL with
+ * no_patch_emb), actions [B,T] int64, positions [B,T,2] int64 (y,x; NULL unless use_pos_emb),
+ * prev_embeddings [B,Tp,C] or NULL.  Without prev_embeddings all T tokens are embedded
+ * (1-D positions 0..T-1); with it only the last one is (1-D position 0, the reference's
+ * recurrent quirk gpt.py:431-449) and appended.  L = prev ? Tp+1 : T+1.
+ * Outputs: logits [B, L-1, n_actions], final_emb [B, L, n_embd] (either may be NULL). */
+int jn_gpt_forward(jn_ctx* ctx, const float* patches_dev, const int64_t* actions_dev,
+                   const int64_t* positions_dev, const float* prev_emb_dev, int B, int T, int Tp,
+                   float* logits_dev, float* final_emb_dev, void* stream);
+/* NeedleYOLOX.forward inference branch (src/models/yolox.py:24-57, 74-113): boxes
+ * [N, max_det_per_patch, 7] (x1,y1,x2,y2,obj,cls,cls_id; clamped to [0,P-1]) + counts [N];
+ * raw_dev optional [N, A, 6] decoded head output before postprocess. */
+int jn_detect(jn_ctx* ctx, const float* patches_dev, int N, float* boxes_dev,
+              int32_t* counts_dev, float* raw_dev, void* stream);
+
+/* ---- the hot loop ----------------------------------------------------------------- */
+/* ReinforceTrainer.rollout (src/reinforce.py:108-215) for the env set by jn_env_init:
+ * reset (positions NULL = random from seed), then up to T steps of
+ * patch-encode -> GPT decode (KV cache) -> action select -> env step [-> detect],
+ * all enqueued on `stream` with no host synchronisation; the returns/logit_masks
+ * epilogue (:186-202) runs on device too.  forced_actions [B,T] int64 for JN_MODE_FORCED.
+ * stop_early != 0 reproduces the reference's `break` when every env is done (:181-184):
+ * later steps become no-ops on device. */
+int jn_rollout(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev,
+               const int64_t* start_positions_dev, uint64_t seed, int do_detection,
+               int stop_early, const jn_rollout_out* out, void* stream);
+/* Number of steps S the last rollout executed (reference tensor width).  Synchronises
+ * on `stream`. */
+int jn_rollout_steps(jn_ctx* ctx, int* n_steps, void* stream);
+
+/* Wall-clock helpers for bench.py: HIP-event time of the most recent jn_rollout on its
+ * stream, split per kernel family.  what = 0 total ms, 1 backbone conv ms. Synchronises. */
+int jn_last_timing(jn_ctx* ctx, int what, float* ms);
+/* Enables HIP-event bracketing of the backbone conv section (costs two events/step). */
+int jn_set_profiling(jn_ctx* ctx, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JNROLL_H */

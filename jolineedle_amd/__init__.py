@@ -1,0 +1,18 @@
+"""jolineedle_amd — MI355X-native glimpse-rollout engine behind JoliNeedle's operator API.
+
+Python mirror of the reference interface for the rollout hot path:
+``GPT``, ``NeedleYOLOX``, ``NeedleGeneralEnv``, ``ReinforceTrainer.rollout`` with the
+reference's names, argument meaning and error behaviour, over the C ABI of
+``libjnroll.so`` (include/jnroll.h).  There is no CPU fallback: the HIP library must be
+built (``python -c 'import __graft_entry__ as g; g.build()'``) and a GPU present.
+"""
+from .common import Action, ACTION_DELTAS, ActionInfo, get_actions_info  # noqa: F401
+from .config import CfgNode, get_args, args_to_config  # noqa: F401
+from ._lib import load_library, LibraryNotBuilt  # noqa: F401
+from .gpt import GPT  # noqa: F401
+from .env import NeedleGeneralEnv  # noqa: F401
+from .yolox import NeedleYOLOX  # noqa: F401
+from .reinforce import ReinforceTrainer  # noqa: F401
+
+__all__ = ["GPT", "NeedleYOLOX", "NeedleGeneralEnv", "ReinforceTrainer", "Action", "ACTION_DELTAS",
+           "ActionInfo", "get_actions_info", "CfgNode", "get_args", "args_to_config", "load_library"]

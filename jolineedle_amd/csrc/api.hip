@@ -1,0 +1,825 @@
+// C ABI of libjnroll.so: context, weight packing, env, networks and the rollout loop.
+// Host code only (compiled by hipcc as C++); kernels live in kernels_*.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <memory>
+
+#include "jn_internal.h"
+
+namespace jnr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int build_pafpn(Net& net, std::vector<ParamEntry>& params, const std::string& prefix, float depth, float width,
+                bool depthwise, int P);
+void add_head_params(std::vector<ParamEntry>& params, std::vector<ConvW>& convs, const std::string& prefix,
+                     float width, bool depthwise, int num_classes);
+
+namespace {
+
+void add_param(std::vector<ParamEntry>& params, const std::string& name, std::initializer_list<int64_t> shape,
+               int dtype, bool buffer, bool used) {
+  ParamEntry e;
+  std::memset(&e, 0, sizeof(e));
+  std::snprintf(e.info.name, sizeof(e.info.name), "%s", name.c_str());
+  e.info.dtype = dtype;
+  e.info.ndim = (int)shape.size();
+  int i = 0;
+  for (auto s : shape) e.info.shape[i++] = s;
+  e.info.is_buffer = buffer;
+  e.info.used = used;
+  params.push_back(e);
+}
+
+template <typename T>
+int dev_alloc(jn_ctx* ctx, T** out, size_t count) {
+  void* p = nullptr;
+  if (count == 0) count = 1;
+  hipError_t e = hipMalloc(&p, count * sizeof(T));
+  if (e != hipSuccess) {
+    set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    return JN_ENOMEM;
+  }
+  ctx->owned.push_back(p);
+  *out = (T*)p;
+  return JN_OK;
+}
+
+int dev_upload(jn_ctx* ctx, float** out, const std::vector<float>& host) {
+  int rc = dev_alloc(ctx, out, host.size());
+  if (rc) return rc;
+  JN_HIP(hipMemcpy(*out, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  return JN_OK;
+}
+
+struct TensorMap {
+  std::map<std::string, const jn_tensor*> m;
+  const float* f32(const std::string& name, size_t numel) const {
+    auto it = m.find(name);
+    if (it == m.end()) { set_error("state-dict entry '%s' is missing", name.c_str()); return nullptr; }
+    const jn_tensor* t = it->second;
+    size_t n = 1;
+    for (int i = 0; i < t->ndim; ++i) n *= (size_t)t->shape[i];
+    if (t->dtype != 0 || n != numel) {
+      set_error("state-dict entry '%s' has %zu elements / dtype %d, expected %zu float32", name.c_str(), n, t->dtype, numel);
+      return nullptr;
+    }
+    return (const float*)t->data;
+  }
+};
+
+// BatchNorm2d(eps=1e-3) in eval mode folded into the preceding bias-free conv
+// (YOLOX BaseConv): scale = gamma / sqrt(var + eps), bias = beta - mean * scale.
+constexpr float kBnEps = 1e-3f;
+
+int fold_scale_bias(const TensorMap& tm, const ConvW& cw, std::vector<float>& scale, std::vector<float>& bias) {
+  const int co = cw.cout;
+  scale.assign(co, 1.0f);
+  bias.assign(co, 0.0f);
+  if (cw.has_bn) {
+    const float* g = tm.f32(cw.prefix + ".bn.weight", co);
+    const float* b = tm.f32(cw.prefix + ".bn.bias", co);
+    const float* mu = tm.f32(cw.prefix + ".bn.running_mean", co);
+    const float* var = tm.f32(cw.prefix + ".bn.running_var", co);
+    if (!g || !b || !mu || !var) return JN_ENOTFOUND;
+    for (int o = 0; o < co; ++o) {
+      scale[o] = g[o] / std::sqrt(var[o] + kBnEps);
+      bias[o] = b[o] - mu[o] * scale[o];
+    }
+  } else if (cw.has_bias) {
+    const float* b = tm.f32(cw.prefix + ".bias", co);
+    if (!b) return JN_ENOTFOUND;
+    for (int o = 0; o < co; ++o) bias[o] = b[o];
+  }
+  return JN_OK;
+}
+
+int pack_conv(jn_ctx* ctx, const TensorMap& tm, ConvW& cw, OpKind kind) {
+  std::vector<float> scale, bias;
+  int rc = fold_scale_bias(tm, cw, scale, bias);
+  if (rc) return rc;
+  const int cig = cw.cin / cw.groups;
+  const std::string wname = cw.prefix + (cw.has_bn ? ".conv.weight" : ".weight");
+  const float* w = tm.f32(wname, (size_t)cw.cout * cig * cw.k * cw.k);
+  if (!w) return JN_ENOTFOUND;
+  std::vector<float> packed;
+  if (kind == OP_STEM) {
+    // [oc][q*3 + c][ky][kx] (Focus order TL, BL, TR, BR: q = py + 2*px)  ->  [(c*6+dy)*6+dx][oc]
+    packed.assign((size_t)108 * cw.cout, 0.0f);
+    for (int oc = 0; oc < cw.cout; ++oc)
+      for (int c = 0; c < 3; ++c)
+        for (int dy = 0; dy < 6; ++dy)
+          for (int dx = 0; dx < 6; ++dx) {
+            const int ky = dy >> 1, py = dy & 1, kx = dx >> 1, px = dx & 1, q = py + 2 * px;
+            packed[(size_t)((c * 6 + dy) * 6 + dx) * cw.cout + oc] =
+                w[(((size_t)oc * 12 + q * 3 + c) * 3 + ky) * 3 + kx] * scale[oc];
+          }
+  } else if (kind == OP_DW) {
+    packed.resize((size_t)9 * cw.cout);
+    for (int c = 0; c < cw.cout; ++c)
+      for (int t = 0; t < 9; ++t) packed[(size_t)t * cw.cout + c] = w[(size_t)c * 9 + t] * scale[c];
+  } else if (kind == OP_PW) {
+    packed.resize((size_t)cw.cout * cw.cin);
+    for (int o = 0; o < cw.cout; ++o)
+      for (int k = 0; k < cw.cin; ++k) packed[(size_t)o * cw.cin + k] = w[(size_t)o * cw.cin + k] * scale[o];
+  } else if (kind == OP_CONV3) {
+    // [tap][oc][cin]: every tap is a 1x1 GEMM weight
+    packed.resize((size_t)9 * cw.cout * cw.cin);
+    for (int o = 0; o < cw.cout; ++o)
+      for (int k = 0; k < cw.cin; ++k)
+        for (int t = 0; t < 9; ++t)
+          packed[((size_t)t * cw.cout + o) * cw.cin + k] = w[((size_t)o * cw.cin + k) * 9 + t] * scale[o];
+  } else {
+    return JN_OK;
+  }
+  rc = dev_upload(ctx, &cw.w_dev, packed);
+  if (rc) return rc;
+  return dev_upload(ctx, &cw.b_dev, bias);
+}
+
+// Linear weight [out][in] -> transposed [in][out]
+std::vector<float> transpose(const float* w, int out, int in) {
+  std::vector<float> t((size_t)out * in);
+  for (int o = 0; o < out; ++o)
+    for (int i = 0; i < in; ++i) t[(size_t)i * out + o] = w[(size_t)o * in + i];
+  return t;
+}
+
+int upload_raw(jn_ctx* ctx, const TensorMap& tm, const std::string& name, size_t n, float** out) {
+  const float* p = tm.f32(name, n);
+  if (!p) return JN_ENOTFOUND;
+  return dev_upload(ctx, out, std::vector<float>(p, p + n));
+}
+int upload_t(jn_ctx* ctx, const TensorMap& tm, const std::string& name, int out_f, int in_f, float** out) {
+  const float* p = tm.f32(name, (size_t)out_f * in_f);
+  if (!p) return JN_ENOTFOUND;
+  return dev_upload(ctx, out, transpose(p, out_f, in_f));
+}
+
+// get_emb(pos * inv_freq) of positional_encodings >= 6 (interleaved sin, cos), SURVEY.md §2.2
+std::vector<float> sinusoid_row(int pos, int channels) {
+  std::vector<float> r(channels);
+  for (int i = 0; i < channels; i += 2) {
+    const float inv_freq = 1.0f / std::pow(10000.0f, (float)i / (float)channels);
+    const float ang = (float)pos * inv_freq;
+    r[i] = std::sin(ang);
+    if (i + 1 < channels) r[i + 1] = std::cos(ang);
+  }
+  return r;
+}
+
+int n_parts(const jn_config& c) { return 2 + (c.no_patch_emb ? 0 : 1) + (c.use_pos_emb ? 1 : 0); }
+
+}  // namespace
+
+// Workspace base of buffer `buf` for a batch capacity of max_batch images.
+static inline float* buf_base(const Net& net, float* ws, int buf, int max_batch) {
+  return ws + net.buf_off[buf] * (size_t)max_batch;
+}
+
+}  // namespace jnr
+
+using namespace jnr;
+
+
+extern "C" {
+
+int jn_abi_version(void) { return JN_ABI_VERSION; }
+const char* jn_last_error(void) { return jnr::g_err; }
+
+int jn_create(const jn_config* cfg, jn_ctx** out) {
+  JN_CHECK(cfg && out, JN_EINVAL, "jn_create: null argument");
+  JN_CHECK(cfg->struct_size == (int)sizeof(jn_config), JN_EINVAL, "jn_config.struct_size %d != %zu", cfg->struct_size,
+           sizeof(jn_config));
+  JN_CHECK(cfg->n_embd > 0 && cfg->n_embd % 4 == 0 && cfg->n_embd <= 256, JN_EINVAL,
+           "n_embd %d unsupported (multiple of 4, <= 256)", cfg->n_embd);
+  JN_CHECK(cfg->n_head > 0 && cfg->n_embd % cfg->n_head == 0, JN_EINVAL, "n_embd %% n_head != 0");
+  JN_CHECK(cfg->n_actions == 8 || cfg->n_actions == 9, JN_EINVAL, "n_actions must be 8 or 9");
+  JN_CHECK(cfg->block_size >= 1 && cfg->block_size <= 255, JN_EINVAL, "block_size out of range");
+  JN_CHECK(cfg->max_batch >= 1, JN_EINVAL, "max_batch must be >= 1");
+  JN_CHECK(cfg->gpt_bb_width > 0 || cfg->with_detector || cfg->no_patch_emb, JN_EINVAL,
+           "no patch encoder: set gpt_bb_width or with_detector (or no_patch_emb)");
+  std::unique_ptr<jn_ctx> ctx(new jn_ctx());
+  ctx->cfg = *cfg;
+  if (ctx->cfg.det_nms_threshold <= 0) ctx->cfg.det_nms_threshold = 0.45f;
+  if (ctx->cfg.max_det_per_patch <= 0) ctx->cfg.max_det_per_patch = 64;
+  const int C = cfg->n_embd, nA = cfg->n_actions;
+  auto& P = ctx->params;
+  // ---- state-dict table in the reference's construction order (src/models/gpt.py:221-318) ----
+  add_param(P, "action_head.lm_heads.0.weight", {nA, C}, 0, false, true);
+  {
+    const int ch2 = (int)std::ceil(C / 4.0) * 2;
+    add_param(P, "positional_encoding.inv_freq", {(ch2 + 1) / 2}, 0, true, false);
+    if (cfg->decoder_pos_encoding) {
+      const int ch1 = (int)std::ceil(C / 2.0) * 2;
+      add_param(P, "decoder_token_pos_enc.inv_freq", {ch1 / 2}, 0, true, false);
+    }
+  }
+  add_param(P, "embed_class.weight", {100, C}, 0, false, true);
+  if (cfg->concat_emb) {
+    add_param(P, "project_concat.weight", {C, (int64_t)n_parts(*cfg) * C}, 0, false, true);
+    add_param(P, "project_concat.bias", {C}, 0, false, true);
+  }
+  int rc;
+  if (cfg->with_detector) {
+    rc = build_pafpn(ctx->nets[JN_NET_DETECTOR], P, "yolox.backbone.", cfg->det_depth, cfg->det_width,
+                     cfg->det_depthwise != 0, cfg->patch_size);
+    if (rc) return rc;
+    ctx->has_net[JN_NET_DETECTOR] = true;
+    std::vector<ConvW> head_convs;
+    add_head_params(P, head_convs, "yolox.head.", cfg->det_width, cfg->det_depthwise != 0, 1);
+  }
+  if (cfg->gpt_bb_width > 0) {
+    rc = build_pafpn(ctx->nets[JN_NET_GPT_BACKBONE], P, "gpt_backbone.", cfg->gpt_bb_depth, cfg->gpt_bb_width,
+                     cfg->gpt_bb_depthwise != 0, cfg->patch_size);
+    if (rc) return rc;
+    ctx->has_net[JN_NET_GPT_BACKBONE] = true;
+    ctx->enc_net = JN_NET_GPT_BACKBONE;
+  } else {
+    ctx->enc_net = JN_NET_DETECTOR;
+  }
+  if (!cfg->no_patch_emb) {
+    const Net& enc = ctx->nets[ctx->enc_net];
+    ctx->efpn_cin = enc.fpn[2].C; ctx->efpn_h = enc.fpn[2].H; ctx->efpn_w = enc.fpn[2].W;
+    add_param(P, "embed_fpn.0.weight", {C, ctx->efpn_cin, 1, 1}, 0, false, true);
+    add_param(P, "embed_fpn.3.weight", {C, (int64_t)ctx->efpn_h * ctx->efpn_w * C}, 0, false, true);
+    add_param(P, "embed_fpn.3.bias", {C}, 0, false, true);
+  }
+  add_param(P, "transformer.wte.weight", {nA, C}, 0, false, true);
+  add_param(P, "transformer.wpe.weight", {cfg->pos_emb_size > 0 ? cfg->pos_emb_size : 1, C}, 0, false,
+            !cfg->decoder_pos_encoding);
+  const int bs1 = cfg->block_size + 1;
+  for (int l = 0; l < cfg->n_layer; ++l) {
+    const std::string p = "transformer.h." + std::to_string(l) + ".";
+    add_param(P, p + "ln_1.weight", {C}, 0, false, true);
+    add_param(P, p + "ln_1.bias", {C}, 0, false, true);
+    add_param(P, p + "attn.c_attn.weight", {3 * C, C}, 0, false, true);
+    add_param(P, p + "attn.c_attn.bias", {3 * C}, 0, false, true);
+    add_param(P, p + "attn.c_proj.weight", {C, C}, 0, false, true);
+    add_param(P, p + "attn.c_proj.bias", {C}, 0, false, true);
+    add_param(P, p + "attn.bias", {1, 1, bs1, bs1}, 0, true, false);
+    add_param(P, p + "ln_2.weight", {C}, 0, false, true);
+    add_param(P, p + "ln_2.bias", {C}, 0, false, true);
+    add_param(P, p + "mlp.c_fc.weight", {4 * C, C}, 0, false, true);
+    add_param(P, p + "mlp.c_fc.bias", {4 * C}, 0, false, true);
+    add_param(P, p + "mlp.c_proj.weight", {C, 4 * C}, 0, false, true);
+    add_param(P, p + "mlp.c_proj.bias", {C}, 0, false, true);
+  }
+  add_param(P, "transformer.ln_f.weight", {C}, 0, false, true);
+  add_param(P, "transformer.ln_f.bias", {C}, 0, false, true);
+  *out = ctx.release();
+  return JN_OK;
+}
+
+int jn_destroy(jn_ctx* ctx) {
+  if (!ctx) return JN_OK;
+  (void)hipSetDevice(ctx->cfg.device);
+  (void)hipDeviceSynchronize();
+  for (void* p : ctx->owned) (void)hipFree(p);
+  for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ctx->conv_ev) (void)hipEventDestroy(e);
+  delete ctx;
+  return JN_OK;
+}
+
+int jn_param_count(const jn_ctx* ctx) { return ctx ? (int)ctx->params.size() : JN_EINVAL; }
+
+int jn_param_info_at(const jn_ctx* ctx, int index, jn_param_info* out) {
+  JN_CHECK(ctx && out && index >= 0 && index < (int)ctx->params.size(), JN_EINVAL, "jn_param_info_at: bad index %d", index);
+  *out = ctx->params[index].info;
+  return JN_OK;
+}
+
+// Device-side workspaces; allocated on the first jn_load_weights (needs a GPU).
+static int alloc_workspaces(jn_ctx* ctx) {
+  jn_ctx& x = *ctx;
+  const jn_config& c = ctx->cfg;
+  const int B = c.max_batch, C = c.n_embd;
+  int rc;
+  for (int n = 0; n < 2; ++n) {
+    if (!ctx->has_net[n]) continue;
+    rc = dev_alloc(ctx, &x.net_ws[n], ctx->nets[n].per_image_floats * (size_t)B);
+    if (rc) return rc;
+  }
+  const int Tmax = c.block_size + 1;
+  if ((rc = dev_alloc(ctx, &ctx->kcache, (size_t)c.n_layer * B * Tmax * C))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->vcache, (size_t)c.n_layer * B * Tmax * C))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->n_done, (size_t)Tmax + 1))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->prev_action, (size_t)B))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->cache_len, (size_t)B))) return rc;
+  if ((rc = dev_alloc(ctx, &x.emb_part, (size_t)B * x.KS * C))) return rc;
+  if (!c.no_patch_emb)
+    if ((rc = dev_alloc(ctx, &ctx->efpn_act, (size_t)B * ctx->efpn_h * ctx->efpn_w * C))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->patch_emb, (size_t)B * C))) return rc;
+  if ((rc = dev_upload(ctx, &x.zero_bias, std::vector<float>(1024, 0.0f)))) return rc;
+  JN_HIP(hipMemset(ctx->n_done, 0, ((size_t)Tmax + 1) * sizeof(int32_t)));
+  for (auto& e : ctx->ev) JN_HIP(hipEventCreate(&e));
+  return JN_OK;
+}
+
+int jn_load_weights(jn_ctx* ctx, const jn_tensor* tensors, size_t n) {
+  JN_CHECK(ctx && tensors, JN_EINVAL, "jn_load_weights: null argument");
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  TensorMap tm;
+  for (size_t i = 0; i < n; ++i) tm.m[tensors[i].name] = &tensors[i];
+  int rc;
+  if (!ctx->act_ws) {
+    if ((rc = alloc_workspaces(ctx))) return rc;
+    ctx->act_ws = ctx->net_ws[ctx->enc_net];
+  }
+  const jn_config& c = ctx->cfg;
+  const int C = c.n_embd, nA = c.n_actions;
+  for (int ni = 0; ni < 2; ++ni) {
+    if (!ctx->has_net[ni]) continue;
+    Net& net = ctx->nets[ni];
+    for (const Op& op : net.ops) {
+      if (op.wslot < 0) continue;
+      if ((rc = pack_conv(ctx, tm, net.convs[op.wslot], op.kind))) return rc;
+    }
+  }
+  GptW& g = ctx->gpt;
+  if ((rc = upload_raw(ctx, tm, "transformer.wte.weight", (size_t)nA * C, &g.wte))) return rc;
+  if (!c.decoder_pos_encoding) {
+    if ((rc = upload_raw(ctx, tm, "transformer.wpe.weight", (size_t)std::max(c.pos_emb_size, 1) * C, &g.wpe))) return rc;
+  }
+  if ((rc = upload_raw(ctx, tm, "embed_class.weight", (size_t)100 * C, &g.embed_class))) return rc;
+  if (c.concat_emb) {
+    if ((rc = upload_t(ctx, tm, "project_concat.weight", C, n_parts(c) * C, &g.proj_wt))) return rc;
+    if ((rc = upload_raw(ctx, tm, "project_concat.bias", C, &g.proj_b))) return rc;
+  }
+  {
+    const int ch1 = (int)std::ceil(C / 2.0) * 2;
+    const int Tmax = c.block_size + 1;
+    std::vector<float> p1((size_t)Tmax * C);
+    for (int t = 0; t < Tmax; ++t) {
+      std::vector<float> r = sinusoid_row(t, ch1);
+      std::copy(r.begin(), r.begin() + C, p1.begin() + (size_t)t * C);
+    }
+    if ((rc = dev_upload(ctx, &g.pos1d, p1))) return rc;
+    const int ch2 = (int)std::ceil(C / 4.0) * 2;
+    std::vector<float> tab((size_t)256 * ch2);
+    for (int p = 0; p < 256; ++p) {
+      std::vector<float> r = sinusoid_row(p, ch2);
+      std::copy(r.begin(), r.end(), tab.begin() + (size_t)p * ch2);
+    }
+    if ((rc = dev_upload(ctx, &g.pos2d_col, tab))) return rc;
+  }
+  if (!c.no_patch_emb) {
+    if ((rc = upload_raw(ctx, tm, "embed_fpn.0.weight", (size_t)C * ctx->efpn_cin, &g.efpn_w))) return rc;
+    const int HW = ctx->efpn_h * ctx->efpn_w;
+    const float* lw = tm.f32("embed_fpn.3.weight", (size_t)C * HW * C);
+    if (!lw) return JN_ENOTFOUND;
+    // Flatten order of the reference is (c, h, w) (nn.Flatten on NCHW, gpt.py:304); ours is (h, w, c).
+    std::vector<float> wt((size_t)HW * C * C);
+    for (int o = 0; o < C; ++o)
+      for (int ch = 0; ch < C; ++ch)
+        for (int p = 0; p < HW; ++p) wt[((size_t)p * C + ch) * C + o] = lw[(size_t)o * HW * C + (size_t)ch * HW + p];
+    if ((rc = dev_upload(ctx, &g.efpn_lin_wt, wt))) return rc;
+    if ((rc = upload_raw(ctx, tm, "embed_fpn.3.bias", C, &g.efpn_lin_b))) return rc;
+  }
+  if ((rc = upload_t(ctx, tm, "action_head.lm_heads.0.weight", nA, C, &g.head_wt))) return rc;
+  if ((rc = upload_raw(ctx, tm, "transformer.ln_f.weight", C, &g.lnf_w))) return rc;
+  if ((rc = upload_raw(ctx, tm, "transformer.ln_f.bias", C, &g.lnf_b))) return rc;
+  g.layers.resize(c.n_layer);
+  std::vector<GptLayerPtrs> lp(c.n_layer);
+  for (int l = 0; l < c.n_layer; ++l) {
+    const std::string p = "transformer.h." + std::to_string(l) + ".";
+    GptW::Layer& L = g.layers[l];
+    if ((rc = upload_raw(ctx, tm, p + "ln_1.weight", C, &L.ln1_w))) return rc;
+    if ((rc = upload_raw(ctx, tm, p + "ln_1.bias", C, &L.ln1_b))) return rc;
+    if ((rc = upload_t(ctx, tm, p + "attn.c_attn.weight", 3 * C, C, &L.qkv_wt))) return rc;
+    if ((rc = upload_raw(ctx, tm, p + "attn.c_attn.bias", 3 * C, &L.qkv_b))) return rc;
+    if ((rc = upload_t(ctx, tm, p + "attn.c_proj.weight", C, C, &L.proj_wt))) return rc;
+    if ((rc = upload_raw(ctx, tm, p + "attn.c_proj.bias", C, &L.proj_b))) return rc;
+    if ((rc = upload_raw(ctx, tm, p + "ln_2.weight", C, &L.ln2_w))) return rc;
+    if ((rc = upload_raw(ctx, tm, p + "ln_2.bias", C, &L.ln2_b))) return rc;
+    if ((rc = upload_t(ctx, tm, p + "mlp.c_fc.weight", 4 * C, C, &L.fc_wt))) return rc;
+    if ((rc = upload_raw(ctx, tm, p + "mlp.c_fc.bias", 4 * C, &L.fc_b))) return rc;
+    if ((rc = upload_t(ctx, tm, p + "mlp.c_proj.weight", C, 4 * C, &L.fc2_wt))) return rc;
+    if ((rc = upload_raw(ctx, tm, p + "mlp.c_proj.bias", C, &L.fc2_b))) return rc;
+    lp[l] = GptLayerPtrs{L.ln1_w, L.ln1_b, L.qkv_wt, L.qkv_b, L.proj_wt, L.proj_b,
+                         L.ln2_w, L.ln2_b, L.fc_wt, L.fc_b, L.fc2_wt, L.fc2_b};
+  }
+  {
+    GptLayerPtrs* d = nullptr;
+    if ((rc = dev_alloc(ctx, &d, (size_t)c.n_layer))) return rc;
+    JN_HIP(hipMemcpy(d, lp.data(), lp.size() * sizeof(GptLayerPtrs), hipMemcpyHostToDevice));
+    ctx->layers_dev = d;
+  }
+  JN_HIP(hipDeviceSynchronize());
+  ctx->weights_loaded = true;
+  return JN_OK;
+}
+
+// ---- network execution ---------------------------------------------------------------
+struct StemSrc {
+  const float* src; const int64_t* positions; long long sample_stride, chan_stride; int row_stride;
+};
+
+static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, const int* skip_flag, int skip_when,
+                   hipStream_t s) {
+  Net& net = ctx->nets[ni];
+  float* ws = ctx->net_ws[ni];
+  const int MB = ctx->cfg.max_batch;
+  auto ptr = [&](const View& v) { return buf_base(net, ws, v.buf, MB) + v.coff; };
+  auto ld = [&](const View& v) { return net.bufs[v.buf].C; };
+  for (const Op& op : net.ops) {
+    switch (op.kind) {
+      case OP_STEM: {
+        const ConvW& cw = net.convs[op.wslot];
+        StemArgs a{ss.src, ss.positions, ss.sample_stride, ss.chan_stride, ss.row_stride, net.P, N, cw.cout,
+                   cw.w_dev, cw.b_dev, ptr(op.out), ld(op.out), skip_flag, skip_when};
+        launch_stem(a, s);
+        break;
+      }
+      case OP_PW:
+      case OP_DW: {
+        const ConvW& cw = net.convs[op.wslot];
+        ConvArgs a{};
+        a.in = ptr(op.in); a.in_ld = ld(op.in); a.w = cw.w_dev; a.bias = cw.b_dev;
+        a.out = ptr(op.out); a.out_ld = ld(op.out);
+        a.res = op.res.buf >= 0 ? ptr(op.res) : nullptr; a.res_ld = op.res.buf >= 0 ? ld(op.res) : 0;
+        a.N = N; a.H = op.in.H; a.W = op.in.W; a.OH = op.out.H; a.OW = op.out.W;
+        a.cin = op.in.C; a.cout = op.out.C; a.stride = op.stride; a.act = op.act;
+        a.skip_flag = skip_flag; a.skip_when = skip_when;
+        if (op.kind == OP_PW) launch_pw(a, s); else launch_dw(a, s);
+        break;
+      }
+      case OP_SPP:
+        launch_spp(buf_base(net, ws, op.out.buf, MB), ld(op.out), op.in.C, op.in.H, op.in.W, N, skip_flag, skip_when, s);
+        break;
+      case OP_UPSAMPLE:
+        launch_upsample(ptr(op.in), ld(op.in), ptr(op.out), ld(op.out), op.in.C, op.in.H, op.in.W, N, skip_flag,
+                        skip_when, s);
+        break;
+      case OP_CONV3:
+        set_error("dense 3x3 conv (%s) is not implemented yet in this build", op.name.c_str());
+        return JN_ESTATE;
+    }
+  }
+  JN_HIP(hipGetLastError());
+  return JN_OK;
+}
+
+// embed_fpn (src/models/gpt.py:294-306, 382) on the last FPN map of the encoder for N patches:
+// 1x1 conv + ReLU, then the split-K partial sums of the Linear (finished by the consumer).
+static int run_embed_fpn(jn_ctx* ctx, int N, const int* skip_flag, int skip_when, hipStream_t s) {
+  const Net& net = ctx->nets[ctx->enc_net];
+  jn_ctx& x = *ctx;
+  const int C = ctx->cfg.n_embd, MB = ctx->cfg.max_batch;
+  const View& f = net.fpn[2];
+  ConvArgs a{};
+  a.in = buf_base(net, x.net_ws[ctx->enc_net], f.buf, MB) + f.coff; a.in_ld = net.bufs[f.buf].C;
+  a.w = ctx->gpt.efpn_w; a.bias = x.zero_bias; a.out = ctx->efpn_act; a.out_ld = C;
+  a.N = N; a.H = f.H; a.W = f.W; a.OH = f.H; a.OW = f.W; a.cin = f.C; a.cout = C; a.stride = 1; a.act = ACT_RELU;
+  a.skip_flag = skip_flag; a.skip_when = skip_when;
+  launch_pw(a, s);
+  launch_efpn_linear(ctx->efpn_act, ctx->gpt.efpn_lin_wt, x.emb_part, N, f.H * f.W * C, C, x.KS, skip_flag, skip_when, s);
+  JN_HIP(hipGetLastError());
+  return JN_OK;
+}
+
+int jn_backbone_forward(jn_ctx* ctx, int net, const float* patches_dev, int N, float* fpn0_dev, float* fpn1_dev,
+                        float* fpn2_dev, void* stream) {
+  JN_CHECK(ctx && patches_dev, JN_EINVAL, "jn_backbone_forward: null argument");
+  JN_CHECK(net >= 0 && net < 2 && ctx->has_net[net], JN_EINVAL, "network %d is not part of this context", net);
+  JN_CHECK(ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
+  JN_CHECK(N >= 1 && N <= ctx->cfg.max_batch, JN_EINVAL, "N=%d exceeds max_batch=%d", N, ctx->cfg.max_batch);
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  const int P = ctx->cfg.patch_size;
+  StemSrc ss{patches_dev, nullptr, 3LL * P * P, (long long)P * P, P};
+  int rc = run_net(ctx, net, N, ss, nullptr, 0, s);
+  if (rc) return rc;
+  float* outs[3] = {fpn0_dev, fpn1_dev, fpn2_dev};
+  const Net& n = ctx->nets[net];
+  for (int i = 0; i < 3; ++i) {
+    if (!outs[i]) continue;
+    const View& f = n.fpn[i];
+    launch_nhwc_to_nchw(buf_base(n, ctx->net_ws[net], f.buf, ctx->cfg.max_batch) + f.coff, n.bufs[f.buf].C, outs[i],
+                        f.C, f.H * f.W, N, s);
+  }
+  JN_HIP(hipGetLastError());
+  return JN_OK;
+}
+
+// finishes the split-K sums: out[n][c] = bias[c] + sum_ks part[n][ks][c]
+__global__ void emb_finish_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
+                                  long long out_stride, int N, int KS, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i - n * C;
+  float s = bias[c];
+  for (int k = 0; k < KS; ++k) s += part[((long long)n * KS + k) * C + c];
+  out[(long long)n * out_stride + c] = s;
+}
+
+int jn_embed_patches(jn_ctx* ctx, const float* patches_dev, int N, float* out_dev, void* stream) {
+  JN_CHECK(ctx && patches_dev && out_dev, JN_EINVAL, "jn_embed_patches: null argument");
+  JN_CHECK(!ctx->cfg.no_patch_emb, JN_ESTATE, "context was created with no_patch_emb");
+  int rc = jn_backbone_forward(ctx, ctx->enc_net, patches_dev, N, nullptr, nullptr, nullptr, stream);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = run_embed_fpn(ctx, N, nullptr, 0, s))) return rc;
+  const int C = ctx->cfg.n_embd;
+  hipLaunchKernelGGL(emb_finish_kernel, dim3((N * C + 255) / 256), dim3(256), 0, s, ctx->emb_part,
+                     ctx->gpt.efpn_lin_b, out_dev, (long long)C, N, ctx->KS, C);
+  JN_HIP(hipGetLastError());
+  return JN_OK;
+}
+
+
+static void fill_gpt_weights(const jn_ctx* ctx, GptStepArgs& a) {
+  const jn_config& c = ctx->cfg;
+  const GptW& g = ctx->gpt;
+  a.C = c.n_embd; a.n_head = c.n_head; a.n_layer = c.n_layer; a.nA = c.n_actions; a.Tmax = c.block_size + 1;
+  a.use_pos_emb = c.use_pos_emb; a.no_patch_emb = c.no_patch_emb; a.concat_emb = c.concat_emb;
+  a.dec_pos_enc = c.decoder_pos_encoding; a.n_parts = n_parts(c);
+  a.pe2_ch = (int)std::ceil(c.n_embd / 4.0) * 2;
+  a.wte = g.wte; a.wpe = g.wpe; a.embed_class = g.embed_class; a.proj_wt = g.proj_wt; a.proj_b = g.proj_b;
+  a.pos1d = g.pos1d; a.pe2 = g.pos2d_col; a.head_wt = g.head_wt; a.lnf_w = g.lnf_w; a.lnf_b = g.lnf_b;
+  a.layers = ctx->layers_dev; a.emb_part = ctx->emb_part; a.KS = ctx->KS; a.efpn_lin_b = g.efpn_lin_b;
+  a.kcache = ctx->kcache; a.vcache = ctx->vcache; a.prev_action = ctx->prev_action; a.cache_len = ctx->cache_len;
+  a.n_done = ctx->n_done;
+}
+
+int jn_gpt_forward(jn_ctx* ctx, const float* patches_dev, const int64_t* actions_dev, const int64_t* positions_dev,
+                   const float* prev_emb_dev, int B, int T, int Tp, float* logits_dev, float* final_emb_dev,
+                   void* stream) {
+  JN_CHECK(ctx && actions_dev, JN_EINVAL, "jn_gpt_forward: null argument");
+  JN_CHECK(ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
+  const jn_config& c = ctx->cfg;
+  JN_CHECK(B >= 1 && B <= c.max_batch, JN_EINVAL, "B=%d exceeds max_batch=%d", B, c.max_batch);
+  // gpt.py:514-518
+  JN_CHECK(T >= 1 && T <= c.block_size, JN_EINVAL, "Cannot forward sequence of length %d, block size is only %d", T,
+           c.block_size);
+  JN_CHECK(!c.use_pos_emb || positions_dev, JN_EINVAL, "positions are required when use_pos_emb is set");
+  JN_CHECK(c.no_patch_emb || patches_dev, JN_EINVAL, "patches are required unless no_patch_emb is set");
+  JN_CHECK(!prev_emb_dev || (Tp >= 1 && Tp + 1 <= c.block_size + 1), JN_EINVAL, "prev_embeddings length %d out of range", Tp);
+  JN_HIP(hipSetDevice(c.device));
+  hipStream_t s = (hipStream_t)stream;
+  const int C = c.n_embd, P = c.patch_size, nA = c.n_actions;
+  const int n_new = prev_emb_dev ? 1 : T, i0 = prev_emb_dev ? T - 1 : 0;
+  const int L = prev_emb_dev ? Tp + 1 : T + 1;
+  int rc;
+  if (!c.no_patch_emb) {
+    if (!ctx->tok_emb) {
+      if ((rc = dev_alloc(ctx, &ctx->tok_emb, (size_t)c.max_batch * (c.block_size + 1) * C))) return rc;
+    }
+    for (int i = 0; i < n_new; ++i) {
+      StemSrc ss{patches_dev + (size_t)(i0 + i) * 3 * P * P, nullptr, (long long)T * 3 * P * P, (long long)P * P, P};
+      if ((rc = run_net(ctx, ctx->enc_net, B, ss, nullptr, 0, s))) return rc;
+      if ((rc = run_embed_fpn(ctx, B, nullptr, 0, s))) return rc;
+      hipLaunchKernelGGL(emb_finish_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, ctx->emb_part, ctx->gpt.efpn_lin_b,
+                         ctx->tok_emb + (size_t)i * C, (long long)n_new * C, B, ctx->KS, C);
+    }
+  }
+  JN_HIP(hipMemsetAsync(ctx->cache_len, 0, (size_t)B * sizeof(int32_t), s));
+  GptStepArgs a{};
+  fill_gpt_weights(ctx, a);
+  a.B = B; a.T = L; a.emb_stride = L; a.out.final_emb = final_emb_dev; a.logits_stride = (L - 1) * nA;
+  for (int tok = 0; tok < L; ++tok) {
+    a.step = tok;
+    a.logits_rows = (tok >= 1 && logits_dev) ? logits_dev + (size_t)(tok - 1) * nA : nullptr;
+    if (prev_emb_dev && tok < Tp) {
+      a.src_mode = GPT_SRC_GIVEN; a.given_emb = prev_emb_dev; a.given_stride = Tp; a.given_index = tok;
+    } else if (!prev_emb_dev && tok == 0) {
+      a.src_mode = GPT_SRC_CLASS;
+    } else {
+      const int i = prev_emb_dev ? 0 : tok - 1;           // index among the new tokens
+      a.src_mode = GPT_SRC_TEACH;
+      a.t_actions = actions_dev; a.t_positions = positions_dev; a.t_stride = T; a.t_index = i0 + i;
+      a.pos_index = prev_emb_dev ? 0 : i;                 // recurrent tokens always get position 0 (gpt.py:431-449)
+      a.tok_emb = ctx->tok_emb; a.tok_emb_stride = n_new; a.tok_emb_index = i;
+    }
+    launch_gpt_step(a, s);
+  }
+  JN_HIP(hipGetLastError());
+  return JN_OK;
+}
+
+int jn_detect(jn_ctx* ctx, const float*, int, float*, int32_t*, float*, void*) {
+  (void)ctx;
+  set_error("jn_detect: detector head is not implemented yet in this build");
+  return JN_ESTATE;
+}
+
+// ---- environment ---------------------------------------------------------------------
+static EnvPtrs env_ptrs(jn_ctx* ctx) {
+  const EnvState& e = ctx->env;
+  EnvPtrs p{e.positions, e.bbox_masks, e.visited, e.steps, e.has_stopped, e.n_bbox_tiles, ctx->found,
+            e.B, e.Gh, e.Gw, e.T, e.stop};
+  return p;
+}
+
+int jn_env_init(jn_ctx* ctx, const float* images_dev, const int64_t* bboxes_dev, int B, int H, int W, int nb,
+                int max_ep_len, int stop_enabled, void* stream) {
+  JN_CHECK(ctx && images_dev && (bboxes_dev || nb == 0), JN_EINVAL, "jn_env_init: null argument");
+  const int P = ctx->cfg.patch_size;
+  JN_CHECK(B >= 1 && B <= ctx->cfg.max_batch, JN_EINVAL, "B=%d exceeds max_batch=%d", B, ctx->cfg.max_batch);
+  // general_env.py:50-51
+  JN_CHECK(H % P == 0 && W % P == 0, JN_EINVAL, "image %dx%d is not divisible by patch_size %d", H, W, P);
+  JN_CHECK(H / P <= 256 && W / P <= 256, JN_EINVAL, "patch grid larger than 256");
+  JN_CHECK(max_ep_len >= 1 && max_ep_len <= ctx->cfg.block_size, JN_EINVAL, "max_ep_len %d > block_size %d", max_ep_len,
+           ctx->cfg.block_size);
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  EnvState& e = ctx->env;
+  const int Gh = H / P, Gw = W / P;
+  int rc;
+  if (!e.positions) {
+    const int MB = ctx->cfg.max_batch;
+    if ((rc = dev_alloc(ctx, &e.positions, (size_t)MB * 2))) return rc;
+    if ((rc = dev_alloc(ctx, &e.bbox_masks, (size_t)MB * 256 * 256))) return rc;
+    if ((rc = dev_alloc(ctx, &e.visited, (size_t)MB * 256 * 256))) return rc;
+    if ((rc = dev_alloc(ctx, &e.steps, (size_t)MB))) return rc;
+    if ((rc = dev_alloc(ctx, &e.has_stopped, (size_t)MB))) return rc;
+    if ((rc = dev_alloc(ctx, &e.n_bbox_tiles, (size_t)MB))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->found, (size_t)MB))) return rc;
+  }
+  e.images = images_dev; e.B = B; e.H = H; e.W = W; e.nb = nb; e.Gh = Gh; e.Gw = Gw; e.T = max_ep_len;
+  e.stop = stop_enabled ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  launch_bbox_masks(bboxes_dev, e.bbox_masks, e.n_bbox_tiles, B, nb, H, W, P, s);
+  launch_env_reset(env_ptrs(ctx), nullptr, 0, s);   // zeroed state at (0,0)-independent start; reset() follows
+  JN_HIP(hipGetLastError());
+  e.ready = true;
+  return JN_OK;
+}
+
+int jn_env_reset(jn_ctx* ctx, const int64_t* positions_dev, uint64_t seed, void* stream) {
+  JN_CHECK(ctx && ctx->env.ready, JN_ESTATE, "jn_env_init has not been called");
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  launch_env_reset(env_ptrs(ctx), positions_dev, seed, (hipStream_t)stream);
+  JN_HIP(hipGetLastError());
+  return JN_OK;
+}
+
+int jn_env_step(jn_ctx* ctx, const int64_t* actions_dev, float* rewards_dev, uint8_t* terminated_dev,
+                uint8_t* truncated_dev, void* stream) {
+  JN_CHECK(ctx && ctx->env.ready, JN_ESTATE, "jn_env_init has not been called");
+  JN_CHECK(actions_dev, JN_EINVAL, "jn_env_step: null actions");
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  launch_env_step(env_ptrs(ctx), actions_dev, rewards_dev, terminated_dev, truncated_dev, (hipStream_t)stream);
+  JN_HIP(hipGetLastError());
+  return JN_OK;
+}
+
+int jn_env_state(jn_ctx* ctx, int what, void** ptr_dev) {
+  JN_CHECK(ctx && ptr_dev && ctx->env.ready, JN_ESTATE, "jn_env_init has not been called");
+  switch (what) {
+    case 0: *ptr_dev = ctx->env.positions; break;
+    case 1: *ptr_dev = ctx->env.bbox_masks; break;
+    case 2: *ptr_dev = ctx->env.visited; break;
+    case 3: *ptr_dev = ctx->env.steps; break;
+    case 4: *ptr_dev = ctx->env.has_stopped; break;
+    default: set_error("jn_env_state: unknown selector %d", what); return JN_EINVAL;
+  }
+  return JN_OK;
+}
+
+int jn_gather_patches(const float* images_dev, const int64_t* positions_dev, float* out_dev, int B, int C, int H, int W,
+                      int P, void* stream) {
+  JN_CHECK(images_dev && positions_dev && out_dev, JN_EINVAL, "jn_gather_patches: null argument");
+  JN_CHECK(B >= 0 && C >= 1 && P >= 1 && H % P == 0 && W % P == 0, JN_EINVAL, "jn_gather_patches: bad shape");
+  if (B == 0) return JN_OK;
+  launch_gather(images_dev, positions_dev, out_dev, (long long)C * P * P, B, C, H, W, P, nullptr, 0, (hipStream_t)stream);
+  JN_HIP(hipGetLastError());
+  return JN_OK;
+}
+
+int jn_env_patches(jn_ctx* ctx, float* out_dev, void* stream) {
+  JN_CHECK(ctx && ctx->env.ready && out_dev, JN_ESTATE, "jn_env_init has not been called");
+  const EnvState& e = ctx->env;
+  return jn_gather_patches(e.images, e.positions, out_dev, e.B, 3, e.H, e.W, ctx->cfg.patch_size, stream);
+}
+
+// ---- the hot loop ----------------------------------------------------------------------
+int jn_set_profiling(jn_ctx* ctx, int enabled) {
+  JN_CHECK(ctx, JN_EINVAL, "null ctx");
+  ctx->profiling = enabled != 0;
+  return JN_OK;
+}
+
+int jn_rollout(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, const int64_t* start_positions_dev,
+               uint64_t seed, int do_detection, int stop_early, const jn_rollout_out* out, void* stream) {
+  JN_CHECK(ctx && out, JN_EINVAL, "jn_rollout: null argument");
+  JN_CHECK(ctx->env.ready, JN_ESTATE, "jn_env_init has not been called");
+  JN_CHECK(ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
+  JN_CHECK(mode >= 0 && mode <= 2, JN_EINVAL, "unknown mode %d", mode);
+  JN_CHECK(mode != JN_MODE_FORCED || forced_actions_dev, JN_EINVAL, "JN_MODE_FORCED needs forced_actions");
+  JN_CHECK(out->rewards_dev && out->masks_dev, JN_EINVAL, "rewards_dev and masks_dev are required outputs");
+  JN_CHECK(!do_detection, JN_ESTATE, "do_detection: detector head is not implemented yet in this build");
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  jn_ctx& x = *ctx;
+  const jn_config& c = ctx->cfg;
+  const EnvState& e = ctx->env;
+  const int B = e.B, T = e.T, C = c.n_embd, P = c.patch_size, nA = c.n_actions;
+  RolloutBuffers r{out->rewards_dev, out->returns_dev, out->logprobs_dev, out->entropies_dev, out->masks_dev,
+                   out->logit_masks_dev, out->positions_dev, out->actions_dev, out->logits_dev, out->final_emb_dev};
+  // zero-fill so that columns past an early stop read as the reference's absent columns would be cut
+  JN_HIP(hipMemsetAsync(r.rewards, 0, (size_t)B * T * sizeof(float), s));
+  if (r.returns) JN_HIP(hipMemsetAsync(r.returns, 0, (size_t)B * T * sizeof(float), s));
+  if (r.logprobs) JN_HIP(hipMemsetAsync(r.logprobs, 0, (size_t)B * T * sizeof(float), s));
+  if (r.entropies) JN_HIP(hipMemsetAsync(r.entropies, 0, (size_t)B * T * sizeof(float), s));
+  JN_HIP(hipMemsetAsync(r.masks, 0, (size_t)B * (T + 1), s));
+  if (r.logit_masks) JN_HIP(hipMemsetAsync(r.logit_masks, 0, (size_t)B * T, s));
+  if (r.positions) JN_HIP(hipMemsetAsync(r.positions, 0, (size_t)B * (T + 1) * 2 * sizeof(int64_t), s));
+  if (r.actions) JN_HIP(hipMemsetAsync(r.actions, 0, (size_t)B * T * sizeof(int64_t), s));
+  if (r.logits) JN_HIP(hipMemsetAsync(r.logits, 0, (size_t)B * T * nA * sizeof(float), s));
+  if (r.final_emb) JN_HIP(hipMemsetAsync(r.final_emb, 0, (size_t)B * (T + 1) * C * sizeof(float), s));
+
+  if (ctx->ev[0]) JN_HIP(hipEventRecord(ctx->ev[0], s));
+  EnvPtrs ep = env_ptrs(ctx);
+  launch_env_reset(ep, start_positions_dev, seed, s);
+  launch_rollout_begin(ep, r, ctx->prev_action, ctx->cache_len, ctx->n_done, s);
+  const long long patch_stride = (long long)(T + 1) * 3 * P * P;
+  if (out->patches_dev)
+    launch_gather(e.images, e.positions, out->patches_dev, patch_stride, B, 3, e.H, e.W, P, nullptr, 0, s);
+
+  if (ctx->profiling) {
+    while ((int)ctx->conv_ev.size() < 2 * T) {
+      hipEvent_t ev;
+      JN_HIP(hipEventCreate(&ev));
+      ctx->conv_ev.push_back(ev);
+    }
+  }
+  ctx->conv_ev_used = 0;
+  StemSrc ss{e.images, e.positions, 3LL * e.H * e.W, (long long)e.H * e.W, e.W};
+  int rc;
+  for (int t = 0; t < T; ++t) {
+    const int* flag = stop_early ? ctx->n_done + t : nullptr;
+    if (!c.no_patch_emb) {
+      if (ctx->profiling) JN_HIP(hipEventRecord(ctx->conv_ev[2 * t], s));
+      if ((rc = run_net(ctx, ctx->enc_net, B, ss, flag, B, s))) return rc;
+      if (ctx->profiling) { JN_HIP(hipEventRecord(ctx->conv_ev[2 * t + 1], s)); ctx->conv_ev_used = 2 * (t + 1); }
+      if ((rc = run_embed_fpn(ctx, B, flag, B, s))) return rc;
+    }
+    GptStepArgs a{};
+    a.C = C; a.n_head = c.n_head; a.n_layer = c.n_layer; a.nA = nA; a.Tmax = c.block_size + 1; a.B = B; a.T = T;
+    a.use_pos_emb = c.use_pos_emb; a.no_patch_emb = c.no_patch_emb; a.concat_emb = c.concat_emb;
+    a.dec_pos_enc = c.decoder_pos_encoding; a.n_parts = n_parts(c);
+    a.pe2_ch = (int)std::ceil(C / 4.0) * 2;
+    const GptW& g = ctx->gpt;
+    a.wte = g.wte; a.wpe = g.wpe; a.embed_class = g.embed_class; a.proj_wt = g.proj_wt; a.proj_b = g.proj_b;
+    a.pos1d = g.pos1d; a.pe2 = g.pos2d_col; a.head_wt = g.head_wt; a.lnf_w = g.lnf_w; a.lnf_b = g.lnf_b;
+    a.layers = x.layers_dev; a.emb_part = x.emb_part; a.KS = x.KS; a.efpn_lin_b = g.efpn_lin_b;
+    a.kcache = ctx->kcache; a.vcache = ctx->vcache; a.prev_action = ctx->prev_action; a.cache_len = ctx->cache_len;
+    a.step = t; a.mode = mode; a.forced = forced_actions_dev; a.seed = seed;
+    a.src_mode = GPT_SRC_ENV; a.pos_index = 0; a.emb_stride = T + 1;
+    a.env = ep; a.out = r; a.n_done = ctx->n_done;
+    a.skip_flag = flag; a.skip_when = B;
+    launch_gpt_step(a, s);
+    if (out->patches_dev)
+      launch_gather(e.images, e.positions, out->patches_dev + (long long)(t + 1) * 3 * P * P, patch_stride, B, 3, e.H, e.W,
+                    P, flag, B, s);
+  }
+  launch_rollout_epilogue(r, ctx->n_done, B, T, s);
+  if (ctx->ev[1]) JN_HIP(hipEventRecord(ctx->ev[1], s));
+  JN_HIP(hipGetLastError());
+  ctx->last_T = T;
+  return JN_OK;
+}
+
+int jn_rollout_steps(jn_ctx* ctx, int* n_steps, void* stream) {
+  JN_CHECK(ctx && n_steps && ctx->last_T > 0, JN_ESTATE, "no rollout has run");
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  const int T = ctx->last_T, B = ctx->env.B;
+  std::vector<int32_t> h(T + 1);
+  JN_HIP(hipMemcpyAsync(h.data(), ctx->n_done, (T + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  JN_HIP(hipStreamSynchronize((hipStream_t)stream));
+  int S = T;
+  for (int t = 1; t <= T; ++t)
+    if (h[t] >= B) { S = t; break; }
+  *n_steps = S;
+  return JN_OK;
+}
+
+int jn_last_timing(jn_ctx* ctx, int what, float* ms) {
+  JN_CHECK(ctx && ms && ctx->last_T > 0, JN_ESTATE, "no rollout has run");
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  JN_HIP(hipEventSynchronize(ctx->ev[1]));
+  if (what == 0) {
+    JN_HIP(hipEventElapsedTime(ms, ctx->ev[0], ctx->ev[1]));
+  } else {
+    float tot = 0.0f;
+    for (int i = 0; i + 1 < ctx->conv_ev_used; i += 2) {
+      float m = 0.0f;
+      JN_HIP(hipEventElapsedTime(&m, ctx->conv_ev[i], ctx->conv_ev[i + 1]));
+      tot += m;
+    }
+    *ms = tot;
+  }
+  return JN_OK;
+}
+
+}  // extern "C"

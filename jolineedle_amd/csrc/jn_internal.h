@@ -1,0 +1,157 @@
+// Internal structures of libjnroll.so (host side).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/jnroll.h"
+#include "jn_kernels.h"
+
+namespace jnr {
+
+void set_error(const char* fmt, ...);
+
+#define JN_HIP(call)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      jnr::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return JN_EHIP;                                                                     \
+    }                                                                                     \
+  } while (0)
+
+#define JN_CHECK(cond, code, ...)   \
+  do {                              \
+    if (!(cond)) {                  \
+      jnr::set_error(__VA_ARGS__);   \
+      return (code);                \
+    }                               \
+  } while (0)
+
+// ---- activation buffers: NHWC fp32, per-image size known at plan time --------------
+struct Buf {
+  int H = 0, W = 0, C = 0;          // C = channel stride of a pixel (ld)
+  size_t per_image() const { return (size_t)H * W * C; }
+};
+
+// A channel slice of a buffer.
+struct View {
+  int buf = -1;
+  int H = 0, W = 0;
+  int C = 0;      // channels in the view
+  int coff = 0;   // first channel inside the buffer
+};
+
+enum OpKind {
+  OP_STEM = 0,      // Focus + dense 3x3 (== 6x6 stride-2 on the image) + bias + SiLU
+  OP_PW,            // 1x1 conv  (GEMM)   + bias + act (+ residual)
+  OP_DW,            // depthwise 3x3 s1/s2 + bias + SiLU
+  OP_CONV3,         // dense 3x3 s1/s2    + bias + SiLU       (non-depthwise models)
+  OP_SPP,           // maxpool 5/9/13 of slice 0 into slices 1..3
+  OP_UPSAMPLE,      // nearest x2 into a slice
+};
+
+struct Op {
+  OpKind kind;
+  View in, out;
+  View res;                 // residual added after the activation (buf = -1: none)
+  int stride = 1;
+  int act = ACT_SILU;
+  int wslot = -1;           // index into Net::convs (packed weights)
+  std::string name;         // module prefix, e.g. "backbone.dark2.0.dconv"
+};
+
+// Packed (device) weights of one conv layer.
+struct ConvW {
+  std::string prefix;       // "<...>.conv" / "<...>.bn" live under this module prefix
+  int cin = 0, cout = 0, k = 1, groups = 1;
+  bool has_bn = true;       // BaseConv; false = plain Conv2d with optional bias
+  bool has_bias = false;    // plain Conv2d bias
+  float* w_dev = nullptr;   // layout depends on the op (see pack_conv)
+  float* b_dev = nullptr;   // [cout] folded bias
+};
+
+struct Net {
+  std::string prefix;       // "gpt_backbone." or "yolox.backbone."
+  bool depthwise = false;
+  float depth = 0, width = 0;
+  int P = 0;
+  std::vector<Buf> bufs;
+  std::vector<Op> ops;
+  std::vector<ConvW> convs;
+  View fpn[3];              // pan_out2, pan_out1, pan_out0
+  size_t per_image_floats = 0;
+  std::vector<size_t> buf_off;    // per-image offset of each buffer (floats)
+};
+
+struct ParamEntry {
+  jn_param_info info;
+};
+
+struct GptW {   // device, packed
+  float *wte = nullptr, *wpe = nullptr, *embed_class = nullptr;
+  float *proj_wt = nullptr, *proj_b = nullptr;          // project_concat: Wt [n_in][C]
+  float *pos1d = nullptr;                                // [T+1][C] 1-D sinusoid table
+  float *pos2d_col = nullptr, *pos2d_row = nullptr;      // [256][ch2] tables (column / row halves)
+  float *efpn_w = nullptr;                               // embed_fpn.0 weight [C][cin]
+  float *efpn_lin_wt = nullptr, *efpn_lin_b = nullptr;   // embed_fpn.3: Wt [(h*w)*C + c][C]
+  float *head_wt = nullptr;                              // [C][nA]
+  float *lnf_w = nullptr, *lnf_b = nullptr;
+  struct Layer {
+    float *ln1_w, *ln1_b, *qkv_wt, *qkv_b, *proj_wt, *proj_b, *ln2_w, *ln2_b, *fc_wt, *fc_b, *fc2_wt, *fc2_b;
+  };
+  std::vector<Layer> layers;
+};
+
+struct EnvState {
+  bool ready = false;
+  const float* images = nullptr;
+  int B = 0, H = 0, W = 0, nb = 0, Gh = 0, Gw = 0, T = 0, stop = 0;
+  int64_t* positions = nullptr;   // [B,2]
+  uint8_t* bbox_masks = nullptr;  // [B,Gh,Gw]
+  uint8_t* visited = nullptr;     // [B,Gh,Gw]
+  int32_t* steps = nullptr;       // [B]
+  uint8_t* has_stopped = nullptr; // [B]
+  int32_t* n_bbox_tiles = nullptr;// [B] sum(bbox_masks)
+};
+
+}  // namespace jnr
+
+struct jn_ctx {
+  jn_config cfg;
+  std::vector<jnr::ParamEntry> params;
+  jnr::Net nets[2];                // [JN_NET_GPT_BACKBONE], [JN_NET_DETECTOR]
+  bool has_net[2] = {false, false};
+  int enc_net = 0;                // which net encodes patches for the GPT
+  jnr::GptW gpt;
+  int efpn_cin = 0, efpn_h = 0, efpn_w = 0;
+  bool weights_loaded = false;
+  std::vector<void*> owned;       // device allocations to free
+  float* act_ws = nullptr;        // activation workspace of the patch encoder
+  float* net_ws[2] = {nullptr, nullptr};   // NHWC activations of each net, max_batch images
+  jnr::GptLayerPtrs* layers_dev = nullptr;
+  float* emb_part = nullptr;      // [B][KS][C] split-K partials of embed_fpn.3
+  int KS = 8;
+  float* zero_bias = nullptr;     // zeros, bias of bias-free 1x1 convs
+  int32_t* found = nullptr;       // [B] visited bbox tiles
+  float* tok_emb = nullptr;       // [B][T][C] patch embeddings of jn_gpt_forward
+  jnr::EnvState env;
+  // rollout workspaces
+  float* patch_emb = nullptr;     // [B, C]
+  float* efpn_act = nullptr;      // [B, h*w, C]
+  float* kcache = nullptr;        // [L][B][T+1][C]
+  float* vcache = nullptr;
+  float* logits_ws = nullptr;     // [B, nA]
+  int32_t* n_done = nullptr;      // [T+1] number of finished envs after step t (index t+1)
+  int64_t* prev_action = nullptr; // [B]
+  int32_t* cache_len = nullptr;   // [B]
+  int last_T = 0;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool profiling = false;
+  std::vector<hipEvent_t> conv_ev;   // pairs per step when profiling
+  int conv_ev_used = 0;
+};

@@ -1,0 +1,105 @@
+// Host-callable launchers of the HIP kernels (internal; not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/jnroll.h"
+
+namespace jnr {
+
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
+
+// Every hot-loop kernel takes (skip_flag, skip_when): it returns at once when
+// *skip_flag >= skip_when.  The rollout points skip_flag at n_done[t] with skip_when = B,
+// which reproduces the reference's early `break` (src/reinforce.py:181-184) with no host sync.
+struct StemArgs {
+  const float* src; const int64_t* positions;
+  long long sample_stride, chan_stride; int row_stride;
+  int P, N, cout;
+  const float* w; const float* bias; float* out; int out_ld;
+  const int* skip_flag; int skip_when;
+};
+
+struct ConvArgs {
+  const float* in; int in_ld;
+  const float* w; const float* bias;
+  float* out; int out_ld;
+  const float* res; int res_ld;
+  int N, H, W, OH, OW, cin, cout, stride, act;
+  const int* skip_flag; int skip_when;
+};
+
+int launch_stem(const StemArgs& a, hipStream_t s);
+int launch_dw(const ConvArgs& a, hipStream_t s);
+int launch_pw(const ConvArgs& a, hipStream_t s);
+int launch_spp(float* cat, int ld, int h, int H, int W, int N, const int* skip_flag, int skip_when, hipStream_t s);
+int launch_upsample(const float* in, int in_ld, float* out, int out_ld, int C, int H, int W, int N,
+                    const int* skip_flag, int skip_when, hipStream_t s);
+int launch_nhwc_to_nchw(const float* in, int in_ld, float* out, int C, int HW, int N, hipStream_t s);
+int launch_efpn_linear(const float* e, const float* wt, float* part, int N, int K, int Co, int KS,
+                       const int* skip_flag, int skip_when, hipStream_t s);
+
+// ---- env / rollout primitives (kernels_env.hip) -------------------------------------
+int launch_gather(const float* images, const int64_t* positions, float* out, long long out_sample_stride,
+                  int B, int C, int H, int W, int P, const int* skip_flag, int skip_when, hipStream_t s);
+int launch_bbox_masks(const int64_t* bboxes, uint8_t* masks, int32_t* n_tiles, int B, int nb, int H, int W, int P,
+                      hipStream_t s);
+
+struct EnvPtrs {
+  int64_t* positions; uint8_t* bbox_masks; uint8_t* visited; int32_t* steps; uint8_t* has_stopped;
+  int32_t* n_bbox_tiles; int32_t* found;
+  int B, Gh, Gw, T, stop;
+};
+int launch_env_reset(const EnvPtrs& e, const int64_t* start_positions, uint64_t seed, hipStream_t s);
+int launch_env_step(const EnvPtrs& e, const int64_t* actions, float* rewards, uint8_t* terminated,
+                    uint8_t* truncated, hipStream_t s);
+
+struct RolloutBuffers {   // device, [B,T]-shaped unless noted; any may be null
+  float* rewards; float* returns; float* logprobs; float* entropies;
+  uint8_t* masks;        // [B,T+1]
+  uint8_t* logit_masks;
+  int64_t* positions;    // [B,T+1,2]
+  int64_t* actions;
+  float* logits;         // [B,T,nA]
+  float* final_emb;      // [B,T+1,C]
+};
+int launch_rollout_begin(const EnvPtrs& e, const RolloutBuffers& r, int64_t* prev_action, int32_t* cache_len,
+                         int32_t* n_done, hipStream_t s);
+int launch_rollout_epilogue(const RolloutBuffers& r, const int32_t* n_done, int B, int T, hipStream_t s);
+
+// ---- decision transformer step (kernels_gpt.hip) -------------------------------------
+struct GptLayerPtrs {
+  const float *ln1_w, *ln1_b, *qkv_wt, *qkv_b, *proj_wt, *proj_b, *ln2_w, *ln2_b, *fc_wt, *fc_b, *fc2_wt, *fc2_b;
+};
+
+enum { GPT_SRC_ENV = 0, GPT_SRC_TEACH = 1, GPT_SRC_GIVEN = 2, GPT_SRC_CLASS = 3 };
+
+struct GptStepArgs {
+  int C, n_head, n_layer, nA, Tmax, B, T;
+  int use_pos_emb, no_patch_emb, concat_emb, dec_pos_enc, n_parts;
+  int pe2_ch;                       // channels per axis of the 2-D sinusoid table
+  const float *wte, *wpe, *embed_class, *proj_wt, *proj_b, *pos1d, *pe2, *head_wt, *lnf_w, *lnf_b;
+  const GptLayerPtrs* layers;       // device array [n_layer]
+  const float* emb_part; int KS; const float* efpn_lin_b;   // patch-embedding split-K partials [B][KS][C]
+  float *kcache, *vcache;           // [L][B][Tmax][C]
+  int64_t* prev_action; int32_t* cache_len;
+  int step;                         // t
+  // token source: rollout state, teacher arrays, a given embedding row, or the class token
+  int src_mode;
+  int pos_index;                    // 1-D position of the token (0 in recurrent mode: gpt.py:431-449 quirk)
+  const int64_t* t_actions; const int64_t* t_positions; int t_stride, t_index;
+  const float* tok_emb; int tok_emb_stride, tok_emb_index;   // patch embeddings [B][stride][C]
+  const float* given_emb; int given_stride, given_index;
+  int embed_only;                   // stop after writing the token embedding
+  int emb_stride;                   // tokens per agent in out.final_emb
+  float* logits_rows; int logits_stride;   // teacher/given modes: logits of this token -> row b
+  int mode; const int64_t* forced; uint64_t seed;
+  EnvPtrs env;
+  RolloutBuffers out;
+  int32_t* n_done;                  // [T+1]
+  const int* skip_flag; int skip_when;
+};
+int launch_gpt_step(const GptStepArgs& a, hipStream_t s);
+
+}  // namespace jnr

@@ -1,0 +1,265 @@
+// One glimpse step of the decision model for every agent of the batch, in ONE launch:
+//   token embedding (src/models/gpt.py:419-479) -> pre-LN GPT-2 blocks with a persistent
+//   per-agent KV cache (the reference recomputes the whole prefix, gpt.py:525-528; with
+//   dropout 0 and a causal mask the cached form is the same function) -> ln_f ->
+//   ActionHead (src/models/action_head.py:24-33) -> Categorical argmax / sample / forced
+//   + log-prob + entropy (src/reinforce.py:73-90) -> env step + reward
+//   (src/env/general_env.py:172-233, 321-358) -> rollout bookkeeping (reinforce.py:169-179).
+// One workgroup per agent; all vectors live in LDS; Linear weights are stored transposed
+// ([k][n]) so lanes read consecutive n.  Nothing here returns to the host.
+#include <hip/hip_runtime.h>
+
+#include "jn_device.h"
+
+namespace jnr {
+
+constexpr int GPT_THREADS = 256;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  // 256 threads -> 4 waves; wave reduce by shuffles then LDS
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// y[n] = b[n] + sum_k x[k] * wt[k*N + n]   (x in LDS, wt transposed in global/L2)
+__device__ __forceinline__ void linear_t(float* y, const float* x, const float* __restrict__ wt,
+                                         const float* __restrict__ b, int K, int N) {
+  for (int n = threadIdx.x; n < N; n += GPT_THREADS) {
+    float acc = b ? b[n] : 0.0f;
+    const float* wp = wt + n;
+#pragma unroll 4
+    for (int k = 0; k < K; ++k) acc = fmaf(x[k], wp[(long long)k * N], acc);
+    y[n] = acc;
+  }
+}
+
+__device__ __forceinline__ void layer_norm(float* y, const float* x, const float* __restrict__ w,
+                                           const float* __restrict__ b, int C, float* red) {
+  float s = 0.0f;
+  for (int i = threadIdx.x; i < C; i += GPT_THREADS) s += x[i];
+  const float mean = block_sum(s, red) / C;
+  float q = 0.0f;
+  for (int i = threadIdx.x; i < C; i += GPT_THREADS) { const float d = x[i] - mean; q += d * d; }
+  const float var = block_sum(q, red) / C;
+  const float rstd = 1.0f / sqrtf(var + 1e-5f);
+  for (int i = threadIdx.x; i < C; i += GPT_THREADS) y[i] = (x[i] - mean) * rstd * w[i] + b[i];
+  __syncthreads();
+}
+
+__device__ __forceinline__ float gelu_tanh(float x) {
+  // NewGELU, src/models/gpt.py:37-47
+  return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+
+__global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
+  if (a.skip_flag && *a.skip_flag >= a.skip_when) {
+    // every env was done before this step: stay skipped for the rest of the trajectory
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.n_done[a.step + 1] = a.skip_when;
+    return;
+  }
+  extern __shared__ float sm[];
+  const int C = a.C, tid = threadIdx.x, b = blockIdx.x;
+  float* x = sm;                 // [C]   residual stream
+  float* h = x + C;              // [C]   LN output / attention output
+  float* qkv = h + C;            // [3C]
+  float* mlp = qkv + 3 * C;      // [4C]  also the concatenated embedding parts
+  float* att = mlp + 4 * C;      // [n_head * Tmax]
+  float* red = att + a.n_head * a.Tmax;   // [4]
+  float* lg = red + 4;           // [16]  logits
+
+  const int t = a.step;
+  const int hs = C / a.n_head;
+  const float scale = 1.0f / sqrtf((float)hs);
+  int len = a.cache_len[b];      // tokens already cached (0 at the start of a sequence)
+  const int n_new = (a.src_mode == GPT_SRC_ENV && t == 0) ? 2 : 1;
+
+  for (int j = 0; j < n_new; ++j) {
+    // ---------------- token embedding ----------------
+    const bool class_tok = (a.src_mode == GPT_SRC_CLASS) || (a.src_mode == GPT_SRC_ENV && t == 0 && j == 0);
+    if (class_tok) {
+      for (int i = tid; i < C; i += GPT_THREADS) x[i] = a.embed_class[i];       // classes == 0 (reinforce.py:129)
+    } else if (a.src_mode == GPT_SRC_GIVEN) {
+      const float* gp = a.given_emb + ((long long)b * a.given_stride + a.given_index) * C;
+      for (int i = tid; i < C; i += GPT_THREADS) x[i] = gp[i];
+    } else {
+      int act, row, col;
+      if (a.src_mode == GPT_SRC_ENV) {
+        act = (int)a.prev_action[b];
+        row = (int)a.env.positions[2 * b]; col = (int)a.env.positions[2 * b + 1];
+      } else {
+        const long long bi = (long long)b * a.t_stride + a.t_index;
+        act = (int)a.t_actions[bi];
+        row = a.t_positions ? (int)a.t_positions[2 * bi] : 0;
+        col = a.t_positions ? (int)a.t_positions[2 * bi + 1] : 0;
+      }
+      act = min(max(act, 0), a.nA - 1);
+      row = min(max(row, 0), 255); col = min(max(col, 0), 255);
+      float* parts = mlp;
+      int p = 0;
+      for (int i = tid; i < C; i += GPT_THREADS) parts[i] = a.wte[act * C + i];
+      ++p;
+      for (int i = tid; i < C; i += GPT_THREADS)
+        parts[p * C + i] = a.dec_pos_enc ? a.pos1d[a.pos_index * C + i] : a.wpe[a.pos_index * C + i];
+      ++p;
+      if (!a.no_patch_emb) {
+        if (a.src_mode == GPT_SRC_ENV) {
+          for (int i = tid; i < C; i += GPT_THREADS) {
+            float s = a.efpn_lin_b[i];
+            for (int ks = 0; ks < a.KS; ++ks) s += a.emb_part[((long long)b * a.KS + ks) * C + i];
+            parts[p * C + i] = s;
+          }
+        } else {
+          const float* pe = a.tok_emb + ((long long)b * a.tok_emb_stride + a.tok_emb_index) * C;
+          for (int i = tid; i < C; i += GPT_THREADS) parts[p * C + i] = pe[i];
+        }
+        ++p;
+      }
+      if (a.use_pos_emb) {
+        for (int i = tid; i < C; i += GPT_THREADS)
+          parts[p * C + i] = (i < a.pe2_ch) ? a.pe2[col * a.pe2_ch + i] : a.pe2[row * a.pe2_ch + (i - a.pe2_ch)];
+        ++p;
+      }
+      __syncthreads();
+      if (a.concat_emb) {
+        linear_t(x, parts, a.proj_wt, a.proj_b, p * C, C);
+      } else {
+        for (int i = tid; i < C; i += GPT_THREADS) {
+          float s = 0.0f;
+          for (int q = 0; q < p; ++q) s += parts[q * C + i];
+          x[i] = s / p;
+        }
+      }
+    }
+    __syncthreads();
+    if (a.out.final_emb)
+      for (int i = tid; i < C; i += GPT_THREADS) a.out.final_emb[((long long)b * a.emb_stride + len) * C + i] = x[i];
+    if (a.embed_only) { ++len; continue; }
+
+    // ---------------- transformer blocks ----------------
+    for (int l = 0; l < a.n_layer; ++l) {
+      const GptLayerPtrs L = a.layers[l];
+      float* kc = a.kcache + (((long long)l * a.B + b) * a.Tmax) * C;
+      float* vc = a.vcache + (((long long)l * a.B + b) * a.Tmax) * C;
+      layer_norm(h, x, L.ln1_w, L.ln1_b, C, red);
+      linear_t(qkv, h, L.qkv_wt, L.qkv_b, C, 3 * C);
+      __syncthreads();
+      for (int i = tid; i < C; i += GPT_THREADS) { kc[len * C + i] = qkv[C + i]; vc[len * C + i] = qkv[2 * C + i]; }
+      __syncthreads();   // own-block global writes are visible to the block after the barrier
+      const int nk = len + 1;
+      for (int e = tid; e < a.n_head * nk; e += GPT_THREADS) {
+        const int hd = e / nk, s = e - hd * nk;
+        const float* kp = (s == len) ? (qkv + C + hd * hs) : (kc + s * C + hd * hs);
+        const float* qp = qkv + hd * hs;
+        float d = 0.0f;
+        for (int i = 0; i < hs; ++i) d = fmaf(qp[i], kp[i], d);
+        att[hd * a.Tmax + s] = d * scale;
+      }
+      __syncthreads();
+      if (tid < a.n_head) {
+        float* ap = att + tid * a.Tmax;
+        float m = -INFINITY;
+        for (int s = 0; s < nk; ++s) m = fmaxf(m, ap[s]);
+        float sum = 0.0f;
+        for (int s = 0; s < nk; ++s) { const float ev = expf(ap[s] - m); ap[s] = ev; sum += ev; }
+        const float inv = 1.0f / sum;
+        for (int s = 0; s < nk; ++s) ap[s] *= inv;
+      }
+      __syncthreads();
+      for (int i = tid; i < C; i += GPT_THREADS) {
+        const int hd = i / hs;
+        float acc = 0.0f;
+        for (int s = 0; s < nk; ++s) {
+          const float vv = (s == len) ? qkv[2 * C + i] : vc[s * C + i];
+          acc = fmaf(att[hd * a.Tmax + s], vv, acc);
+        }
+        h[i] = acc;
+      }
+      __syncthreads();
+      linear_t(qkv, h, L.proj_wt, L.proj_b, C, C);      // qkv[0:C] reused as scratch
+      __syncthreads();
+      for (int i = tid; i < C; i += GPT_THREADS) x[i] += qkv[i];
+      __syncthreads();
+      layer_norm(h, x, L.ln2_w, L.ln2_b, C, red);
+      linear_t(mlp, h, L.fc_wt, L.fc_b, C, 4 * C);
+      __syncthreads();
+      for (int i = tid; i < 4 * C; i += GPT_THREADS) mlp[i] = gelu_tanh(mlp[i]);
+      __syncthreads();
+      linear_t(qkv, mlp, L.fc2_wt, L.fc2_b, 4 * C, C);
+      __syncthreads();
+      for (int i = tid; i < C; i += GPT_THREADS) x[i] += qkv[i];
+      __syncthreads();
+    }
+    ++len;
+  }
+
+  if (a.embed_only) {
+    if (tid == 0) a.cache_len[b] = len;
+    return;
+  }
+  // ---------------- head on the newest token ----------------
+  layer_norm(h, x, a.lnf_w, a.lnf_b, C, red);
+  linear_t(lg, h, a.head_wt, nullptr, C, a.nA);
+  __syncthreads();
+
+  if (a.src_mode != GPT_SRC_ENV) {
+    if (tid == 0) a.cache_len[b] = len;
+    if (a.logits_rows && tid < a.nA) a.logits_rows[(long long)b * a.logits_stride + tid] = lg[tid];
+    return;
+  }
+  if (tid == 0) {
+    a.cache_len[b] = len;
+    const int nA = a.nA;
+    float m = -INFINITY;
+    int best = 0;
+    for (int i = 0; i < nA; ++i)
+      if (lg[i] > m) { m = lg[i]; best = i; }           // first maximum, as torch.argmax
+    float sum = 0.0f;
+    for (int i = 0; i < nA; ++i) sum += expf(lg[i] - m);
+    const float lse = m + logf(sum);
+    float ent = 0.0f;
+    for (int i = 0; i < nA; ++i) { const float lp = lg[i] - lse; ent -= lp * expf(lp); }
+    int act = best;
+    if (a.mode == JN_MODE_FORCED) {
+      act = (int)a.forced[(long long)b * a.T + t];
+      act = min(max(act, 0), nA - 1);
+    } else if (a.mode == JN_MODE_SAMPLE) {
+      const uint4 r = philox4x32(a.seed, (uint32_t)b, (uint32_t)t, 0x53414d50u, 0u);
+      const float u = u01(r.x);
+      float cdf = 0.0f;
+      act = nA - 1;
+      for (int i = 0; i < nA; ++i) {
+        cdf += expf(lg[i] - lse);
+        if (u < cdf) { act = i; break; }
+      }
+    }
+    const float logp = lg[act] - lse;
+    const EnvStepResult r = env_step_one(a.env, b, act);
+    a.prev_action[b] = act;
+    const long long bt = (long long)b * a.T + t;
+    if (a.out.rewards) a.out.rewards[bt] = r.reward;
+    if (a.out.logprobs) a.out.logprobs[bt] = logp;
+    if (a.out.entropies) a.out.entropies[bt] = ent;
+    if (a.out.actions) a.out.actions[bt] = act;
+    if (a.out.masks) a.out.masks[(long long)b * (a.T + 1) + t + 1] = r.terminated ? 0 : 1;
+    if (a.out.positions) {
+      a.out.positions[((long long)b * (a.T + 1) + t + 1) * 2] = r.y;
+      a.out.positions[((long long)b * (a.T + 1) + t + 1) * 2 + 1] = r.x;
+    }
+    if (a.out.logits)
+      for (int i = 0; i < nA; ++i) a.out.logits[bt * nA + i] = lg[i];
+    if (r.terminated || r.truncated) atomicAdd(a.n_done + t + 1, 1);
+  }
+}
+
+int launch_gpt_step(const GptStepArgs& a, hipStream_t s) {
+  const size_t smem = (size_t)(9 * a.C + a.n_head * a.Tmax + 4 + 16) * sizeof(float);
+  hipLaunchKernelGGL(gpt_step_kernel, dim3(a.B), dim3(GPT_THREADS), smem, s, a);
+  return 0;
+}
+
+}  // namespace jnr

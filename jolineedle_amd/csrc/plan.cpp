@@ -1,0 +1,221 @@
+// Layer plans: turns (depth, width, depthwise, P) into a flat list of conv ops over
+// NHWC buffers, plus the state-dict table the weights are loaded by.
+//
+// Topology restated from the published YOLOX CSPDarknet / YOLOPAFPN / YOLOXHead
+// (the package the reference imports at src/models/gpt.py:24, src/models/yolox.py:7-10;
+// SURVEY.md §2.1).  Concats are free: producers write into channel slices of the
+// consumer's buffer; nearest-x2 upsampling is a copy into a slice.
+#include <cmath>
+#include <cstring>
+
+#include "jn_internal.h"
+
+namespace jnr {
+
+namespace {
+
+struct Builder {
+  Net& net;
+  std::vector<ParamEntry>& params;
+  const std::string mod_prefix;   // state-dict prefix of this net ("gpt_backbone.")
+
+  int new_buf(int H, int W, int C) {
+    Buf b; b.H = H; b.W = W; b.C = C;
+    net.bufs.push_back(b);
+    return (int)net.bufs.size() - 1;
+  }
+  View full(int buf) const {
+    const Buf& b = net.bufs[buf];
+    View v; v.buf = buf; v.H = b.H; v.W = b.W; v.C = b.C; v.coff = 0;
+    return v;
+  }
+  static View slice(View v, int coff, int C) { v.coff += coff; v.C = C; return v; }
+  View fresh(int H, int W, int C) { return full(new_buf(H, W, C)); }
+
+  void add_param(const std::string& name, std::initializer_list<int64_t> shape, int dtype, bool buffer, bool used) {
+    ParamEntry e; std::memset(&e, 0, sizeof(e));
+    std::snprintf(e.info.name, sizeof(e.info.name), "%s", name.c_str());
+    e.info.dtype = dtype; e.info.ndim = (int)shape.size();
+    int i = 0; for (auto s : shape) e.info.shape[i++] = s;
+    e.info.is_buffer = buffer; e.info.used = used;
+    params.push_back(e);
+  }
+
+  int add_conv(const std::string& name, int cin, int cout, int k, int groups, bool bn, bool bias) {
+    ConvW w; w.prefix = mod_prefix + name; w.cin = cin; w.cout = cout; w.k = k; w.groups = groups;
+    w.has_bn = bn; w.has_bias = bias;
+    net.convs.push_back(w);
+    if (bn) {
+      add_param(w.prefix + ".conv.weight", {cout, cin / groups, k, k}, 0, false, true);
+      add_param(w.prefix + ".bn.weight", {cout}, 0, false, true);
+      add_param(w.prefix + ".bn.bias", {cout}, 0, false, true);
+      add_param(w.prefix + ".bn.running_mean", {cout}, 0, true, true);
+      add_param(w.prefix + ".bn.running_var", {cout}, 0, true, true);
+      add_param(w.prefix + ".bn.num_batches_tracked", {}, 1, true, false);
+    } else {
+      add_param(w.prefix + ".weight", {cout, cin / groups, k, k}, 0, false, true);
+      if (bias) add_param(w.prefix + ".bias", {cout}, 0, false, true);
+    }
+    return (int)net.convs.size() - 1;
+  }
+
+  static int out_dim(int x, int s) { return (x + 2 - 3) / s + 1; }   // 3x3, pad 1
+
+  // BaseConv(cin, cout, k, s, groups): conv + BN + SiLU.
+  View base_conv(const std::string& name, View in, int cout, int k, int s, bool dw,
+                 const View* dst = nullptr, const View* res = nullptr, int act = ACT_SILU) {
+    int OH = (k == 1) ? in.H : out_dim(in.H, s), OW = (k == 1) ? in.W : out_dim(in.W, s);
+    View out = dst ? *dst : fresh(OH, OW, cout);
+    Op op;
+    op.kind = (k == 1) ? OP_PW : (dw ? OP_DW : OP_CONV3);
+    op.in = in; op.out = out; op.stride = s; op.act = act; op.name = name;
+    if (res) op.res = *res;
+    op.wslot = add_conv(name, in.C, cout, k, dw ? in.C : 1, true, false);
+    net.ops.push_back(op);
+    return out;
+  }
+  // DWConv = depthwise k x k (stride s) + pointwise 1x1.
+  View dw_conv(const std::string& name, View in, int cout, int k, int s,
+               const View* dst = nullptr, const View* res = nullptr) {
+    View d = base_conv(name + ".dconv", in, in.C, k, s, true);
+    return base_conv(name + ".pconv", d, cout, 1, 1, false, dst, res);
+  }
+  View conv(const std::string& name, View in, int cout, int k, int s,
+            const View* dst = nullptr, const View* res = nullptr) {
+    if (net.depthwise) return dw_conv(name, in, cout, k, s, dst, res);
+    return base_conv(name, in, cout, k, s, false, dst, res);
+  }
+  // Bottleneck(c, c, shortcut, expansion=1.0)
+  View bottleneck(const std::string& name, View in, bool shortcut, const View* dst) {
+    View u = base_conv(name + ".conv1", in, in.C, 1, 1, false);
+    return conv(name + ".conv2", u, in.C, 3, 1, dst, shortcut ? &in : nullptr);
+  }
+  View csp(const std::string& name, View in, int cout, int n, bool shortcut, const View* dst = nullptr) {
+    int h = cout / 2;
+    View cat = fresh(in.H, in.W, 2 * h);
+    View s0 = slice(cat, 0, h), s1 = slice(cat, h, h);
+    if (n == 0) {
+      base_conv(name + ".conv1", in, h, 1, 1, false, &s0);
+    } else {
+      View t = base_conv(name + ".conv1", in, h, 1, 1, false);
+      for (int i = 0; i < n; ++i)
+        t = bottleneck(name + ".m." + std::to_string(i), t, shortcut, i == n - 1 ? &s0 : nullptr);
+    }
+    base_conv(name + ".conv2", in, h, 1, 1, false, &s1);
+    return base_conv(name + ".conv3", cat, cout, 1, 1, false, dst);
+  }
+  View spp(const std::string& name, View in, int cout) {
+    int h = in.C / 2;
+    View cat = fresh(in.H, in.W, 4 * h);
+    View s0 = slice(cat, 0, h);
+    base_conv(name + ".conv1", in, h, 1, 1, false, &s0);
+    Op op; op.kind = OP_SPP; op.in = s0; op.out = cat; op.name = name + ".m"; op.act = ACT_NONE;
+    net.ops.push_back(op);
+    return base_conv(name + ".conv2", cat, cout, 1, 1, false);
+  }
+  void upsample(View in, View dst) {
+    Op op; op.kind = OP_UPSAMPLE; op.in = in; op.out = dst; op.name = "upsample"; op.act = ACT_NONE;
+    net.ops.push_back(op);
+  }
+};
+
+}  // namespace
+
+int build_pafpn(Net& net, std::vector<ParamEntry>& params, const std::string& prefix,
+                float depth, float width, bool depthwise, int P) {
+  JN_CHECK(P % 32 == 0 && P >= 32, JN_EINVAL, "patch_size %d must be a multiple of 32", P);
+  net.prefix = prefix; net.depthwise = depthwise; net.depth = depth; net.width = width; net.P = P;
+  Builder b{net, params, prefix};
+  const int bc = (int)(width * 64);
+  const int bd = std::max((int)std::lround(depth * 3), 1);
+  const int c0 = (int)(256 * width), c1 = (int)(512 * width), c2 = (int)(1024 * width);
+  const int n = (int)std::lround(3 * depth);
+  JN_CHECK(bc % 16 == 0, JN_EINVAL, "width %.3f gives %d stem channels; channel counts must be multiples of 16", width, bc);
+  JN_CHECK(c0 == bc * 4 && c1 == bc * 8 && c2 == bc * 16, JN_EINVAL, "unsupported width %.3f", width);
+  const int H2 = P / 2, H4 = P / 4, H8 = P / 8, H16 = P / 16, H32 = P / 32;
+
+  // concat buffers of the PAFPN, allocated first so producers can target their slices
+  View cat_p4 = b.fresh(H16, H16, 2 * c1);
+  View cat_p3 = b.fresh(H8, H8, 2 * c0);
+  View cat_n3 = b.fresh(H16, H16, 2 * c0);
+  View cat_n4 = b.fresh(H32, H32, 2 * c1);
+
+  // ---- CSPDarknet ("backbone.backbone.*") ----
+  View stem = b.fresh(H2, H2, bc);
+  {
+    Op op; op.kind = OP_STEM; op.out = stem; op.act = ACT_SILU; op.name = "backbone.stem.conv";
+    op.in.buf = -1; op.in.H = P; op.in.W = P; op.in.C = 3;
+    op.wslot = b.add_conv("backbone.stem.conv", 12, bc, 3, 1, true, false);
+    net.ops.push_back(op);
+  }
+  View x = b.conv("backbone.dark2.0", stem, bc * 2, 3, 2);
+  x = b.csp("backbone.dark2.1", x, bc * 2, bd, true);
+  x = b.conv("backbone.dark3.0", x, bc * 4, 3, 2);
+  View x2_dst = Builder::slice(cat_p3, c0, c0);
+  View x2 = b.csp("backbone.dark3.1", x, bc * 4, bd * 3, true, &x2_dst);
+  x = b.conv("backbone.dark4.0", x2, bc * 8, 3, 2);
+  View x1_dst = Builder::slice(cat_p4, c1, c1);
+  View x1 = b.csp("backbone.dark4.1", x, bc * 8, bd * 3, true, &x1_dst);
+  x = b.conv("backbone.dark5.0", x1, bc * 16, 3, 2);
+  x = b.spp("backbone.dark5.1", x, bc * 16);
+  View x0 = b.csp("backbone.dark5.2", x, bc * 16, bd, false);
+  (void)H4;
+
+  // ---- PAFPN ----
+  View fpn_out0_dst = Builder::slice(cat_n4, c1, c1);
+  View fpn_out0 = b.base_conv("lateral_conv0", x0, c1, 1, 1, false, &fpn_out0_dst);
+  b.upsample(fpn_out0, Builder::slice(cat_p4, 0, c1));
+  View f_out0 = b.csp("C3_p4", cat_p4, c1, n, false);
+  View fpn_out1_dst = Builder::slice(cat_n3, c0, c0);
+  View fpn_out1 = b.base_conv("reduce_conv1", f_out0, c0, 1, 1, false, &fpn_out1_dst);
+  b.upsample(fpn_out1, Builder::slice(cat_p3, 0, c0));
+  View pan_out2 = b.csp("C3_p3", cat_p3, c0, n, false);
+  View bu2_dst = Builder::slice(cat_n3, 0, c0);
+  b.conv("bu_conv2", pan_out2, c0, 3, 2, &bu2_dst);
+  View pan_out1 = b.csp("C3_n3", cat_n3, c1, n, false);
+  View bu1_dst = Builder::slice(cat_n4, 0, c1);
+  b.conv("bu_conv1", pan_out1, c1, 3, 2, &bu1_dst);
+  View pan_out0 = b.csp("C3_n4", cat_n4, c2, n, false);
+  net.fpn[0] = pan_out2; net.fpn[1] = pan_out1; net.fpn[2] = pan_out0;
+
+  net.buf_off.resize(net.bufs.size());
+  size_t off = 0;
+  for (size_t i = 0; i < net.bufs.size(); ++i) {
+    net.buf_off[i] = off;
+    off += (net.bufs[i].per_image() + 63) / 64 * 64;   // keep every buffer 256-B aligned
+  }
+  net.per_image_floats = off;
+  return JN_OK;
+}
+
+// YOLOXHead parameters ("yolox.head.*"), listed for state-dict compatibility; the op plan
+// of the head is built by the detector module.
+void add_head_params(std::vector<ParamEntry>& params, std::vector<ConvW>& convs, const std::string& prefix,
+                     float width, bool depthwise, int num_classes) {
+  Net dummy; dummy.depthwise = depthwise;
+  Builder b{dummy, params, prefix};
+  const int hid = (int)(256 * width);
+  const int in_ch[3] = {(int)(256 * width), (int)(512 * width), (int)(1024 * width)};
+  auto conv_params = [&](const std::string& name, int cin, int cout) {
+    if (depthwise) {
+      b.add_conv(name + ".dconv", cin, cin, 3, cin, true, false);
+      b.add_conv(name + ".pconv", cin, cout, 1, 1, true, false);
+    } else {
+      b.add_conv(name, cin, cout, 3, 1, true, false);
+    }
+  };
+  for (int k = 0; k < 3; ++k) {
+    const std::string s = std::to_string(k);
+    conv_params("cls_convs." + s + ".0", hid, hid);
+    conv_params("cls_convs." + s + ".1", hid, hid);
+    conv_params("reg_convs." + s + ".0", hid, hid);
+    conv_params("reg_convs." + s + ".1", hid, hid);
+    b.add_conv("cls_preds." + s, hid, num_classes, 1, 1, false, true);
+    b.add_conv("reg_preds." + s, hid, 4, 1, 1, false, true);
+    b.add_conv("obj_preds." + s, hid, 1, 1, 1, false, true);
+    b.add_conv("stems." + s, in_ch[k], hid, 1, 1, true, false);
+  }
+  convs = dummy.convs;
+}
+
+}  // namespace jnr

@@ -1,0 +1,211 @@
+"""``GPT`` — the decision model behind the reference's operator API
+(src/models/gpt.py:143-562), computed by libjnroll.so.
+
+The module owns the parameters under the reference's state-dict names (so reference
+checkpoints load and ``configure_optimizers`` splits by the ``yolox`` prefix exactly as
+gpt.py:547-562) but holds no torch compute graph: ``forward`` uploads the current
+weights (when they changed) and calls ``jn_gpt_forward``.  Eval-mode numerics
+(BatchNorm running statistics, dropout must be 0).
+"""
+import math
+from copy import deepcopy
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, ptr
+from .engine import Engine, make_jn_config, GPT_ZOO
+from .yolox import NeedleYOLOX
+
+
+class _Slot(nn.Module):
+    """Parameter container: structure only, no forward."""
+
+    def forward(self, *a, **k):
+        raise RuntimeError("parameter container of the HIP engine: compute goes through GPT.forward / jn_* calls")
+
+
+def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, is_buffer: bool):
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        nxt = mod._modules.get(p)
+        if nxt is None:
+            nxt = _Slot()
+            mod.add_module(p, nxt)
+        mod = nxt
+    if is_buffer:
+        mod.register_buffer(parts[-1], tensor)
+    else:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor))
+
+
+class GPT(nn.Module):
+    """GPT Language Model driving the glimpse agent (drop-in for src/models/gpt.py:GPT)."""
+
+    @staticmethod
+    def get_default_config():
+        from .config import CfgNode
+        C = CfgNode()
+        C.model_type = "gpt"
+        C.n_layer = C.n_head = C.n_embd = None
+        C.block_size = None
+        C.embd_pdrop = C.resid_pdrop = C.attn_pdrop = 0.1
+        return C
+
+    def __init__(self, config, max_batch: int = 64, device="cuda:0"):
+        super().__init__()
+        assert config.block_size is not None
+        type_given = config.model_type is not None
+        params_given = all(getattr(config, k, None) is not None for k in ("n_layer", "n_head", "n_embd"))
+        assert type_given ^ params_given          # gpt.py:181-189
+        if getattr(config, "dropout", 0.0) != 0.0:
+            raise NotImplementedError("the HIP rollout engine implements the dropout=0 recipes (README.md:56-131)")
+        self.config = config
+        self.block_size = config.block_size
+        self.patch_size = config.patch_size
+        self.image_processor = config.image_processor
+        self.use_pos_emb, self.no_patch_emb = config.use_pos_emb, config.no_patch_emb
+        self.concat_emb, self.decoder_pos_encoding = config.concat_emb, config.decoder_pos_encoding
+        self.token_offset = 1
+        self.device = torch.device(device)
+        self.max_batch = max_batch
+        n_actions = config.actions_info[0].nclasses
+        dev_index = self.device.index or 0
+        self._engine = Engine(make_jn_config(config, dev_index, max_batch, n_actions))
+        self.n_layer, self.n_head, self.n_embd = (self._engine.cfg.n_layer, self._engine.cfg.n_head,
+                                                 self._engine.cfg.n_embd)
+        self._build_parameters()
+        self._uploaded_version = None
+        if self._engine.cfg.with_detector:
+            object.__setattr__(self, "_yolox_view", NeedleYOLOX(self, config.detector_conf_threshold))
+
+    # ---- parameters under the reference's names -------------------------------------
+    def _build_parameters(self):
+        C = self.n_embd
+        for name, shape, dtype, is_buffer, _used in self._engine.param_table():
+            leaf = name.rsplit(".", 1)[-1]
+            if dtype == 1:
+                t = torch.zeros(shape, dtype=torch.long)
+            elif name.endswith("inv_freq"):
+                n = shape[0]
+                ch = 2 * n
+                t = 1.0 / (10000 ** (torch.arange(0, ch, 2).float() / ch))
+            elif name.endswith(".attn.bias"):
+                bs = shape[-1]
+                t = torch.tril(torch.ones(bs, bs)).view(1, 1, bs, bs)
+            elif ".bn." in name:
+                t = torch.ones(shape) if leaf in ("weight", "running_var") else torch.zeros(shape)
+            elif len(shape) == 4:                               # Conv2d default init
+                t = torch.empty(shape)
+                nn.init.kaiming_uniform_(t, a=math.sqrt(5))
+            elif ("ln_" in name) and leaf == "weight":
+                t = torch.ones(shape)
+            elif leaf == "bias":
+                t = torch.zeros(shape)
+                if "cls_preds" in name or "obj_preds" in name:  # YOLOXHead.initialize_biases(1e-2)
+                    t.fill_(-math.log((1 - 1e-2) / 1e-2))
+            else:                                               # Linear / Embedding, gpt.py:536-545
+                t = torch.empty(shape).normal_(0.0, 0.02)
+                if name.endswith("c_proj.weight"):
+                    t.normal_(0.0, 0.02 / math.sqrt(2 * self.n_layer))
+            _attach(self, name, t, is_buffer)
+        if self.decoder_pos_encoding and "wpe" in self.transformer._modules:
+            self.transformer.wpe.weight.requires_grad_(False)   # gpt.py:320-321
+
+    @property
+    def yolox(self):
+        return self._yolox_view
+
+    def engine(self) -> Engine:
+        return self._engine
+
+    def _weights_version(self):
+        return tuple(int(t._version) for t in self.state_dict(keep_vars=True).values())
+
+    def sync_weights(self, force: bool = False):
+        """Upload the current parameters (BN folded, Linear transposed) if they changed."""
+        v = self._weights_version()
+        if force or v != self._uploaded_version:
+            self._engine.load_state_dict(self.state_dict())
+            self._uploaded_version = v
+
+    def load_state_dict(self, state_dict, strict=True):
+        # main.py:541-543 strips DDP's "module." prefix before loading
+        state_dict = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        out = super().load_state_dict(state_dict, strict=strict)
+        self._uploaded_version = None
+        return out
+
+    # ---- forward ----------------------------------------------------------------------
+    def forward(self, patches, actions, classes, positions=None, prev_embeddings=None):
+        """Same contract as src/models/gpt.py:481-534 (eval mode).  ``classes`` must be 0
+        (the reference never passes anything else, src/reinforce.py:128-129)."""
+        seq_len = actions.shape[1]
+        assert seq_len <= self.block_size, \
+            f"Cannot forward sequence of length {seq_len}, block size is only {self.block_size}"
+        assert (not self.use_pos_emb) or (positions is not None)
+        assert actions.dim() == 2, "single categorical action only"
+        if getattr(self.config, "no_recurrent_embedding", False):
+            prev_embeddings = None
+        self.sync_weights()
+        dev = self.device
+        B = actions.shape[0]
+        C, nA = self.n_embd, self._engine.cfg.n_actions
+        patches = None if self.no_patch_emb else patches.to(dev, torch.float32).contiguous()
+        actions = actions.to(dev, torch.int64).contiguous()
+        positions = None if positions is None else positions.to(dev, torch.int64).contiguous()
+        Tp = 0
+        if prev_embeddings is not None:
+            prev_embeddings = prev_embeddings.to(dev, torch.float32).contiguous()
+            Tp = prev_embeddings.shape[1]
+        L = Tp + 1 if prev_embeddings is not None else seq_len + 1
+        logits = torch.empty((B, L - 1, nA), device=dev, dtype=torch.float32)
+        final_emb = torch.empty((B, L, C), device=dev, dtype=torch.float32)
+        lib = self._engine.lib
+        check(lib.jn_gpt_forward(self._engine.handle, ptr(patches), ptr(actions), ptr(positions),
+                                 ptr(prev_embeddings), B, seq_len, Tp, ptr(logits), ptr(final_emb),
+                                 _lib.current_stream(dev)), "jn_gpt_forward")
+        return logits, final_emb
+
+    def embed_patches(self, patches):
+        """[B, T, 3, P, P] -> [B, T, n_embd] (src/models/gpt.py:356-384)."""
+        self.sync_weights()
+        B, T = patches.shape[:2]
+        flat = patches.to(self.device, torch.float32).reshape(B * T, *patches.shape[2:]).contiguous()
+        out = torch.empty((B * T, self.n_embd), device=self.device, dtype=torch.float32)
+        lib = self._engine.lib
+        for i in range(0, B * T, self.max_batch):
+            n = min(self.max_batch, B * T - i)
+            check(lib.jn_embed_patches(self._engine.handle, ptr(flat[i:i + n]), n, ptr(out[i:i + n]),
+                                       _lib.current_stream(self.device)), "jn_embed_patches")
+        return out.view(B, T, -1)
+
+    def backbone_features(self, patches, net=None):
+        """fpn_outs of the patch encoder (gpt.py:375) or of the detector backbone, NCHW."""
+        self.sync_weights()
+        cfg = self._engine.cfg
+        if net is None:
+            net = _lib.JN_NET_GPT_BACKBONE if cfg.gpt_bb_width > 0 else _lib.JN_NET_DETECTOR
+        width = cfg.gpt_bb_width if net == _lib.JN_NET_GPT_BACKBONE else cfg.det_width
+        N, P = patches.shape[0], self.patch_size
+        x = patches.to(self.device, torch.float32).contiguous()
+        chans = [int(256 * width), int(512 * width), int(1024 * width)]
+        outs = [torch.empty((N, c, P // s, P // s), device=self.device) for c, s in zip(chans, (8, 16, 32))]
+        lib = self._engine.lib
+        for i in range(0, N, self.max_batch):
+            n = min(self.max_batch, N - i)
+            check(lib.jn_backbone_forward(self._engine.handle, net, ptr(x[i:i + n]), n, ptr(outs[0][i:i + n]),
+                                          ptr(outs[1][i:i + n]), ptr(outs[2][i:i + n]),
+                                          _lib.current_stream(self.device)), "jn_backbone_forward")
+        return tuple(outs)
+
+    def configure_optimizers(self, train_config):
+        """gpt.py:547-562: everything not under ``yolox`` vs the detector."""
+        optim_gpt = torch.optim.AdamW(
+            params=[p for pn, p in self.named_parameters() if not pn.startswith("yolox")],
+            lr=train_config.learning_rate)
+        yolo_params = [p for pn, p in self.named_parameters() if pn.startswith("yolox")]
+        optim_yolox = torch.optim.AdamW(params=yolo_params, lr=train_config.yolo_lr) if yolo_params else None
+        return optim_gpt, optim_yolox

@@ -1,0 +1,125 @@
+"""``ReinforceTrainer.rollout`` and the REINFORCE metrics of the reference
+(src/reinforce.py:73-265) over ``jn_rollout``: the whole trajectory of the whole batch is
+enqueued on the current stream, with no host synchronisation until the step count is read."""
+import ctypes as C
+from typing import Dict
+
+import torch
+
+from . import _lib
+from ._lib import JnRolloutOut, check, ptr
+from .env import NeedleGeneralEnv
+
+
+class ReinforceTrainer:
+    """Rollout / loss part of the reference trainer (dataset, Visdom, checkpoints are
+    out of scope).  ``config`` needs max_seq_len, entropy_weight,
+    stop_enabled, reward_norm (main.py:310-388)."""
+
+    def __init__(self, config, model, logger=None, train_dataset=None, test_dataset=None, rank: int = 0):
+        self.config, self.model, self.logger, self.rank = config, model, logger, rank
+        self.patch_size = model.patch_size
+        self.max_ep_len = config.max_seq_len
+        self.entropy_weight = config.entropy_weight
+        self.n_glimps_levels = 1
+        self.stop_enabled = config.stop_enabled
+        self.device = model.device
+        self.best_metric_name = "prop_patches_found"
+        self.last_return_values = []
+        self.last_return_mean = 0
+        self.last_return_std = 1
+        self.seed = int(getattr(config, "seed", 0))
+        self._rollouts = 0
+
+    def yolox_model(self):
+        return self.model.yolox
+
+    @torch.no_grad()
+    def _compute_last_returns_mean_std(self):
+        allv = torch.cat(self.last_return_values) if self.last_return_values else torch.zeros(0)
+        if len(allv) == 0:
+            mean, std = 0, 1
+        elif len(allv) == 1:
+            mean, std = allv[0], 1
+        else:
+            mean, std = allv.mean(), allv.std()
+        self.last_return_mean, self.last_return_std = mean, std
+        self.last_return_values = []
+
+    def rollout(self, env: NeedleGeneralEnv, do_detection: bool = False, sample_actions: bool = True,
+                forced_actions: torch.Tensor = None, start_positions: torch.Tensor = None,
+                keep_patches: bool = True, stop_early: bool = True) -> Dict[str, torch.Tensor]:
+        """src/reinforce.py:108-215.  Extra keyword arguments (not in the reference):
+        `forced_actions` [B,T] replays a trajectory, `start_positions` [B,2] injects reset
+        positions (reference: env.reset(positions)), `keep_patches=False` skips the
+        [B,S+1,3,P,P] patch stack, `stop_early=False` always runs max_ep_len steps."""
+        model, dev = self.model, self.device
+        model.sync_weights()
+        eng = model.engine()
+        env.bind(eng)
+        B, T, P = env.batch_size, env.max_ep_len, env.patch_size
+        C_, nA = model.n_embd, eng.cfg.n_actions
+        f32 = dict(device=dev, dtype=torch.float32)
+        buf = {
+            "rewards": torch.empty((B, T), **f32), "returns": torch.empty((B, T), **f32),
+            "logprobs": torch.empty((B, T), **f32), "entropies": torch.empty((B, T), **f32),
+            "masks": torch.empty((B, T + 1), device=dev, dtype=torch.uint8),
+            "logit_masks": torch.empty((B, T), device=dev, dtype=torch.uint8),
+            "positions": torch.empty((B, T + 1, 2), device=dev, dtype=torch.int64),
+            "actions": torch.empty((B, T), device=dev, dtype=torch.int64),
+            "logits": torch.empty((B, T, nA), **f32),
+            "final_emb": torch.empty((B, T + 1, C_), **f32),
+        }
+        patches = torch.empty((B, T + 1, 3, P, P), **f32) if keep_patches else None
+        out = JnRolloutOut()
+        for k, t in buf.items():
+            setattr(out, k + "_dev", t.data_ptr())
+        out.patches_dev = patches.data_ptr() if patches is not None else None
+        if forced_actions is not None:
+            mode = _lib.JN_MODE_FORCED
+            forced_actions = forced_actions.to(dev, torch.int64).contiguous()
+        else:
+            mode = _lib.JN_MODE_SAMPLE if sample_actions else _lib.JN_MODE_GREEDY
+        if start_positions is not None:
+            start_positions = start_positions.to(dev, torch.int64).contiguous()
+        self._rollouts += 1
+        seed = (self.seed * 1000003 + self._rollouts) & 0xFFFFFFFFFFFFFFFF
+        stream = _lib.current_stream(dev)
+        check(eng.lib.jn_rollout(eng.handle, mode, ptr(forced_actions), ptr(start_positions), seed,
+                                 int(do_detection), int(stop_early), C.byref(out), stream), "jn_rollout")
+        S = C.c_int()
+        check(eng.lib.jn_rollout_steps(eng.handle, C.byref(S), stream), "jn_rollout_steps")
+        S = S.value
+        res = {
+            "rewards": buf["rewards"][:, :S], "returns": buf["returns"][:, :S],
+            "logprobs": buf["logprobs"][:, :S], "entropies": buf["entropies"][:, :S],
+            "masks": buf["masks"][:, :S + 1].bool(), "logit_masks": buf["logit_masks"][:, :S].bool(),
+            "positions": buf["positions"][:, :S + 1], "bboxes": [[] for _ in range(B)],
+            "patches": patches[:, :S + 1] if patches is not None else None,
+            "actions": buf["actions"][:, :S], "logits": buf["logits"][:, :S],
+            "final_emb": buf["final_emb"][:, :S + 1],
+        }
+        return res
+
+    def compute_metrics(self, rollout: Dict[str, torch.Tensor], env: NeedleGeneralEnv = None):
+        """src/reinforce.py:217-265."""
+        metrics = dict()
+        returns, masks = rollout["returns"], rollout["logit_masks"]
+        if self.config.reward_norm:
+            self.last_return_values.append(returns[masks].clone().detach())
+            mean, std = self.last_return_mean, self.last_return_std
+            advantages = (returns - mean) / (std + 1e-8)
+        else:
+            advantages = returns
+        metrics["action_loss"] = -(rollout["logprobs"] * advantages * masks).sum() / masks.sum()
+        metrics["entropy_loss"] = -(rollout["entropies"] * masks).sum() / masks.sum()
+        metrics["loss"] = metrics["action_loss"] + self.entropy_weight * metrics["entropy_loss"]
+        metrics["returns"] = (rollout["rewards"] * masks).sum(dim=1).mean()
+        metrics["episode_length"] = masks.sum(dim=1).float().mean()
+        if env:
+            metrics["prop_patches_found"] = env.prop_patches_found[0]
+            metrics["prop_bbox_found"] = env.prop_bboxes_found[0]
+            if self.stop_enabled:
+                metrics["stop_used"] = env.terminated[0].to(torch.float32)
+                metrics["stop_misused"] = (env.terminated[0] and env.prop_patches_found[0] < 1).to(torch.float32)
+        return metrics

@@ -47,6 +47,9 @@ class EnvRef:
 
     def __init__(self, images: torch.Tensor, bboxes: torch.Tensor, patch_size: int,
                  max_ep_len: int, n_glimps_levels: int = 1, stop_enabled: bool = False):
+        if not torch.is_tensor(images):               # shape tuple: state-only env (no patch gather)
+            self._shape_only = tuple(images)
+            images = torch.zeros((images[0], images[1], 1, 1)).expand(*images)
         assert images.shape[0] == bboxes.shape[0] and images.dim() == 4
         assert n_glimps_levels == 1
         self.patch_size, self.max_ep_len, self.stop_enabled = patch_size, max_ep_len, stop_enabled
@@ -73,6 +76,8 @@ class EnvRef:
 
     @property
     def patches(self) -> torch.Tensor:
+        if getattr(self, "_shape_only", None):
+            return None
         P = self.patch_size
         return torch.stack([
             self.images[i, :, :, int(y) * P:(int(y) + 1) * P, int(x) * P:(int(x) + 1) * P]

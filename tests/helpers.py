@@ -38,3 +38,30 @@ def synth_tokens(B, T, P, nA, grid, seed):
     actions = torch.randint(0, nA, (B, T), generator=g)
     positions = torch.randint(0, grid, (B, T, 2), generator=g)
     return patches, actions, positions
+
+
+def model_config(**kw):
+    """Reference-style model_config (main.py:367-386) for the product GPT."""
+    import jolineedle_amd as ja
+    cfg = dict(model_type="gpt-nano", n_layer=None, n_head=None, n_embd=None, block_size=20, patch_size=448,
+               image_processor="yolox-s", gpt_backbone="yolox-nano", use_pos_emb=True, no_patch_emb=False,
+               concat_emb=True, decoder_pos_encoding=True, pos_emb_size=25, dropout=0.0,
+               detector_conf_threshold=0.5, no_recurrent_embedding=False, with_detector=True, nclasses=9)
+    cfg.update(kw)
+    n = cfg.pop("nclasses")
+    cfg["actions_info"] = [ja.ActionInfo("categorical", n)]
+    return ja.CfgNode(**cfg)
+
+
+def make_pair(seed=0, bn_seed=5, max_batch=8, **kw):
+    """(product GPT on the GPU engine, oracle GPTRef on CPU) holding the same weights."""
+    import jolineedle_amd as ja
+    from oracle.gpt_ref import build_gpt_ref
+    okw = dict(kw)
+    oracle = build_gpt_ref(seed, **okw)
+    if bn_seed is not None:
+        randomize_bn(oracle, bn_seed)
+    oracle.eval()
+    product = ja.GPT(model_config(**kw), max_batch=max_batch)
+    product.load_state_dict(oracle.state_dict())
+    return product, oracle

@@ -1,0 +1,332 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the
+golden vectors.  Run on the MI355X box: python -m pytest tests -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+import jolineedle_amd as ja
+from jolineedle_amd import _lib
+from jolineedle_amd._lib import check, ptr
+from tests.helpers import make_pair, model_config, randomize_bn, synth_batch, synth_tokens
+
+pytestmark = pytest.mark.gpu
+T_ = torch.from_numpy
+DEV = "cuda:0"
+# tolerance of BASELINE.json's north star: logits / boxes within 1e-3 of the CPU reference;
+# fp32 activations + exact-fp32 MFMA keep the maps themselves to ~1e-4.
+TOL_MAP = 2e-4
+TOL_LOGIT = 1e-4
+
+
+def _cfg(**kw):
+    return ja.CfgNode(max_seq_len=kw.pop("T", 6), entropy_weight=0.01, stop_enabled=kw.pop("stop", True),
+                      reward_norm=True, seed=1, **kw)
+
+
+# --------------------------------------------------------------------------------------
+# integer / byte work: bit exact
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,C,G,P", [(3, 3, (4, 5), 16), (2, 3, (2, 3), 448), (5, 3, (3, 3), 30), (1, 1, (1, 1), 7)])
+def test_gather_bit_exact(B, C, G, P):
+    g = torch.Generator().manual_seed(B * 100 + P)
+    H, W = G[0] * P, G[1] * P
+    images = torch.rand((B, C, H, W), generator=g).to(DEV)
+    pos = torch.stack((torch.randint(0, G[0], (B,), generator=g), torch.randint(0, G[1], (B,), generator=g)), 1)
+    out = torch.full((B, C, P, P), -1.0, device=DEV)
+    lib = _lib.load_library()
+    check(lib.jn_gather_patches(ptr(images), ptr(pos.to(DEV)), ptr(out), B, C, H, W, P, _lib.current_stream(torch.device(DEV))))
+    torch.cuda.synchronize()
+    ref = torch.stack([images[b, :, y * P:(y + 1) * P, x * P:(x + 1) * P] for b, (y, x) in enumerate(pos.tolist())])
+    assert torch.equal(out, ref)
+
+
+def test_gather_empty_batch():
+    lib = _lib.load_library()
+    x = torch.zeros(4, device=DEV)
+    check(lib.jn_gather_patches(ptr(x), ptr(x), ptr(x), 0, 3, 16, 16, 16, None))
+
+
+def test_env_reference_test_case(golden):
+    """tests/test_env.py:10-31 of the reference through the device env."""
+    g = golden("g1_env.npz")
+    images = torch.zeros(1, 3, 1792, 2240, device=DEV)
+    env = ja.NeedleGeneralEnv(images, torch.tensor([[[310, 810, 400, 850], [700, 1500, 800, 1600]]]), 448, 8, 1)
+    patches, infos = env.reset(torch.tensor([[1, 0]]))
+    assert torch.equal(infos["positions"].cpu(), torch.tensor([[1, 0]]))
+    assert np.array_equal(env.bbox_masks.cpu().numpy(), g["t_env_bbox_masks"])
+    for t, a in enumerate(g["t_env_actions"]):
+        patches, r, te, tr, infos = env.step(torch.tensor([int(a)]))
+        assert np.array_equal(r.cpu().numpy(), g["t_env_rewards"][:, t])
+        assert np.array_equal(te.cpu().numpy(), g["t_env_terminated"][:, t])
+    assert torch.equal(infos["positions"].cpu(), torch.tensor([[3, 1]]))
+    assert patches.shape == (1, 1, 3, 448, 448)
+
+
+@pytest.mark.parametrize("tag,stop", [("nostop", False), ("stop", True)])
+def test_env_random_walks_golden(golden, tag, stop):
+    """Reference env replays (sticky STOP, reward-before-visited, padding rows, clamping)."""
+    g = golden("g1_env.npz")
+    images, bboxes, start = T_(g[f"{tag}_images"]), T_(g[f"{tag}_bboxes"]), T_(g[f"{tag}_start"])
+    acts = T_(g[f"{tag}_actions"])
+    P = images.shape[-1] // 5
+    env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, acts.shape[1], 1, stop)
+    assert np.array_equal(env.bbox_masks.cpu().numpy(), g[f"{tag}_bbox_masks"])
+    p, info = env.reset(start)
+    pats = [p]
+    for t in range(acts.shape[1]):
+        p, r, te, tr, info = env.step(acts[:, t])
+        pats.append(p)
+        assert np.array_equal(r.cpu().numpy(), g[f"{tag}_rewards"][:, t]), (tag, t)
+        assert np.array_equal(te.cpu().numpy(), g[f"{tag}_terminated"][:, t])
+        assert np.array_equal(tr.cpu().numpy(), g[f"{tag}_truncated"][:, t])
+        assert np.array_equal(info["positions"].cpu().numpy(), g[f"{tag}_positions"][:, t + 1])
+        assert np.array_equal(env.visited_patches.cpu().numpy(), g[f"{tag}_visited"][:, t])
+    assert np.array_equal(torch.cat(pats, 1).cpu().numpy(), g[f"{tag}_patches"])
+    assert np.array_equal(env.prop_patches_found.cpu().numpy(), g[f"{tag}_prop_patches_found"])
+
+
+def test_env_asserts_like_reference():
+    with pytest.raises(AssertionError):
+        ja.NeedleGeneralEnv(torch.zeros(1, 3, 100, 64, device=DEV), torch.zeros(1, 1, 4, dtype=torch.long), 32, 4)
+    with pytest.raises(AssertionError):
+        ja.NeedleGeneralEnv(torch.zeros(2, 3, 64, 64, device=DEV), torch.zeros(1, 1, 4, dtype=torch.long), 32, 4)
+
+
+# --------------------------------------------------------------------------------------
+# conv stack
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("P,N", [(64, 3), (96, 2), (448, 2)])
+def test_nano_backbone_fpn_maps(P, N):
+    product, oracle = make_pair(3, patch_size=P, block_size=6, with_detector=False, image_processor=None)
+    x = torch.rand((N, 3, P, P), generator=torch.Generator().manual_seed(P))
+    with torch.no_grad():
+        ref = oracle.gpt_backbone(x)
+    got = product.backbone_features(x)
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert got[i].shape == ref[i].shape
+        err = (got[i].cpu() - ref[i]).abs().max().item()
+        assert err < TOL_MAP, (i, err)
+
+
+def test_backbone_golden_and_patch_embedding(golden):
+    g = golden("g3_gpt_forward.npz")
+    product, oracle = make_pair(int(g["seed"]), int(g["bn_seed"]), patch_size=64, block_size=6,
+                                image_processor="yolox-nano", gpt_backbone="yolox-nano")
+    patches, actions, positions = synth_tokens(3, 6, 64, 9, 5, seed=int(g["tok_seed"]))
+    fpn = product.backbone_features(patches[:, 0])
+    for i in range(3):
+        assert np.allclose(fpn[i].cpu().numpy(), g[f"fpn{i}"], atol=TOL_MAP), i
+    emb = product.embed_patches(patches[:, :2])
+    assert np.allclose(emb.cpu().numpy(), g["patch_emb"], atol=TOL_MAP)
+
+
+# --------------------------------------------------------------------------------------
+# decision model
+# --------------------------------------------------------------------------------------
+def test_gpt_forward_full_and_recurrent_golden(golden):
+    """Reference GPT.forward outputs (full sequence and recurrent incl. the position-0 quirk)."""
+    g = golden("g3_gpt_forward.npz")
+    product, _ = make_pair(int(g["seed"]), int(g["bn_seed"]), patch_size=64, block_size=6,
+                           image_processor="yolox-nano", gpt_backbone="yolox-nano")
+    patches, actions, positions = synth_tokens(3, 6, 64, 9, 5, seed=int(g["tok_seed"]))
+    classes = torch.zeros(3, dtype=torch.long)
+    lg, emb = product(patches, actions, classes, positions)
+    assert np.allclose(lg.cpu().numpy(), g["full_logits"], atol=TOL_LOGIT)
+    assert np.allclose(emb.cpu().numpy(), g["full_emb"], atol=TOL_LOGIT)
+    e, rec = None, []
+    for t in range(6):
+        l, e = product(patches[:, :t + 1], actions[:, :t + 1], classes, positions[:, :t + 1], e)
+        assert l.shape == (3, t + 1, 9) and e.shape == (3, t + 2, 48)
+        rec.append(l[:, -1])
+    assert np.allclose(torch.stack(rec, 1).cpu().numpy(), g["rec_logits"], atol=TOL_LOGIT)
+    assert np.allclose(e.cpu().numpy(), g["rec_emb"], atol=TOL_LOGIT)
+
+
+@pytest.mark.parametrize("kw", [dict(concat_emb=False), dict(decoder_pos_encoding=False, nclasses=8),
+                                dict(use_pos_emb=False), dict(model_type="gpt-mini"),
+                                dict(gpt_backbone=None, image_processor="yolox-nano")])
+def test_gpt_forward_variants_vs_oracle(kw):
+    base = dict(patch_size=64, block_size=5, image_processor="yolox-nano", gpt_backbone="yolox-nano")
+    base.update(kw)
+    product, oracle = make_pair(7, **base)
+    nA = base.get("nclasses", 9)
+    patches, actions, positions = synth_tokens(2, 5, 64, nA, 5, seed=11)
+    classes = torch.zeros(2, dtype=torch.long)
+    with torch.no_grad():
+        rl, re = oracle(patches, actions, classes, positions)
+    lg, emb = product(patches, actions, classes, positions)
+    assert (lg.cpu() - rl).abs().max() < TOL_LOGIT and (emb.cpu() - re).abs().max() < TOL_LOGIT
+    with torch.no_grad():
+        e_o, e_p = None, None
+        for t in range(3):
+            lo, e_o = oracle(patches[:, :t + 1], actions[:, :t + 1], classes, positions[:, :t + 1], e_o)
+            lp, e_p = product(patches[:, :t + 1], actions[:, :t + 1], classes, positions[:, :t + 1], e_p)
+            assert (lp.cpu() - lo).abs().max() < TOL_LOGIT
+
+
+def test_gpt_forward_asserts_like_reference():
+    product, _ = make_pair(7, patch_size=64, block_size=4, image_processor="yolox-nano")
+    patches, actions, positions = synth_tokens(1, 5, 64, 9, 5, seed=1)
+    with pytest.raises(AssertionError, match="Cannot forward sequence of length 5"):
+        product(patches, actions, torch.zeros(1, dtype=torch.long), positions)
+    with pytest.raises(AssertionError):
+        product(patches[:, :2], actions[:, :2], torch.zeros(1, dtype=torch.long), None)
+
+
+# --------------------------------------------------------------------------------------
+# the rollout
+# --------------------------------------------------------------------------------------
+def test_rollout_greedy_golden(golden):
+    """ReinforceTrainer.rollout of the reference (greedy) + compute_metrics, golden g4."""
+    g = golden("g4_rollout.npz")
+    g3 = golden("g3_gpt_forward.npz")
+    P, Tn = int(g["P"]), int(g["T"])
+    product, _ = make_pair(int(g3["seed"]), int(g3["bn_seed"]), patch_size=P, block_size=Tn,
+                           image_processor="yolox-nano", gpt_backbone="yolox-nano")
+    images, bboxes, _ = synth_batch(4, 4, 5, P, seed=int(g["batch_seed"]))
+    env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True)
+    tr = ja.ReinforceTrainer(_cfg(T=Tn), product)
+    ro = tr.rollout(env, sample_actions=False, start_positions=T_(g["start"]))
+    for k in ("masks", "logit_masks", "positions"):
+        assert np.array_equal(ro[k].cpu().numpy(), g[k]), k
+    assert np.array_equal(ro["rewards"].cpu().numpy(), g["rewards"])
+    for k in ("returns", "logprobs", "entropies"):
+        assert np.allclose(ro[k].cpu().numpy(), g[k], atol=TOL_LOGIT), k
+    assert ro["patches"].shape == (4, g["masks"].shape[1], 3, P, P)
+    pos = ro["positions"].cpu()
+    for b in range(4):
+        for t in range(pos.shape[1]):
+            y, x = pos[b, t].tolist()
+            assert torch.equal(ro["patches"][b, t].cpu(), images[b, :, y * P:(y + 1) * P, x * P:(x + 1) * P])
+    m1 = tr.compute_metrics(ro)
+    tr._compute_last_returns_mean_std()
+    m2 = tr.compute_metrics(ro)
+    assert np.allclose(float(tr.last_return_mean), g["norm_mean"], atol=1e-5)
+    assert np.allclose(float(tr.last_return_std), g["norm_std"], atol=1e-5)
+    for tag, mm in (("m1", m1), ("m2", m2)):
+        for k, v in mm.items():
+            assert np.allclose(float(v), g[f"{tag}.{k}"], atol=2e-4), (tag, k)
+
+
+@pytest.mark.parametrize("stop,B,P,Tn", [(False, 5, 64, 7), (True, 3, 96, 5)])
+def test_rollout_forced_vs_oracle(stop, B, P, Tn):
+    from oracle import env_ref, rollout_ref
+    nA = 9 if stop else 8
+    product, oracle = make_pair(5, patch_size=P, block_size=Tn, nclasses=nA, image_processor="yolox-nano")
+    images, bboxes, start = synth_batch(B, 3, 4, P, seed=31)
+    forced = torch.randint(0, nA, (B, Tn), generator=torch.Generator().manual_seed(9))
+    envo = env_ref.EnvRef(images, bboxes, P, Tn, 1, stop)
+    with torch.no_grad():
+        ref = rollout_ref.rollout(oracle, envo, forced_actions=forced, start_positions=start, stop_early=True)
+    env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, stop)
+    ro = ja.ReinforceTrainer(_cfg(T=Tn, stop=stop), product).rollout(env, forced_actions=forced, start_positions=start)
+    S = ref["rewards"].shape[1]
+    assert ro["rewards"].shape[1] == S
+    for k in ("masks", "logit_masks", "positions", "actions"):
+        assert torch.equal(ro[k].cpu(), ref[k]), k
+    assert torch.equal(ro["rewards"].cpu(), ref["rewards"])
+    for k in ("returns", "logprobs", "entropies", "logits"):
+        assert (ro[k].cpu() - ref[k]).abs().max() < TOL_LOGIT, k
+    assert torch.equal(ro["patches"].cpu(), ref["patches"])       # bit exact gather inside the loop
+
+
+def test_rollout_early_stop_and_full_length():
+    """All agents STOP at step 2: reference breaks (reinforce.py:181-184) -> S == 2."""
+    from oracle import env_ref, rollout_ref
+    P, Tn, B = 64, 6, 3
+    product, oracle = make_pair(5, patch_size=P, block_size=Tn, image_processor="yolox-nano")
+    images, bboxes, start = synth_batch(B, 3, 3, P, seed=2)
+    forced = torch.tensor([[1, 8, 0, 0, 0, 0], [8, 3, 0, 0, 0, 0], [2, 8, 0, 0, 0, 0]])
+    env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True)
+    tr = ja.ReinforceTrainer(_cfg(T=Tn), product)
+    ro = tr.rollout(env, forced_actions=forced, start_positions=start)
+    assert ro["rewards"].shape == (B, 2) and ro["masks"].shape == (B, 3) and ro["patches"].shape[1] == 3
+    with torch.no_grad():
+        ref = rollout_ref.rollout(oracle, env_ref.EnvRef(images, bboxes, P, Tn, 1, True), forced_actions=forced,
+                                  start_positions=start)
+    assert torch.equal(ro["masks"].cpu(), ref["masks"]) and torch.equal(ro["rewards"].cpu(), ref["rewards"])
+    assert (ro["returns"].cpu() - ref["returns"]).abs().max() < 1e-6
+    full = tr.rollout(env, forced_actions=forced, start_positions=start, stop_early=False)
+    assert full["rewards"].shape == (B, Tn)
+    assert torch.equal(full["rewards"][:, :2].cpu(), ref["rewards"])
+
+
+def test_rollout_sampling_statistics():
+    """Sampled mode cannot match torch's RNG stream; check the action histogram of step 0
+    against the softmax of the (deterministic) step-0 logits with a chi-square bound."""
+    P, Tn, B = 32, 2, 1
+    product, _ = make_pair(5, patch_size=P, block_size=Tn, image_processor="yolox-nano", max_batch=1)
+    with torch.no_grad():
+        product.action_head.lm_heads._modules["0"].weight.mul_(40.0)     # spread the distribution
+    images, bboxes, start = synth_batch(B, 3, 3, P, seed=4)
+    env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True)
+    tr = ja.ReinforceTrainer(_cfg(T=Tn), product)
+    n, counts, probs = 600, torch.zeros(9), None
+    for i in range(n):
+        ro = tr.rollout(env, sample_actions=True, start_positions=start, keep_patches=False, stop_early=False)
+        counts[int(ro["actions"][0, 0])] += 1
+        if probs is None:
+            probs = torch.softmax(ro["logits"][0, 0].cpu(), -1)
+            assert torch.isclose(ro["logprobs"][0, 0].cpu(), torch.log(probs[int(ro["actions"][0, 0])]), atol=1e-5)
+            assert torch.isclose(ro["entropies"][0, 0].cpu(), -(probs * probs.log()).sum(), atol=1e-5)
+    chi2 = float((((counts - n * probs) ** 2) / (n * probs)).sum())
+    assert chi2 < 32.9, (chi2, counts.tolist(), probs.tolist())    # chi2(8 dof) 99.99th percentile
+    assert probs.max() < 0.9
+
+
+def test_full_size_c3_properties():
+    """BASELINE config 3 sizes (448 px, seq-len 20, STOP, 4480x4480 images) at a batch the
+    test box holds comfortably; size-independent properties + an oracle spot check."""
+    from oracle import env_ref
+    P, Tn, B, G = 448, 20, 8, 10
+    product, oracle = make_pair(1, patch_size=P, block_size=Tn, with_detector=False, image_processor=None,
+                                max_batch=B)
+    gen = torch.Generator(device=DEV).manual_seed(12345)
+    images = torch.rand((B, 3, G * P, G * P), device=DEV, generator=gen)
+    g = torch.Generator().manual_seed(12345)
+    bboxes = torch.zeros((B, 3, 4), dtype=torch.long)
+    for b in range(B):
+        for k in range(int(torch.randint(1, 4, (1,), generator=g))):
+            w, h = (int(torch.randint(32, P, (1,), generator=g)) for _ in range(2))
+            x, y = int(torch.randint(0, G * P - w, (1,), generator=g)), int(torch.randint(0, G * P - h, (1,), generator=g))
+            bboxes[b, k] = torch.tensor([x, y, x + w, y + h])
+    start = torch.randint(0, G, (B, 2), generator=g)
+    forced = torch.randint(0, 8, (B, Tn), generator=g)              # non-STOP: S == T
+    env = ja.NeedleGeneralEnv(images, bboxes, P, Tn, 1, True)
+    tr = ja.ReinforceTrainer(_cfg(T=Tn), product)
+    ro = tr.rollout(env, forced_actions=forced, start_positions=start)
+    assert ro["rewards"].shape == (B, Tn)
+    # (1) env trajectory equals the oracle env replay (integer exact); images are not needed for it
+    envo = env_ref.EnvRef((B, 3, G * P, G * P), bboxes, P, Tn, 1, True)
+    _, info = envo.reset(start)
+    pos, rew = [info["positions"].clone()], []
+    for t in range(Tn):
+        _, r, te, trc, info = envo.step(forced[:, t])
+        rew.append(r); pos.append(info["positions"].clone())
+    assert torch.equal(ro["positions"].cpu(), torch.stack(pos, 1))
+    assert torch.equal(ro["rewards"].cpu(), torch.stack(rew, 1))
+    # (2) patches are bit-exact slices of the images at the visited positions
+    p = ro["positions"]
+    for b in range(B):
+        for t in (0, 7, Tn):
+            y, x = p[b, t].tolist()
+            assert torch.equal(ro["patches"][b, t], images[b, :, y * P:(y + 1) * P, x * P:(x + 1) * P])
+    # (3) returns are suffix sums of the masked rewards; logit_masks is the rolled mask
+    lm = ro["logit_masks"].float()
+    sfx = torch.flip(torch.cumsum(torch.flip(ro["rewards"] * lm, (1,)), 1), (1,))
+    assert torch.allclose(ro["returns"], sfx, atol=1e-5)
+    assert torch.equal(ro["logit_masks"][:, 1:], ro["masks"][:, 1:-1]) and bool(ro["logit_masks"][:, 0].all())
+    # (4) log-probs / entropies are consistent with the logits; probabilities sum to one
+    lsm = torch.log_softmax(ro["logits"], -1)
+    assert torch.allclose(lsm.gather(2, ro["actions"][..., None]).squeeze(2), ro["logprobs"], atol=1e-5)
+    assert torch.allclose(-(lsm.exp() * lsm).sum(-1), ro["entropies"], atol=1e-5)
+    # (5) oracle spot check on 2 agents x 3 steps at full patch size (logits within 1e-3, north star)
+    with torch.no_grad():
+        for b in (0, B - 1):
+            e = None
+            for t in range(3):
+                pt = ro["patches"][b:b + 1, :t + 1].cpu()
+                acts = torch.cat((torch.zeros(1, 1, dtype=torch.long), forced[b:b + 1, :t]), 1)
+                lg, e = oracle(pt, acts, torch.zeros(1, dtype=torch.long), ro["positions"][b:b + 1, :t + 1].cpu(), e)
+                assert (lg[0, -1] - ro["logits"][b, t].cpu()).abs().max() < 1e-3

@@ -1,0 +1,113 @@
+"""CPU-only checks of the boundary: the C-ABI library loads and exports every declared
+symbol, the state-dict table matches the oracle / reference names, host-side logic."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+import jolineedle_amd as ja
+from jolineedle_amd import _lib
+from jolineedle_amd.engine import Engine, make_jn_config
+from tests.helpers import model_config
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load_library()
+    header = (ROOT / "include" / "jnroll.h").read_text()
+    declared = set(re.findall(r"\b(jn_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.jn_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+    header = (ROOT / "include" / "jnroll.h").read_text()
+    body = header[header.index("typedef struct jn_config {"):header.index("} jn_config;")]
+    fields = []
+    for line in body.splitlines()[1:]:
+        line = line.split("/*")[0].strip()
+        m = re.match(r"(int32_t|float)\s+([^;]+);", line)
+        if m:
+            fields += [f.strip() for f in m.group(2).split(",")]
+    assert fields == [f[0] for f in _lib.JnConfig._fields_]
+    body = header[header.index("typedef struct jn_rollout_out {"):header.index("} jn_rollout_out;")]
+    names = re.findall(r"\*\s*([a-z_]+_dev);", body)
+    assert names == [f[0] for f in _lib.JnRolloutOut._fields_]
+
+
+def test_create_rejects_bad_config_with_message():
+    lib = _lib.load_library()
+    cfg = make_jn_config(model_config(), 0, 4, 9)
+    cfg.n_actions = 5
+    h = C.c_void_p()
+    assert lib.jn_create(C.byref(cfg), C.byref(h)) == -1
+    assert b"n_actions" in lib.jn_last_error()
+    cfg = make_jn_config(model_config(image_processor="yolox-tiny"), 0, 4, 9)
+    assert lib.jn_create(C.byref(cfg), C.byref(h)) == -1      # 24-channel stem: not a multiple of 16
+    cfg = make_jn_config(model_config(patch_size=100), 0, 4, 9)
+    assert lib.jn_create(C.byref(cfg), C.byref(h)) == -1
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(gpt_backbone=None, image_processor="yolox-nano"),
+                                dict(model_type="gpt-mini", patch_size=640, block_size=32, gpt_backbone="yolox-s"),
+                                dict(concat_emb=False, decoder_pos_encoding=False, use_pos_emb=False, nclasses=8)])
+def test_state_dict_table_matches_oracle(kw):
+    """Key names + shapes are the reference's (load_state_dict(strict) both ways)."""
+    from oracle.gpt_ref import build_gpt_ref
+    okw = dict(kw)
+    oracle = build_gpt_ref(1, **okw)
+    m = ja.GPT(model_config(**kw), max_batch=2)
+    sd, osd = m.state_dict(), oracle.state_dict()
+    assert list(sorted(sd)) == list(sorted(osd))
+    for k in sd:
+        assert sd[k].shape == osd[k].shape and sd[k].dtype == osd[k].dtype, k
+    m.load_state_dict(osd)
+    oracle.load_state_dict(m.state_dict())
+    names = {n for n, _ in m.named_parameters()}
+    assert {n for n, _ in oracle.named_parameters()} == names
+    g, y = m.configure_optimizers(ja.CfgNode(learning_rate=1e-4, yolo_lr=1e-4))
+    n_gpt = sum(p.numel() for grp in g.param_groups for p in grp["params"])
+    assert n_gpt == sum(p.numel() for n, p in oracle.named_parameters() if not n.startswith("yolox"))
+
+
+def test_plan_has_the_surveyed_layer_counts():
+    m = ja.GPT(model_config(), max_batch=1)
+    tab = m.engine().param_table()
+    nano_convs = [n for n, *_ in tab if n.startswith("gpt_backbone.") and n.endswith("conv.weight")]
+    assert len(nano_convs) == 77
+    s_convs = [n for n, *_ in tab if n.startswith("yolox.backbone.") and n.endswith("conv.weight")]
+    assert len(s_convs) == 59
+
+
+def test_no_cpu_fallback_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = ja.GPT(model_config(), max_batch=1)
+    with pytest.raises(_lib.JnError):
+        m.sync_weights()
+    with pytest.raises(RuntimeError):
+        ja.NeedleGeneralEnv(torch.zeros(1, 3, 64, 64), torch.zeros(1, 1, 4, dtype=torch.long), 32, 4)
+    with pytest.raises(_lib.LibraryNotBuilt):
+        _lib.load_library("/nonexistent/libjnroll.so")
+
+
+def test_action_vocabulary_and_args(golden):
+    g = golden("g1_env.npz")
+    deltas = [ja.ACTION_DELTAS[ja.Action(i)] for i in range(9)]
+    assert deltas == [tuple(r) for r in g["action_deltas"].tolist()]
+    assert ja.get_actions_info(ja.CfgNode(stop_enabled=True))[0].nclasses == int(g["nclasses_stop"])
+    assert ja.get_actions_info(ja.CfgNode(stop_enabled=False))[0].nclasses == int(g["nclasses_nostop"])
+    # the reference's own RL test command line (tests/test_rl.py:13-46) parses
+    args = ja.get_args(["--seed", "12345", "--training-mode", "reinforce", "--model-type", "gpt-nano",
+                        "--gpt-backbone", "yolox-nano", "--image-processor", "yolox-s", "--concat-embeddings",
+                        "--decoder-pos-encoding", "--use-positional-embedding", "--max-seq-len", "8",
+                        "--batch-size", "4", "--dropout", "0.0", "--patch-size", "448", "--devices", "0",
+                        "--enable-stop", "--detector-conf-threshold", "0.50"])
+    t, m = ja.args_to_config(args)
+    assert (t.max_seq_len, t.stop_enabled, t.patch_size, m.pos_emb_size, m.block_size) == (8, True, 448, 25, 8)
+    assert m.gpt_backbone == "yolox-nano" and m.concat_emb and m.decoder_pos_encoding
