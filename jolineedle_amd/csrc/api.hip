@@ -783,7 +783,8 @@ int jn_rollout(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, const i
       launch_gather(e.images, e.positions, out->patches_dev + (long long)(t + 1) * 3 * P * P, patch_stride, B, 3, e.H, e.W,
                     P, flag, B, s);
   }
-  launch_rollout_epilogue(r, ctx->n_done, B, T, s);
+  launch_rollout_epilogue(r, ctx->n_done, B, T, stop_early ? 1 : 0, s);
+  ctx->last_stop_early = stop_early != 0;
   if (ctx->ev[1]) JN_HIP(hipEventRecord(ctx->ev[1], s));
   JN_HIP(hipGetLastError());
   ctx->last_T = T;
@@ -798,8 +799,9 @@ int jn_rollout_steps(jn_ctx* ctx, int* n_steps, void* stream) {
   JN_HIP(hipMemcpyAsync(h.data(), ctx->n_done, (T + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
   JN_HIP(hipStreamSynchronize((hipStream_t)stream));
   int S = T;
-  for (int t = 1; t <= T; ++t)
-    if (h[t] >= B) { S = t; break; }
+  if (ctx->last_stop_early)
+    for (int t = 1; t <= T; ++t)
+      if (h[t] >= B) { S = t; break; }
   *n_steps = S;
   return JN_OK;
 }

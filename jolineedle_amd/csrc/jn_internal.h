@@ -150,6 +150,7 @@ struct jn_ctx {
   int64_t* prev_action = nullptr; // [B]
   int32_t* cache_len = nullptr;   // [B]
   int last_T = 0;
+  bool last_stop_early = true;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool profiling = false;
   std::vector<hipEvent_t> conv_ev;   // pairs per step when profiling

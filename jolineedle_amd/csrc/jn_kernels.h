@@ -66,7 +66,8 @@ struct RolloutBuffers {   // device, [B,T]-shaped unless noted; any may be null
 };
 int launch_rollout_begin(const EnvPtrs& e, const RolloutBuffers& r, int64_t* prev_action, int32_t* cache_len,
                          int32_t* n_done, hipStream_t s);
-int launch_rollout_epilogue(const RolloutBuffers& r, const int32_t* n_done, int B, int T, hipStream_t s);
+int launch_rollout_epilogue(const RolloutBuffers& r, const int32_t* n_done, int B, int T, int stop_early,
+                            hipStream_t s);
 
 // ---- decision transformer step (kernels_gpt.hip) -------------------------------------
 struct GptLayerPtrs {

@@ -282,35 +282,35 @@ int launch_pw(const ConvArgs& a, hipStream_t s) {
 // SPP: slices 1..3 of `cat` = maxpool 5 / 9 / 13 (stride 1, -inf padding) of slice 0.
 // mp9 = mp5(mp5), mp13 = mp5(mp9); each mp5 is separable.  Block = (image, 32 channels).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void spp_kernel(float* __restrict__ cat, int ld, int h, int H, int W,
+__global__ __launch_bounds__(256) void spp_kernel(float* __restrict__ cat, int ld, int h, int H, int W, int cb,
                                                   const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
   extern __shared__ float sp[];
   const int HW = H * W;
   float* A = sp;
-  float* Bf = sp + HW * 32;
-  const int n = blockIdx.y, c0 = blockIdx.x * 32;
+  float* Bf = sp + HW * cb;
+  const int n = blockIdx.y, c0 = blockIdx.x * cb;
   float* base = cat + (long long)n * HW * ld + c0;
   const int tid = threadIdx.x;
-  for (int e = tid; e < HW * 32; e += 256) A[e] = base[(long long)(e >> 5) * ld + (e & 31)];
+  for (int e = tid; e < HW * cb; e += 256) A[e] = base[(long long)(e / cb) * ld + (e % cb)];
   __syncthreads();
   for (int stage = 1; stage <= 3; ++stage) {
-    for (int e = tid; e < HW * 32; e += 256) {
-      const int p = e >> 5, c = e & 31, y = p / W, xx = p - y * W;
+    for (int e = tid; e < HW * cb; e += 256) {
+      const int p = e / cb, c = e % cb, y = p / W, xx = p - y * W;
       float m = -INFINITY;
       for (int d = -2; d <= 2; ++d) {
         const int x2 = xx + d;
-        if (x2 >= 0 && x2 < W) m = fmaxf(m, A[(y * W + x2) * 32 + c]);
+        if (x2 >= 0 && x2 < W) m = fmaxf(m, A[(y * W + x2) * cb + c]);
       }
       Bf[e] = m;
     }
     __syncthreads();
-    for (int e = tid; e < HW * 32; e += 256) {
-      const int p = e >> 5, c = e & 31, y = p / W, xx = p - y * W;
+    for (int e = tid; e < HW * cb; e += 256) {
+      const int p = e / cb, c = e % cb, y = p / W, xx = p - y * W;
       float m = -INFINITY;
       for (int d = -2; d <= 2; ++d) {
         const int y2 = y + d;
-        if (y2 >= 0 && y2 < H) m = fmaxf(m, Bf[(y2 * W + xx) * 32 + c]);
+        if (y2 >= 0 && y2 < H) m = fmaxf(m, Bf[(y2 * W + xx) * cb + c]);
       }
       A[e] = m;
       base[(long long)p * ld + stage * h + c] = m;
@@ -320,9 +320,11 @@ __global__ __launch_bounds__(256) void spp_kernel(float* __restrict__ cat, int l
 }
 
 int launch_spp(float* cat, int ld, int h, int H, int W, int N, const int* skip_flag, int skip_when, hipStream_t s) {
-  dim3 grid(h / 32, N);
-  const size_t smem = (size_t)H * W * 32 * 2 * sizeof(float);
-  hipLaunchKernelGGL(spp_kernel, grid, dim3(256), smem, s, cat, ld, h, H, W, skip_flag, skip_when);
+  int cb = 32;                                   // channels per block: keep 2 * HW * cb floats under 48 KB
+  while (cb > 4 && (size_t)H * W * cb * 2 * sizeof(float) > 48 * 1024) cb >>= 1;
+  dim3 grid(h / cb, N);
+  const size_t smem = (size_t)H * W * cb * 2 * sizeof(float);
+  hipLaunchKernelGGL(spp_kernel, grid, dim3(256), smem, s, cat, ld, h, H, W, cb, skip_flag, skip_when);
   return 0;
 }
 

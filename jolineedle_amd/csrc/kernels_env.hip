@@ -147,12 +147,14 @@ int launch_rollout_begin(const EnvPtrs& e, const RolloutBuffers& r, int64_t* pre
 // Rollout epilogue (src/reinforce.py:186-202): logit_masks = roll(masks[:,1:], 1) with column 0
 // forced True; returns[t] = sum_{k>=t} rewards[k] * logit_masks[k], accumulated from the end
 // (the order of the reference's flip -> cumsum -> flip).  S = steps actually executed.
-__global__ void rollout_epilogue_kernel(RolloutBuffers r, const int32_t* __restrict__ n_done, int B, int T) {
+__global__ void rollout_epilogue_kernel(RolloutBuffers r, const int32_t* __restrict__ n_done, int B, int T,
+                                        int stop_early) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   int S = T;
-  for (int t = 1; t <= T; ++t)
-    if (n_done[t] >= B) { S = t; break; }
+  if (stop_early)
+    for (int t = 1; t <= T; ++t)
+      if (n_done[t] >= B) { S = t; break; }
   float run = 0.0f;
   for (int t = S - 1; t >= 0; --t) {
     const bool lm = (t == 0) ? true : (r.masks[(long long)b * (T + 1) + t] != 0);
@@ -162,8 +164,9 @@ __global__ void rollout_epilogue_kernel(RolloutBuffers r, const int32_t* __restr
   }
 }
 
-int launch_rollout_epilogue(const RolloutBuffers& r, const int32_t* n_done, int B, int T, hipStream_t s) {
-  hipLaunchKernelGGL(rollout_epilogue_kernel, dim3((B + 63) / 64), dim3(64), 0, s, r, n_done, B, T);
+int launch_rollout_epilogue(const RolloutBuffers& r, const int32_t* n_done, int B, int T, int stop_early,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(rollout_epilogue_kernel, dim3((B + 63) / 64), dim3(64), 0, s, r, n_done, B, T, stop_early);
   return 0;
 }
 

@@ -258,7 +258,7 @@ def test_rollout_sampling_statistics():
     P, Tn, B = 32, 2, 1
     product, _ = make_pair(5, patch_size=P, block_size=Tn, image_processor="yolox-nano", max_batch=1)
     with torch.no_grad():
-        product.action_head.lm_heads._modules["0"].weight.mul_(40.0)     # spread the distribution
+        product.action_head.lm_heads._modules["0"].weight.mul_(12.0)     # spread the distribution
     images, bboxes, start = synth_batch(B, 3, 3, P, seed=4)
     env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True)
     tr = ja.ReinforceTrainer(_cfg(T=Tn), product)
@@ -270,9 +270,12 @@ def test_rollout_sampling_statistics():
             probs = torch.softmax(ro["logits"][0, 0].cpu(), -1)
             assert torch.isclose(ro["logprobs"][0, 0].cpu(), torch.log(probs[int(ro["actions"][0, 0])]), atol=1e-5)
             assert torch.isclose(ro["entropies"][0, 0].cpu(), -(probs * probs.log()).sum(), atol=1e-5)
-    chi2 = float((((counts - n * probs) ** 2) / (n * probs)).sum())
-    assert chi2 < 32.9, (chi2, counts.tolist(), probs.tolist())    # chi2(8 dof) 99.99th percentile
-    assert probs.max() < 0.9
+    big = n * probs >= 5                                           # lump rare actions into one bin
+    obs = torch.cat((counts[big], counts[~big].sum()[None]))
+    exp = torch.cat((n * probs[big], n * probs[~big].sum()[None])).clamp(min=1e-9)
+    chi2 = float((((obs - exp) ** 2) / exp).sum())
+    assert chi2 < 32.9, (chi2, counts.tolist(), probs.tolist())    # chi2(<=8 dof) 99.99th percentile
+    assert probs.max() < 0.9 and int(big.sum()) >= 3
 
 
 def test_full_size_c3_properties():
