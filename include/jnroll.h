@@ -149,11 +149,16 @@ int jn_gather_patches(const float* images_dev, const int64_t* positions_dev, flo
                       int B, int C, int H, int W, int P, void* stream);
 
 /* ---- networks ------------------------------------------------------------------- */
-/* YOLOPAFPN.forward as called at src/models/gpt.py:375 / src/models/yolox.py:55 (eval-mode
- * BN).  patches [N,3,P,P] f32 NCHW; fpn outputs NCHW f32 ([N,c,P/8,P/8], /16, /32),
- * any may be NULL. */
-int jn_backbone_forward(jn_ctx* ctx, int net, const float* patches_dev, int N,
+/* YOLOPAFPN.forward as called at src/models/gpt.py:375 / src/models/yolox.py:55 "with the
+ * current mode of the model": train = 0 uses the BatchNorm running statistics, train != 0
+ * the batch statistics of these N patches (and updates the running statistics, momentum
+ * 0.03).  patches [N,3,P,P] f32 NCHW; fpn outputs NCHW f32 ([N,c,P/8,P/8], /16, /32), any
+ * may be NULL. */
+int jn_backbone_forward(jn_ctx* ctx, int net, const float* patches_dev, int N, int train,
                         float* fpn0_dev, float* fpn1_dev, float* fpn2_dev, void* stream);
+/* Reads back a tensor the engine mutates (BatchNorm "<prefix>.bn.running_mean" / "running_var")
+ * into host memory, so state_dict() of the owning module stays current.  Synchronises. */
+int jn_read_tensor(jn_ctx* ctx, const char* name, float* host_out, size_t numel);
 /* GPT.embed_patches (src/models/gpt.py:356-384): patches [N,3,P,P] -> [N, n_embd]. */
 int jn_embed_patches(jn_ctx* ctx, const float* patches_dev, int N, float* out_dev, void* stream);
 /* GPT.forward (src/models/gpt.py:481-534), eval mode.  patches [B,T,3,P,P] f32 (NULL with

@@ -55,8 +55,10 @@ int dev_alloc(jn_ctx* ctx, T** out, size_t count) {
 }
 
 int dev_upload(jn_ctx* ctx, float** out, const std::vector<float>& host) {
-  int rc = dev_alloc(ctx, out, host.size());
-  if (rc) return rc;
+  if (!*out) {                                   // re-uploads (weights changed) reuse the allocation
+    int rc = dev_alloc(ctx, out, host.size());
+    if (rc) return rc;
+  }
   JN_HIP(hipMemcpy(*out, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
   return JN_OK;
 }
@@ -77,75 +79,6 @@ struct TensorMap {
   }
 };
 
-// BatchNorm2d(eps=1e-3) in eval mode folded into the preceding bias-free conv
-// (YOLOX BaseConv): scale = gamma / sqrt(var + eps), bias = beta - mean * scale.
-constexpr float kBnEps = 1e-3f;
-
-int fold_scale_bias(const TensorMap& tm, const ConvW& cw, std::vector<float>& scale, std::vector<float>& bias) {
-  const int co = cw.cout;
-  scale.assign(co, 1.0f);
-  bias.assign(co, 0.0f);
-  if (cw.has_bn) {
-    const float* g = tm.f32(cw.prefix + ".bn.weight", co);
-    const float* b = tm.f32(cw.prefix + ".bn.bias", co);
-    const float* mu = tm.f32(cw.prefix + ".bn.running_mean", co);
-    const float* var = tm.f32(cw.prefix + ".bn.running_var", co);
-    if (!g || !b || !mu || !var) return JN_ENOTFOUND;
-    for (int o = 0; o < co; ++o) {
-      scale[o] = g[o] / std::sqrt(var[o] + kBnEps);
-      bias[o] = b[o] - mu[o] * scale[o];
-    }
-  } else if (cw.has_bias) {
-    const float* b = tm.f32(cw.prefix + ".bias", co);
-    if (!b) return JN_ENOTFOUND;
-    for (int o = 0; o < co; ++o) bias[o] = b[o];
-  }
-  return JN_OK;
-}
-
-int pack_conv(jn_ctx* ctx, const TensorMap& tm, ConvW& cw, OpKind kind) {
-  std::vector<float> scale, bias;
-  int rc = fold_scale_bias(tm, cw, scale, bias);
-  if (rc) return rc;
-  const int cig = cw.cin / cw.groups;
-  const std::string wname = cw.prefix + (cw.has_bn ? ".conv.weight" : ".weight");
-  const float* w = tm.f32(wname, (size_t)cw.cout * cig * cw.k * cw.k);
-  if (!w) return JN_ENOTFOUND;
-  std::vector<float> packed;
-  if (kind == OP_STEM) {
-    // [oc][q*3 + c][ky][kx] (Focus order TL, BL, TR, BR: q = py + 2*px)  ->  [(c*6+dy)*6+dx][oc]
-    packed.assign((size_t)108 * cw.cout, 0.0f);
-    for (int oc = 0; oc < cw.cout; ++oc)
-      for (int c = 0; c < 3; ++c)
-        for (int dy = 0; dy < 6; ++dy)
-          for (int dx = 0; dx < 6; ++dx) {
-            const int ky = dy >> 1, py = dy & 1, kx = dx >> 1, px = dx & 1, q = py + 2 * px;
-            packed[(size_t)((c * 6 + dy) * 6 + dx) * cw.cout + oc] =
-                w[(((size_t)oc * 12 + q * 3 + c) * 3 + ky) * 3 + kx] * scale[oc];
-          }
-  } else if (kind == OP_DW) {
-    packed.resize((size_t)9 * cw.cout);
-    for (int c = 0; c < cw.cout; ++c)
-      for (int t = 0; t < 9; ++t) packed[(size_t)t * cw.cout + c] = w[(size_t)c * 9 + t] * scale[c];
-  } else if (kind == OP_PW) {
-    packed.resize((size_t)cw.cout * cw.cin);
-    for (int o = 0; o < cw.cout; ++o)
-      for (int k = 0; k < cw.cin; ++k) packed[(size_t)o * cw.cin + k] = w[(size_t)o * cw.cin + k] * scale[o];
-  } else if (kind == OP_CONV3) {
-    // [tap][oc][cin]: every tap is a 1x1 GEMM weight
-    packed.resize((size_t)9 * cw.cout * cw.cin);
-    for (int o = 0; o < cw.cout; ++o)
-      for (int k = 0; k < cw.cin; ++k)
-        for (int t = 0; t < 9; ++t)
-          packed[((size_t)t * cw.cout + o) * cw.cin + k] = w[((size_t)o * cw.cin + k) * 9 + t] * scale[o];
-  } else {
-    return JN_OK;
-  }
-  rc = dev_upload(ctx, &cw.w_dev, packed);
-  if (rc) return rc;
-  return dev_upload(ctx, &cw.b_dev, bias);
-}
-
 // Linear weight [out][in] -> transposed [in][out]
 std::vector<float> transpose(const float* w, int out, int in) {
   std::vector<float> t((size_t)out * in);
@@ -165,6 +98,55 @@ int upload_t(jn_ctx* ctx, const TensorMap& tm, const std::string& name, int out_
   return dev_upload(ctx, out, transpose(p, out_f, in_f));
 }
 
+// YOLOX BaseConv = bias-free conv + BatchNorm2d(eps=1e-3, momentum=0.03) + SiLU.
+// Nothing is folded: convs write raw z and consumers apply (scale, shift) + SiLU on read.
+constexpr float kBnEps = 1e-3f;
+constexpr float kBnMomentum = 0.03f;
+
+int pack_conv(jn_ctx* ctx, const TensorMap& tm, ConvW& cw, OpKind kind) {
+  const int cig = cw.cin / cw.groups;
+  const std::string wname = cw.prefix + (cw.has_bn ? ".conv.weight" : ".weight");
+  const float* w = tm.f32(wname, (size_t)cw.cout * cig * cw.k * cw.k);
+  if (!w) return JN_ENOTFOUND;
+  int rc;
+  if (cw.has_bn) {
+    const int co = cw.cout;
+    if ((rc = upload_raw(ctx, tm, cw.prefix + ".bn.weight", co, &cw.gamma_dev))) return rc;
+    if ((rc = upload_raw(ctx, tm, cw.prefix + ".bn.bias", co, &cw.beta_dev))) return rc;
+    if ((rc = upload_raw(ctx, tm, cw.prefix + ".bn.running_mean", co, &cw.rmean_dev))) return rc;
+    if ((rc = upload_raw(ctx, tm, cw.prefix + ".bn.running_var", co, &cw.rvar_dev))) return rc;
+  } else if (cw.has_bias) {
+    if ((rc = upload_raw(ctx, tm, cw.prefix + ".bias", cw.cout, &cw.b_dev))) return rc;
+  }
+  std::vector<float> packed;
+  if (kind == OP_STEM) {
+    // [oc][q*3 + c][ky][kx] (Focus order TL, BL, TR, BR: q = py + 2*px)  ->  [(c*6+dy)*6+dx][oc]
+    packed.assign((size_t)108 * cw.cout, 0.0f);
+    for (int oc = 0; oc < cw.cout; ++oc)
+      for (int c = 0; c < 3; ++c)
+        for (int dy = 0; dy < 6; ++dy)
+          for (int dx = 0; dx < 6; ++dx) {
+            const int ky = dy >> 1, py = dy & 1, kx = dx >> 1, px = dx & 1, q = py + 2 * px;
+            packed[(size_t)((c * 6 + dy) * 6 + dx) * cw.cout + oc] = w[(((size_t)oc * 12 + q * 3 + c) * 3 + ky) * 3 + kx];
+          }
+  } else if (kind == OP_DW) {
+    packed.resize((size_t)9 * cw.cout);
+    for (int c = 0; c < cw.cout; ++c)
+      for (int t = 0; t < 9; ++t) packed[(size_t)t * cw.cout + c] = w[(size_t)c * 9 + t];
+  } else if (kind == OP_PW) {
+    packed.assign(w, w + (size_t)cw.cout * cw.cin);
+  } else if (kind == OP_CONV3) {
+    // [tap][oc][cin]: every tap is a 1x1 GEMM weight
+    packed.resize((size_t)9 * cw.cout * cw.cin);
+    for (int o = 0; o < cw.cout; ++o)
+      for (int k = 0; k < cw.cin; ++k)
+        for (int t = 0; t < 9; ++t) packed[((size_t)t * cw.cout + o) * cw.cin + k] = w[((size_t)o * cw.cin + k) * 9 + t];
+  } else {
+    return JN_OK;
+  }
+  return dev_upload(ctx, &cw.w_dev, packed);
+}
+
 // get_emb(pos * inv_freq) of positional_encodings >= 6 (interleaved sin, cos), SURVEY.md §2.2
 std::vector<float> sinusoid_row(int pos, int channels) {
   std::vector<float> r(channels);
@@ -181,10 +163,19 @@ int n_parts(const jn_config& c) { return 2 + (c.no_patch_emb ? 0 : 1) + (c.use_p
 
 }  // namespace
 
-// Workspace base of buffer `buf` for a batch capacity of max_batch images.
-static inline float* buf_base(const Net& net, float* ws, int buf, int max_batch) {
-  return ws + net.buf_off[buf] * (size_t)max_batch;
+// ---- workspace slots ----------------------------------------------------------------
+inline float* slot_act(const Net& net, int slot, int max_batch) {
+  return net.act + (size_t)slot * net.per_image_floats * max_batch;
 }
+inline float* view_ptr(const Net& net, int slot, int max_batch, const View& v) {
+  return slot_act(net, slot, max_batch) + net.buf_off[v.buf] * (size_t)max_batch + v.coff;
+}
+inline ChanTab view_tab(const Net& net, int slot, const View& v) {
+  float* t = net.tab + (size_t)slot * 3 * net.tab_channels + net.tab_off[v.buf] + v.coff;
+  return ChanTab{t, t + net.tab_channels, t + 2 * net.tab_channels};
+}
+inline double* slot_stats(const Net& net, int slot) { return net.stats + (size_t)slot * 2 * net.stat_channels; }
+inline float* slot_save(const Net& net, int slot) { return net.save + (size_t)slot * 2 * net.stat_channels; }
 
 }  // namespace jnr
 
@@ -299,6 +290,65 @@ int jn_param_info_at(const jn_ctx* ctx, int index, jn_param_info* out) {
   return JN_OK;
 }
 
+// (scale, shift, flag) of BN channels from the running statistics (eval mode)
+__global__ void bn_eval_table_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ rmean, const float* __restrict__ rvar, ChanTab t0,
+                                     ChanTab t1, int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(rvar[c] + eps);
+  const float sh = beta[c] - rmean[c] * sc;
+  t0.sc[c] = sc; t0.sh[c] = sh; t0.fl[c] = 1.0f;
+  if (t1.sc) { t1.sc[c] = sc; t1.sh[c] = sh; t1.fl[c] = 1.0f; }
+}
+
+__global__ void fill_kernel(float* p, float v, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// Allocates (or grows to) n_slots workspace slots of a net; tables start as identity
+// (scale 1, shift 0, flag 0 = "already an activation").
+static int ensure_slots(jn_ctx* ctx, Net& net, int n_slots) {
+  if (net.n_slots >= n_slots) return JN_OK;
+  const int MB = ctx->cfg.max_batch;
+  float *act = nullptr, *tab = nullptr, *save = nullptr;
+  double* stats = nullptr;
+  int rc;
+  if ((rc = dev_alloc(ctx, &act, (size_t)n_slots * net.per_image_floats * MB))) return rc;
+  if ((rc = dev_alloc(ctx, &tab, (size_t)n_slots * 3 * net.tab_channels))) return rc;
+  if ((rc = dev_alloc(ctx, &save, (size_t)n_slots * 2 * net.stat_channels))) return rc;
+  if ((rc = dev_alloc(ctx, &stats, (size_t)n_slots * 2 * net.stat_channels))) return rc;
+  // old (smaller) allocations stay owned by the context until jn_destroy; slots are grown once per config
+  net.act = act; net.tab = tab; net.save = save; net.stats = stats; net.n_slots = n_slots;
+  for (int sl = 0; sl < n_slots; ++sl) {
+    float* t = tab + (size_t)sl * 3 * net.tab_channels;
+    const long long n = net.tab_channels;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, t, 1.0f, n);
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, 0, t + n, 0.0f, 2 * n);
+  }
+  JN_HIP(hipGetLastError());
+  net.eval_tab_dirty = true;
+  return JN_OK;
+}
+
+// Slot-0 table from the BN running statistics (after a weight load or a training step).
+static int refresh_eval_table(jn_ctx* ctx, Net& net, hipStream_t s) {
+  if (!net.eval_tab_dirty) return JN_OK;
+  for (const Op& op : net.ops) {
+    if (op.wslot < 0) continue;
+    const ConvW& cw = net.convs[op.wslot];
+    if (!cw.has_bn) continue;
+    ChanTab t1{nullptr, nullptr, nullptr};
+    if (op.alias.buf >= 0) t1 = view_tab(net, 0, op.alias);
+    hipLaunchKernelGGL(bn_eval_table_kernel, dim3((cw.cout + 63) / 64), dim3(64), 0, s, cw.gamma_dev, cw.beta_dev,
+                       cw.rmean_dev, cw.rvar_dev, view_tab(net, 0, op.out), t1, cw.cout, kBnEps);
+  }
+  JN_HIP(hipGetLastError());
+  net.eval_tab_dirty = false;
+  return JN_OK;
+}
+
 // Device-side workspaces; allocated on the first jn_load_weights (needs a GPU).
 static int alloc_workspaces(jn_ctx* ctx) {
   jn_ctx& x = *ctx;
@@ -307,8 +357,7 @@ static int alloc_workspaces(jn_ctx* ctx) {
   int rc;
   for (int n = 0; n < 2; ++n) {
     if (!ctx->has_net[n]) continue;
-    rc = dev_alloc(ctx, &x.net_ws[n], ctx->nets[n].per_image_floats * (size_t)B);
-    if (rc) return rc;
+    if ((rc = ensure_slots(ctx, ctx->nets[n], 1))) return rc;
   }
   const int Tmax = c.block_size + 1;
   if ((rc = dev_alloc(ctx, &ctx->kcache, (size_t)c.n_layer * B * Tmax * C))) return rc;
@@ -320,7 +369,6 @@ static int alloc_workspaces(jn_ctx* ctx) {
   if (!c.no_patch_emb)
     if ((rc = dev_alloc(ctx, &ctx->efpn_act, (size_t)B * ctx->efpn_h * ctx->efpn_w * C))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->patch_emb, (size_t)B * C))) return rc;
-  if ((rc = dev_upload(ctx, &x.zero_bias, std::vector<float>(1024, 0.0f)))) return rc;
   JN_HIP(hipMemset(ctx->n_done, 0, ((size_t)Tmax + 1) * sizeof(int32_t)));
   for (auto& e : ctx->ev) JN_HIP(hipEventCreate(&e));
   return JN_OK;
@@ -332,9 +380,8 @@ int jn_load_weights(jn_ctx* ctx, const jn_tensor* tensors, size_t n) {
   TensorMap tm;
   for (size_t i = 0; i < n; ++i) tm.m[tensors[i].name] = &tensors[i];
   int rc;
-  if (!ctx->act_ws) {
+  if (!ctx->kcache) {
     if ((rc = alloc_workspaces(ctx))) return rc;
-    ctx->act_ws = ctx->net_ws[ctx->enc_net];
   }
   const jn_config& c = ctx->cfg;
   const int C = c.n_embd, nA = c.n_actions;
@@ -345,6 +392,7 @@ int jn_load_weights(jn_ctx* ctx, const jn_tensor* tensors, size_t n) {
       if (op.wslot < 0) continue;
       if ((rc = pack_conv(ctx, tm, net.convs[op.wslot], op.kind))) return rc;
     }
+    net.eval_tab_dirty = true;
   }
   GptW& g = ctx->gpt;
   if ((rc = upload_raw(ctx, tm, "transformer.wte.weight", (size_t)nA * C, &g.wte))) return rc;
@@ -421,45 +469,72 @@ int jn_load_weights(jn_ctx* ctx, const jn_tensor* tensors, size_t n) {
 }
 
 // ---- network execution ---------------------------------------------------------------
+static View net_full_view(const Net& net, int buf) {
+  View v; v.buf = buf; v.H = net.bufs[buf].H; v.W = net.bufs[buf].W; v.C = net.bufs[buf].C; v.coff = 0;
+  return v;
+}
+
 struct StemSrc {
   const float* src; const int64_t* positions; long long sample_stride, chan_stride; int row_stride;
 };
 
-static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, const int* skip_flag, int skip_when,
-                   hipStream_t s) {
+// One pass of a PAFPN over N patches in workspace slot `slot`.  train != 0: batch-statistics
+// BatchNorm (stats accumulated by every conv, finalised per layer, running stats updated).
+static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int train, const int* skip_flag,
+                   int skip_when, hipStream_t s) {
   Net& net = ctx->nets[ni];
-  float* ws = ctx->net_ws[ni];
   const int MB = ctx->cfg.max_batch;
-  auto ptr = [&](const View& v) { return buf_base(net, ws, v.buf, MB) + v.coff; };
+  int rc;
+  if (!train && (rc = refresh_eval_table(ctx, net, s))) return rc;
+  double* stats = train ? slot_stats(net, slot) : nullptr;
+  float* save = train ? slot_save(net, slot) : nullptr;
+  if (train) JN_HIP(hipMemsetAsync(stats, 0, (size_t)2 * net.stat_channels * sizeof(double), s));
+  auto ptr = [&](const View& v) { return view_ptr(net, slot, MB, v); };
+  auto tab = [&](const View& v) { return view_tab(net, slot, v); };
   auto ld = [&](const View& v) { return net.bufs[v.buf].C; };
+  auto finalize = [&](const Op& op, const ConvW& cw) {
+    if (!train || !cw.has_bn) return;
+    ChanTab t1{nullptr, nullptr, nullptr};
+    if (op.alias.buf >= 0) t1 = tab(op.alias);
+    launch_bn_finalize(stats + 2 * cw.stat_off, (double)N * op.out.H * op.out.W, cw.gamma_dev, cw.beta_dev, cw.rmean_dev,
+                       cw.rvar_dev, save + 2 * cw.stat_off, tab(op.out), t1, cw.cout, kBnEps, kBnMomentum, skip_flag,
+                       skip_when, s);
+  };
   for (const Op& op : net.ops) {
     switch (op.kind) {
       case OP_STEM: {
         const ConvW& cw = net.convs[op.wslot];
         StemArgs a{ss.src, ss.positions, ss.sample_stride, ss.chan_stride, ss.row_stride, net.P, N, cw.cout,
-                   cw.w_dev, cw.b_dev, ptr(op.out), ld(op.out), skip_flag, skip_when};
+                   cw.w_dev, ptr(op.out), ld(op.out), train ? stats + 2 * cw.stat_off : nullptr, skip_flag, skip_when};
         launch_stem(a, s);
+        finalize(op, cw);
         break;
       }
       case OP_PW:
       case OP_DW: {
         const ConvW& cw = net.convs[op.wslot];
         ConvArgs a{};
-        a.in = ptr(op.in); a.in_ld = ld(op.in); a.w = cw.w_dev; a.bias = cw.b_dev;
+        a.in = ptr(op.in); a.in_ld = ld(op.in); a.itab = tab(op.in); a.w = cw.w_dev; a.bias = cw.b_dev;
         a.out = ptr(op.out); a.out_ld = ld(op.out);
-        a.res = op.res.buf >= 0 ? ptr(op.res) : nullptr; a.res_ld = op.res.buf >= 0 ? ld(op.res) : 0;
         a.N = N; a.H = op.in.H; a.W = op.in.W; a.OH = op.out.H; a.OW = op.out.W;
         a.cin = op.in.C; a.cout = op.out.C; a.stride = op.stride; a.act = op.act;
+        a.stats = (train && cw.has_bn) ? stats + 2 * cw.stat_off : nullptr;
         a.skip_flag = skip_flag; a.skip_when = skip_when;
         if (op.kind == OP_PW) launch_pw(a, s); else launch_dw(a, s);
+        finalize(op, cw);
         break;
       }
       case OP_SPP:
-        launch_spp(buf_base(net, ws, op.out.buf, MB), ld(op.out), op.in.C, op.in.H, op.in.W, N, skip_flag, skip_when, s);
+        launch_spp(view_ptr(net, slot, MB, net_full_view(net, op.out.buf)), ld(op.out), op.in.C, op.in.H, op.in.W, N,
+                   tab(op.in), skip_flag, skip_when, s);
         break;
       case OP_UPSAMPLE:
         launch_upsample(ptr(op.in), ld(op.in), ptr(op.out), ld(op.out), op.in.C, op.in.H, op.in.W, N, skip_flag,
                         skip_when, s);
+        break;
+      case OP_ADDACT:
+        launch_addact(ptr(op.in), ld(op.in), tab(op.in), ptr(op.res), ld(op.res), tab(op.res), ptr(op.out), ld(op.out),
+                      op.out.C, (long long)N * op.out.H * op.out.W, skip_flag, skip_when, s);
         break;
       case OP_CONV3:
         set_error("dense 3x3 conv (%s) is not implemented yet in this build", op.name.c_str());
@@ -467,19 +542,20 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, const int* ski
     }
   }
   JN_HIP(hipGetLastError());
+  if (train) net.eval_tab_dirty = true;     // running statistics moved
   return JN_OK;
 }
 
 // embed_fpn (src/models/gpt.py:294-306, 382) on the last FPN map of the encoder for N patches:
 // 1x1 conv + ReLU, then the split-K partial sums of the Linear (finished by the consumer).
-static int run_embed_fpn(jn_ctx* ctx, int N, const int* skip_flag, int skip_when, hipStream_t s) {
+static int run_embed_fpn(jn_ctx* ctx, int N, int slot, const int* skip_flag, int skip_when, hipStream_t s) {
   const Net& net = ctx->nets[ctx->enc_net];
   jn_ctx& x = *ctx;
   const int C = ctx->cfg.n_embd, MB = ctx->cfg.max_batch;
   const View& f = net.fpn[2];
   ConvArgs a{};
-  a.in = buf_base(net, x.net_ws[ctx->enc_net], f.buf, MB) + f.coff; a.in_ld = net.bufs[f.buf].C;
-  a.w = ctx->gpt.efpn_w; a.bias = x.zero_bias; a.out = ctx->efpn_act; a.out_ld = C;
+  a.in = view_ptr(net, slot, MB, f); a.in_ld = net.bufs[f.buf].C; a.itab = view_tab(net, slot, f);
+  a.w = ctx->gpt.efpn_w; a.bias = nullptr; a.out = ctx->efpn_act; a.out_ld = C;
   a.N = N; a.H = f.H; a.W = f.W; a.OH = f.H; a.OW = f.W; a.cin = f.C; a.cout = C; a.stride = 1; a.act = ACT_RELU;
   a.skip_flag = skip_flag; a.skip_when = skip_when;
   launch_pw(a, s);
@@ -488,8 +564,8 @@ static int run_embed_fpn(jn_ctx* ctx, int N, const int* skip_flag, int skip_when
   return JN_OK;
 }
 
-int jn_backbone_forward(jn_ctx* ctx, int net, const float* patches_dev, int N, float* fpn0_dev, float* fpn1_dev,
-                        float* fpn2_dev, void* stream) {
+int jn_backbone_forward(jn_ctx* ctx, int net, const float* patches_dev, int N, int train, float* fpn0_dev,
+                        float* fpn1_dev, float* fpn2_dev, void* stream) {
   JN_CHECK(ctx && patches_dev, JN_EINVAL, "jn_backbone_forward: null argument");
   JN_CHECK(net >= 0 && net < 2 && ctx->has_net[net], JN_EINVAL, "network %d is not part of this context", net);
   JN_CHECK(ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
@@ -498,15 +574,15 @@ int jn_backbone_forward(jn_ctx* ctx, int net, const float* patches_dev, int N, f
   hipStream_t s = (hipStream_t)stream;
   const int P = ctx->cfg.patch_size;
   StemSrc ss{patches_dev, nullptr, 3LL * P * P, (long long)P * P, P};
-  int rc = run_net(ctx, net, N, ss, nullptr, 0, s);
+  int rc = run_net(ctx, net, N, ss, 0, train ? 1 : 0, nullptr, 0, s);
   if (rc) return rc;
   float* outs[3] = {fpn0_dev, fpn1_dev, fpn2_dev};
   const Net& n = ctx->nets[net];
   for (int i = 0; i < 3; ++i) {
     if (!outs[i]) continue;
     const View& f = n.fpn[i];
-    launch_nhwc_to_nchw(buf_base(n, ctx->net_ws[net], f.buf, ctx->cfg.max_batch) + f.coff, n.bufs[f.buf].C, outs[i],
-                        f.C, f.H * f.W, N, s);
+    launch_nhwc_to_nchw(view_ptr(n, 0, ctx->cfg.max_batch, f), n.bufs[f.buf].C, view_tab(n, 0, f), outs[i], f.C,
+                        f.H * f.W, N, s);
   }
   JN_HIP(hipGetLastError());
   return JN_OK;
@@ -526,10 +602,10 @@ __global__ void emb_finish_kernel(const float* __restrict__ part, const float* _
 int jn_embed_patches(jn_ctx* ctx, const float* patches_dev, int N, float* out_dev, void* stream) {
   JN_CHECK(ctx && patches_dev && out_dev, JN_EINVAL, "jn_embed_patches: null argument");
   JN_CHECK(!ctx->cfg.no_patch_emb, JN_ESTATE, "context was created with no_patch_emb");
-  int rc = jn_backbone_forward(ctx, ctx->enc_net, patches_dev, N, nullptr, nullptr, nullptr, stream);
+  int rc = jn_backbone_forward(ctx, ctx->enc_net, patches_dev, N, 0, nullptr, nullptr, nullptr, stream);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if ((rc = run_embed_fpn(ctx, N, nullptr, 0, s))) return rc;
+  if ((rc = run_embed_fpn(ctx, N, 0, nullptr, 0, s))) return rc;
   const int C = ctx->cfg.n_embd;
   hipLaunchKernelGGL(emb_finish_kernel, dim3((N * C + 255) / 256), dim3(256), 0, s, ctx->emb_part,
                      ctx->gpt.efpn_lin_b, out_dev, (long long)C, N, ctx->KS, C);
@@ -577,8 +653,8 @@ int jn_gpt_forward(jn_ctx* ctx, const float* patches_dev, const int64_t* actions
     }
     for (int i = 0; i < n_new; ++i) {
       StemSrc ss{patches_dev + (size_t)(i0 + i) * 3 * P * P, nullptr, (long long)T * 3 * P * P, (long long)P * P, P};
-      if ((rc = run_net(ctx, ctx->enc_net, B, ss, nullptr, 0, s))) return rc;
-      if ((rc = run_embed_fpn(ctx, B, nullptr, 0, s))) return rc;
+      if ((rc = run_net(ctx, ctx->enc_net, B, ss, 0, 0, nullptr, 0, s))) return rc;
+      if ((rc = run_embed_fpn(ctx, B, 0, nullptr, 0, s))) return rc;
       hipLaunchKernelGGL(emb_finish_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, ctx->emb_part, ctx->gpt.efpn_lin_b,
                          ctx->tok_emb + (size_t)i * C, (long long)n_new * C, B, ctx->KS, C);
     }
@@ -605,6 +681,28 @@ int jn_gpt_forward(jn_ctx* ctx, const float* patches_dev, const int64_t* actions
   }
   JN_HIP(hipGetLastError());
   return JN_OK;
+}
+
+int jn_read_tensor(jn_ctx* ctx, const char* name, float* host_out, size_t numel) {
+  JN_CHECK(ctx && name && host_out, JN_EINVAL, "jn_read_tensor: null argument");
+  JN_CHECK(ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  const std::string nm(name);
+  for (int ni = 0; ni < 2; ++ni) {
+    if (!ctx->has_net[ni]) continue;
+    for (const ConvW& cw : ctx->nets[ni].convs) {
+      if (!cw.has_bn || nm.compare(0, cw.prefix.size(), cw.prefix) != 0) continue;
+      const std::string leaf = nm.substr(cw.prefix.size());
+      const float* src = leaf == ".bn.running_mean" ? cw.rmean_dev : leaf == ".bn.running_var" ? cw.rvar_dev : nullptr;
+      if (!src) continue;
+      JN_CHECK(numel == (size_t)cw.cout, JN_EINVAL, "'%s' has %d elements, not %zu", name, cw.cout, numel);
+      JN_HIP(hipDeviceSynchronize());
+      JN_HIP(hipMemcpy(host_out, src, numel * sizeof(float), hipMemcpyDeviceToHost));
+      return JN_OK;
+    }
+  }
+  set_error("jn_read_tensor: '%s' is not a tensor the engine updates", name);
+  return JN_ENOTFOUND;
 }
 
 int jn_detect(jn_ctx* ctx, const float*, int, float*, int32_t*, float*, void*) {
@@ -760,9 +858,9 @@ int jn_rollout(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, const i
     const int* flag = stop_early ? ctx->n_done + t : nullptr;
     if (!c.no_patch_emb) {
       if (ctx->profiling) JN_HIP(hipEventRecord(ctx->conv_ev[2 * t], s));
-      if ((rc = run_net(ctx, ctx->enc_net, B, ss, flag, B, s))) return rc;
+      if ((rc = run_net(ctx, ctx->enc_net, B, ss, 0, 0, flag, B, s))) return rc;
       if (ctx->profiling) { JN_HIP(hipEventRecord(ctx->conv_ev[2 * t + 1], s)); ctx->conv_ev_used = 2 * (t + 1); }
-      if ((rc = run_embed_fpn(ctx, B, flag, B, s))) return rc;
+      if ((rc = run_embed_fpn(ctx, B, 0, flag, B, s))) return rc;
     }
     GptStepArgs a{};
     a.C = C; a.n_head = c.n_head; a.n_layer = c.n_layer; a.nA = nA; a.Tmax = c.block_size + 1; a.B = B; a.T = T;

@@ -52,13 +52,15 @@ enum OpKind {
   OP_DW,            // depthwise 3x3 s1/s2 + bias + SiLU
   OP_CONV3,         // dense 3x3 s1/s2    + bias + SiLU       (non-depthwise models)
   OP_SPP,           // maxpool 5/9/13 of slice 0 into slices 1..3
-  OP_UPSAMPLE,      // nearest x2 into a slice
+  OP_UPSAMPLE,      // nearest x2 (raw values) into a slice
+  OP_ADDACT,        // bottleneck shortcut: out = act(in) + act(res), materialised
 };
 
 struct Op {
   OpKind kind;
   View in, out;
-  View res;                 // residual added after the activation (buf = -1: none)
+  View res;                 // OP_ADDACT: the shortcut input (buf = -1: none)
+  View alias;               // conv: second view that receives this layer's (scale, shift) (upsampled copy)
   int stride = 1;
   int act = ACT_SILU;
   int wslot = -1;           // index into Net::convs (packed weights)
@@ -71,8 +73,11 @@ struct ConvW {
   int cin = 0, cout = 0, k = 1, groups = 1;
   bool has_bn = true;       // BaseConv; false = plain Conv2d with optional bias
   bool has_bias = false;    // plain Conv2d bias
-  float* w_dev = nullptr;   // layout depends on the op (see pack_conv)
-  float* b_dev = nullptr;   // [cout] folded bias
+  float* w_dev = nullptr;   // raw conv weight, layout depends on the op (see pack_conv)
+  float* b_dev = nullptr;   // [cout] bias of a BN-free Conv2d (else null)
+  float *gamma_dev = nullptr, *beta_dev = nullptr;     // BN affine
+  float *rmean_dev = nullptr, *rvar_dev = nullptr;     // BN running statistics (updated in train mode)
+  int stat_off = 0;         // first channel of this layer in the per-slot stats / save arrays
 };
 
 struct Net {
@@ -86,6 +91,16 @@ struct Net {
   View fpn[3];              // pan_out2, pan_out1, pan_out0
   size_t per_image_floats = 0;
   std::vector<size_t> buf_off;    // per-image offset of each buffer (floats)
+  std::vector<int> tab_off;       // first table channel of each buffer
+  int tab_channels = 0;           // sum of buffer channels (table length)
+  int stat_channels = 0;          // sum of BN channels
+  // workspace slots: slot 0 = eval / single-step; slots 1..n = one per glimpse step when training
+  int n_slots = 0;
+  float* act = nullptr;           // [n_slots][per_image_floats * max_batch]
+  float* tab = nullptr;           // [n_slots][3][tab_channels]
+  float* save = nullptr;          // [n_slots][2 * stat_channels]  (mean, invstd)
+  double* stats = nullptr;        // [n_slots][2 * stat_channels]  (sum, sumsq)
+  bool eval_tab_dirty = true;     // slot-0 table must be rebuilt from the running statistics
 };
 
 struct ParamEntry {
@@ -131,12 +146,9 @@ struct jn_ctx {
   int efpn_cin = 0, efpn_h = 0, efpn_w = 0;
   bool weights_loaded = false;
   std::vector<void*> owned;       // device allocations to free
-  float* act_ws = nullptr;        // activation workspace of the patch encoder
-  float* net_ws[2] = {nullptr, nullptr};   // NHWC activations of each net, max_batch images
   jnr::GptLayerPtrs* layers_dev = nullptr;
   float* emb_part = nullptr;      // [B][KS][C] split-K partials of embed_fpn.3
   int KS = 8;
-  float* zero_bias = nullptr;     // zeros, bias of bias-free 1x1 convs
   int32_t* found = nullptr;       // [B] visited bbox tiles
   float* tok_emb = nullptr;       // [B][T][C] patch embeddings of jn_gpt_forward
   jnr::EnvState env;

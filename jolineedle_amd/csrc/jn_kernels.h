@@ -13,30 +13,42 @@ enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
 // Every hot-loop kernel takes (skip_flag, skip_when): it returns at once when
 // *skip_flag >= skip_when.  The rollout points skip_flag at n_done[t] with skip_when = B,
 // which reproduces the reference's early `break` (src/reinforce.py:181-184) with no host sync.
+// Per-channel "normalize on read" table of a buffer view: a = fl ? silu(z * sc + sh) : z.
+struct ChanTab {
+  float* sc; float* sh; float* fl;
+};
+
 struct StemArgs {
   const float* src; const int64_t* positions;
   long long sample_stride, chan_stride; int row_stride;
   int P, N, cout;
-  const float* w; const float* bias; float* out; int out_ld;
+  const float* w; float* out; int out_ld;
+  double* stats;                    // [cout][2] sum / sumsq accumulators (train mode) or null
   const int* skip_flag; int skip_when;
 };
 
 struct ConvArgs {
-  const float* in; int in_ld;
-  const float* w; const float* bias;
+  const float* in; int in_ld; ChanTab itab;
+  const float* w; const float* bias;     // bias only for BN-free layers
   float* out; int out_ld;
-  const float* res; int res_ld;
   int N, H, W, OH, OW, cin, cout, stride, act;
+  double* stats;
   const int* skip_flag; int skip_when;
 };
 
 int launch_stem(const StemArgs& a, hipStream_t s);
 int launch_dw(const ConvArgs& a, hipStream_t s);
 int launch_pw(const ConvArgs& a, hipStream_t s);
-int launch_spp(float* cat, int ld, int h, int H, int W, int N, const int* skip_flag, int skip_when, hipStream_t s);
+int launch_spp(float* cat, int ld, int h, int H, int W, int N, ChanTab it, const int* skip_flag, int skip_when,
+               hipStream_t s);
 int launch_upsample(const float* in, int in_ld, float* out, int out_ld, int C, int H, int W, int N,
                     const int* skip_flag, int skip_when, hipStream_t s);
-int launch_nhwc_to_nchw(const float* in, int in_ld, float* out, int C, int HW, int N, hipStream_t s);
+int launch_addact(const float* z, int z_ld, ChanTab zt, const float* res, int res_ld, ChanTab rt, float* out,
+                  int out_ld, int C, long long M, const int* skip_flag, int skip_when, hipStream_t s);
+int launch_bn_finalize(const double* stats, double count, const float* gamma, const float* beta, float* run_mean,
+                       float* run_var, float* save, ChanTab t0, ChanTab t1, int C, float eps, float momentum,
+                       const int* skip_flag, int skip_when, hipStream_t s);
+int launch_nhwc_to_nchw(const float* in, int in_ld, ChanTab it, float* out, int C, int HW, int N, hipStream_t s);
 int launch_efpn_linear(const float* e, const float* wt, float* part, int N, int K, int Co, int KS,
                        const int* skip_flag, int skip_when, hipStream_t s);
 

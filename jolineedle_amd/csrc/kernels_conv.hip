@@ -1,16 +1,26 @@
 // Convolution kernels of the YOLOX PAFPN patch encoder for gfx950 (MI355X).
-// Activations: NHWC fp32.  Eval-mode BatchNorm is folded into weight + bias at load
-// time; bias + SiLU (+ residual) are applied in each kernel's epilogue so every
-// activation is written once and read once per consumer.
 //
-//   stem_kernel     Focus (space-to-depth) + dense 3x3 conv == 6x6 stride-2 conv on the
-//                   image; reads the patch straight out of the big image at the agent's
-//                   position (the gather is fused: SURVEY.md §8 a2 + a3), LDS halo tile.
-//   dw3x3_kernel    depthwise 3x3, stride 1/2, float4 over channels, 4-row strips.
-//   pw_mfma_kernel  1x1 conv as a GEMM on v_mfma_f32_16x16x4_f32 (exact fp32), X and W
-//                   tiles staged in LDS, one dwordx4 store per lane per 16x16 tile.
-//   spp_kernel      SPP max-pools 5/9/13 as a cascade of separable 5-pools in LDS.
-//   upsample_kernel nearest x2 into a channel slice of the consumer's concat buffer.
+// Data model ("normalize on read").  Every conv writes its RAW output z (no bias, no BN, no
+// activation) exactly once, NHWC fp32.  Each buffer channel carries an affine (scale, shift)
+// and a flag in a small per-workspace table; every consumer applies
+//        a = flag ? silu(z * scale + shift) : z
+// while loading.  In eval mode the table holds the BatchNorm running statistics (set once at
+// weight load); in train mode each conv also accumulates per-channel sum / sum-of-squares of
+// z (fp64 atomics, one pair per channel per workgroup) and a tiny finalize kernel turns them
+// into the batch-statistics (scale, shift) of that layer before its consumers run — the
+// reference trains with batch statistics per glimpse step (src/reinforce.py:304,
+// src/models/yolox.py:54-55).  One code path serves both modes and the backward pass
+// (which needs z, not a).
+//
+//   stem_mfma_kernel  Focus + dense 3x3 == 6x6 stride-2 conv on the image (K = 108 = 27 x 4)
+//                     on v_mfma_f32_16x16x4_f32; reads the patch straight out of the big image
+//                     at the agent's position (gather fused), LDS halo tile.
+//   dw3x3_kernel      depthwise 3x3, stride 1/2, float4 over channels, 4-row strips.
+//   pw_mfma_kernel    1x1 conv as GEMM D = W * X^T on v_mfma_f32_16x16x4_f32 (exact fp32).
+//   spp_kernel        SPP max-pools 5/9/13 as cascaded separable 5-pools in LDS.
+//   upsample_kernel   nearest x2 copy of raw z into a concat slice.
+//   addact_kernel     bottleneck shortcut: out = T(res) + silu(bn(z)) materialised.
+//   bn_finalize_kernel  batch statistics -> (scale, shift) table, running-stat update.
 #include <hip/hip_runtime.h>
 
 #include "jn_kernels.h"
@@ -19,83 +29,120 @@ namespace jnr {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+__device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
 __device__ __forceinline__ float act_apply(float v, int act) {
-  if (act == ACT_SILU) return v / (1.0f + __expf(-v));
+  if (act == ACT_SILU) return silu(v);
   if (act == ACT_RELU) return fmaxf(v, 0.0f);
   if (act == ACT_SIGMOID) return 1.0f / (1.0f + __expf(-v));
   return v;
 }
 
+// a = flag ? silu(z * sc + sh) : z, 4 channels at once
+__device__ __forceinline__ f32x4 tf4(f32x4 z, f32x4 sc, f32x4 sh, f32x4 fl) {
+  f32x4 r;
+  r.x = fl.x != 0.0f ? silu(fmaf(z.x, sc.x, sh.x)) : z.x;
+  r.y = fl.y != 0.0f ? silu(fmaf(z.y, sc.y, sh.y)) : z.y;
+  r.z = fl.z != 0.0f ? silu(fmaf(z.z, sc.z, sh.z)) : z.z;
+  r.w = fl.w != 0.0f ? silu(fmaf(z.w, sc.w, sh.w)) : z.w;
+  return r;
+}
+
+// Sum over the 16 lanes of a DPP row (lanes that share lane>>4).
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+
+// Epilogue helper of the MFMA kernels: s1/s2[t] hold sum / sumsq over this lane's pixels of channels
+// (16 t + 4g .. +3).  Adds the wave's per-channel totals into LDS scratch `red` [nch][2].
+template <int NT>
+__device__ __forceinline__ void wave_stats_to_lds(const f32x4 (&s1)[NT], const f32x4 (&s2)[NT], float* red,
+                                                  int lane, int nch) {
+  const int lm = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float a = row16_sum(s1[t][r]);
+      const float b = row16_sum(s2[t][r]);
+      const int ch = 16 * t + 4 * g + r;
+      if (lm == 0 && ch < nch) {
+        atomicAdd(&red[2 * ch], a);
+        atomicAdd(&red[2 * ch + 1], b);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------
-// stem: out[n][oy][ox][oc] = silu(b[oc] + sum_{c,dy,dx} w[c][dy][dx][oc] * img[c][2oy-2+dy][2ox-2+dx])
+// stem: z[n][oy][ox][oc] = sum_{c,dy,dx} w[(c,dy,dx)][oc] * img[c][2oy-2+dy][2ox-2+dx]
+// Workgroup = 16 x 32 output pixels; 4 waves x 4 rows; per row two 16-pixel MFMA tiles.
 // ------------------------------------------------------------------------------------
 constexpr int ST_TY = 16, ST_TX = 32;
 constexpr int ST_IH = 2 * ST_TY + 4, ST_IW = 2 * ST_TX + 4;   // 36 x 68
+constexpr int ST_KS = 27;                                     // 108 / 4 k-steps
 
-__global__ __launch_bounds__(256) void stem_kernel(
+__global__ __launch_bounds__(256) void stem_mfma_kernel(
     const float* __restrict__ src, const long long* __restrict__ pos, long long sample_stride,
-    long long chan_stride, int row_stride, int P, const float* __restrict__ w,
-    const float* __restrict__ bias, float* __restrict__ out, int out_ld, int cout, int ocg,
-    const int* __restrict__ skip_flag, int skip_when) {
+    long long chan_stride, int row_stride, int P, const float* __restrict__ w, float* __restrict__ out,
+    int out_ld, int cout, int ocg, double* __restrict__ stats, const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
-  __shared__ __attribute__((aligned(16))) float tile[3][ST_IH][ST_IW];
-  const int tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float tile[3 * ST_IH * ST_IW];
+  __shared__ float red[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, g = lane >> 4;
   const int n = blockIdx.z / ocg, og = blockIdx.z % ocg;
   const int OH = P / 2;
   const int oy0 = blockIdx.y * ST_TY, ox0 = blockIdx.x * ST_TX;
   const float* base = src + (long long)n * sample_stride;
   if (pos) base += pos[2 * n] * (long long)P * row_stride + pos[2 * n + 1] * (long long)P;
+  if (tid < 32) red[tid] = 0.0f;
   for (int i = tid; i < 3 * ST_IH * ST_IW; i += 256) {
     const int c = i / (ST_IH * ST_IW), r = (i / ST_IW) % ST_IH, q = i % ST_IW;
     const int iy = 2 * oy0 - 2 + r, ix = 2 * ox0 - 2 + q;
     float v = 0.0f;
     if (iy >= 0 && iy < P && ix >= 0 && ix < P) v = base[c * chan_stride + (long long)iy * row_stride + ix];
-    tile[c][r][q] = v;
+    tile[i] = v;
+  }
+  // A operand (weights): lane holds W[oc = lm][k = 4s + g] for every k-step s; B operand offset table
+  float wreg[ST_KS];
+  int koff[ST_KS];
+#pragma unroll
+  for (int s = 0; s < ST_KS; ++s) {
+    const int k = 4 * s + g;
+    wreg[s] = w[k * cout + og * 16 + lm];
+    const int c = k / 36, dy = (k % 36) / 6, dx = k % 6;
+    koff[s] = (c * ST_IH + dy) * ST_IW + dx;
   }
   __syncthreads();
-  const int txp = tid & 15, ty = tid >> 4;
-  float acc0[16], acc1[16];
+  f32x4 s1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, s2[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 1
+  for (int r = 0; r < 4; ++r) {
+    const int ty = wave * 4 + r;
+    const int oy = oy0 + ty;
 #pragma unroll
-  for (int o = 0; o < 16; ++o) acc0[o] = acc1[o] = bias[og * 16 + o];
-  const float* wg = w + og * 16;
+    for (int h = 0; h < 2; ++h) {
+      const int pbase = (2 * ty) * ST_IW + 2 * (16 * h + lm);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-#pragma unroll
-    for (int dy = 0; dy < 6; ++dy) {
-      const f32x4* rp = reinterpret_cast<const f32x4*>(&tile[c][2 * ty + dy][4 * txp]);
-      const f32x4 a = rp[0], b = rp[1];
-      const float in[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-      for (int dx = 0; dx < 6; ++dx) {
-        const float* wp = wg + ((c * 6 + dy) * 6 + dx) * cout;
-#pragma unroll
-        for (int o = 0; o < 16; ++o) {
-          const float wv = wp[o];
-          acc0[o] = fmaf(in[dx], wv, acc0[o]);
-          acc1[o] = fmaf(in[dx + 2], wv, acc1[o]);
-        }
+      for (int s = 0; s < ST_KS; ++s)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], tile[pbase + koff[s]], acc, 0, 0, 0);
+      const int ox = ox0 + 16 * h + lm;
+      if (oy < OH && ox < OH) {
+        *reinterpret_cast<f32x4*>(out + (((long long)n * OH + oy) * OH + ox) * out_ld + og * 16 + 4 * g) = acc;
+        s1[0] += acc;
+        s2[0] += acc * acc;
       }
     }
   }
-  const int oy = oy0 + ty, ox = ox0 + 2 * txp;
-  if (oy < OH) {
-    float* op = out + (((long long)n * OH + oy) * OH + ox) * out_ld + og * 16;
-    if (ox < OH) {
-#pragma unroll
-      for (int o = 0; o < 16; o += 4) {
-        f32x4 v = {act_apply(acc0[o], ACT_SILU), act_apply(acc0[o + 1], ACT_SILU),
-                   act_apply(acc0[o + 2], ACT_SILU), act_apply(acc0[o + 3], ACT_SILU)};
-        *reinterpret_cast<f32x4*>(op + o) = v;
-      }
-    }
-    if (ox + 1 < OH) {
-#pragma unroll
-      for (int o = 0; o < 16; o += 4) {
-        f32x4 v = {act_apply(acc1[o], ACT_SILU), act_apply(acc1[o + 1], ACT_SILU),
-                   act_apply(acc1[o + 2], ACT_SILU), act_apply(acc1[o + 3], ACT_SILU)};
-        *reinterpret_cast<f32x4*>(op + out_ld + o) = v;
-      }
-    }
+  if (stats) {
+    wave_stats_to_lds<1>(s1, s2, red, lane, 16);
+    __syncthreads();
+    if (tid < 32) atomicAdd(&stats[2 * (og * 16) + tid], (double)red[tid]);
   }
 }
 
@@ -103,9 +150,9 @@ int launch_stem(const StemArgs& a, hipStream_t s) {
   const int OH = a.P / 2;
   const int ocg = a.cout / 16;
   dim3 grid((OH + ST_TX - 1) / ST_TX, (OH + ST_TY - 1) / ST_TY, a.N * ocg);
-  hipLaunchKernelGGL(stem_kernel, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.sample_stride,
-                     a.chan_stride, a.row_stride, a.P, a.w, a.bias, a.out, a.out_ld, a.cout, ocg,
-                     a.skip_flag, a.skip_when);
+  hipLaunchKernelGGL(stem_mfma_kernel, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.sample_stride,
+                     a.chan_stride, a.row_stride, a.P, a.w, a.out, a.out_ld, a.cout, ocg, a.stats, a.skip_flag,
+                     a.skip_when);
   return 0;
 }
 
@@ -114,52 +161,75 @@ int launch_stem(const StemArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------
 template <int S>
 __global__ __launch_bounds__(256) void dw3x3_kernel(
-    const float* __restrict__ in, int in_ld, const float* __restrict__ w, const float* __restrict__ bias,
-    float* __restrict__ out, int out_ld, int C, int H, int W, int OH, int OW, int N, int act,
+    const float* __restrict__ in, int in_ld, ChanTab it, const float* __restrict__ w, float* __restrict__ out,
+    int out_ld, int C, int H, int W, int OH, int OW, int N, double* __restrict__ stats,
     const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
+  extern __shared__ float red[];   // [C][2] when stats
+  if (stats) {
+    for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.0f;
+    __syncthreads();
+  }
   const int C4 = C >> 2;
   const int YS = (OH + 3) >> 2;
   const long long total = (long long)N * YS * OW * C4;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int c4 = (int)(idx % C4);
-  const int ox = (int)((idx / C4) % OW);
-  const int ys = (int)((idx / ((long long)C4 * OW)) % YS);
-  const int n = (int)(idx / ((long long)C4 * OW * YS));
-  const int c = c4 * 4;
-  f32x4 wv[9];
+  if (idx < total) {
+    const int c4 = (int)(idx % C4);
+    const int ox = (int)((idx / C4) % OW);
+    const int ys = (int)((idx / ((long long)C4 * OW)) % YS);
+    const int n = (int)(idx / ((long long)C4 * OW * YS));
+    const int c = c4 * 4;
+    f32x4 wv[9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(w + t * C + c);
-  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c);
-  f32x4 acc[4] = {bv, bv, bv, bv};
-  const int oy0 = ys * 4;
-  constexpr int R = 3 * S + 3;
-  const float* inb = in + (long long)n * H * W * in_ld + c;
+    for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(w + t * C + c);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(it.sc + c);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(it.sh + c);
+    const f32x4 fl = *reinterpret_cast<const f32x4*>(it.fl + c);
+    f32x4 acc[4];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int iy = oy0 * S - 1 + r;
-    if (iy < 0 || iy >= H) continue;
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int oy0 = ys * 4;
+    constexpr int R = 3 * S + 3;
+    const float* inb = in + (long long)n * H * W * in_ld + c;
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int ix = ox * S - 1 + kx;
-      if (ix < 0 || ix >= W) continue;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(inb + ((long long)iy * W + ix) * in_ld);
+    for (int r = 0; r < R; ++r) {
+      const int iy = oy0 * S - 1 + r;
+      if (iy < 0 || iy >= H) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ky = r - j * S;
-        if (ky >= 0 && ky < 3) acc[j] += v * wv[ky * 3 + kx];
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * S - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        const f32x4 v = tf4(*reinterpret_cast<const f32x4*>(inb + ((long long)iy * W + ix) * in_ld), sc, sh, fl);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ky = r - j * S;
+          if (ky >= 0 && ky < 3) acc[j] += v * wv[ky * 3 + kx];
+        }
+      }
+    }
+    float* ob = out + (long long)n * OH * OW * out_ld + c;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int oy = oy0 + j;
+      if (oy < OH) {
+        *reinterpret_cast<f32x4*>(ob + ((long long)oy * OW + ox) * out_ld) = acc[j];
+        s1 += acc[j];
+        s2 += acc[j] * acc[j];
+      }
+    }
+    if (stats) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        atomicAdd(&red[2 * (c + q)], s1[q]);
+        atomicAdd(&red[2 * (c + q) + 1], s2[q]);
       }
     }
   }
-  float* ob = out + (long long)n * OH * OW * out_ld + c;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int oy = oy0 + j;
-    if (oy < OH) {
-      f32x4 v = {act_apply(acc[j].x, act), act_apply(acc[j].y, act), act_apply(acc[j].z, act), act_apply(acc[j].w, act)};
-      *reinterpret_cast<f32x4*>(ob + ((long long)oy * OW + ox) * out_ld) = v;
-    }
+  if (stats) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&stats[i], (double)red[i]);
   }
 }
 
@@ -167,37 +237,40 @@ int launch_dw(const ConvArgs& a, hipStream_t s) {
   const int YS = (a.OH + 3) / 4;
   const long long total = (long long)a.N * YS * a.OW * (a.cin / 4);
   const unsigned blocks = (unsigned)((total + 255) / 256);
+  const size_t smem = a.stats ? (size_t)2 * a.cin * sizeof(float) : 0;
   if (a.stride == 1)
-    hipLaunchKernelGGL(dw3x3_kernel<1>, dim3(blocks), dim3(256), 0, s, a.in, a.in_ld, a.w, a.bias, a.out, a.out_ld,
-                       a.cin, a.H, a.W, a.OH, a.OW, a.N, a.act, a.skip_flag, a.skip_when);
+    hipLaunchKernelGGL(dw3x3_kernel<1>, dim3(blocks), dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.out, a.out_ld,
+                       a.cin, a.H, a.W, a.OH, a.OW, a.N, a.stats, a.skip_flag, a.skip_when);
   else
-    hipLaunchKernelGGL(dw3x3_kernel<2>, dim3(blocks), dim3(256), 0, s, a.in, a.in_ld, a.w, a.bias, a.out, a.out_ld,
-                       a.cin, a.H, a.W, a.OH, a.OW, a.N, a.act, a.skip_flag, a.skip_when);
+    hipLaunchKernelGGL(dw3x3_kernel<2>, dim3(blocks), dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.out, a.out_ld,
+                       a.cin, a.H, a.W, a.OH, a.OW, a.N, a.stats, a.skip_flag, a.skip_when);
   return 0;
 }
 
 // ------------------------------------------------------------------------------------
-// pointwise 1x1 conv: out[m][n] = act(bias[n] + sum_k x[m][k] * w[n][k]) (+ res[m][n])
-// D = W * X^T per 16x16 tile on v_mfma_f32_16x16x4_f32: channel n on the row, pixel m on the
-// lane, so each lane owns 4 consecutive channels of one pixel (one dwordx4 store).
+// pointwise 1x1 conv: z[m][n] = sum_k T(x[m][k]) * w[n][k];  optional bias + act epilogue for the
+// BN-free layers (embed_fpn.0, head predictors).  D = W * X^T per 16x16 tile: channel on the
+// row, pixel on the lane -> each lane owns 4 consecutive channels of one pixel (dwordx4 store).
 // ------------------------------------------------------------------------------------
-constexpr int PW_BM = 128;     // pixels per block (4 waves x 2 tiles of 16)
+constexpr int PW_BM = 128;     // pixels per workgroup (4 waves x 2 tiles of 16)
 
 template <int CT, int PW_KC>
 __global__ __launch_bounds__(256) void pw_mfma_kernel(
-    const float* __restrict__ x, int x_ld, const float* __restrict__ w, const float* __restrict__ bias,
-    float* __restrict__ out, int out_ld, const float* __restrict__ res, int res_ld,
-    long long M, int K, int Nc, int act, const int* __restrict__ skip_flag, int skip_when) {
+    const float* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, int out_ld, long long M, int K, int Nc, int act, double* __restrict__ stats,
+    const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
   constexpr int PW_LD = PW_KC + 4;        // K chunk staged in LDS (+4 floats: bank spread, 16-B rows)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;                       // [PW_BM][PW_LD]
   float* Ws = smem + PW_BM * PW_LD;       // [16*CT][PW_LD]
+  float* red = Ws + 16 * CT * PW_LD;      // [16*CT][2]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, g = lane >> 4;
   const long long m0 = (long long)blockIdx.x * PW_BM;
   const int n0 = blockIdx.y * (16 * CT);
+  if (stats && tid < 32 * CT) red[tid] = 0.0f;
 
   f32x4 acc[2][CT];
 #pragma unroll
@@ -212,7 +285,11 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
     for (int i = tid; i < PW_BM * q4; i += 256) {
       const int r = i / q4, q = i - r * q4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m0 + r < M) v = *reinterpret_cast<const f32x4*>(x + (m0 + r) * x_ld + k0 + 4 * q);
+      if (m0 + r < M) {
+        const int kk = k0 + 4 * q;
+        v = tf4(*reinterpret_cast<const f32x4*>(x + (m0 + r) * x_ld + kk), *reinterpret_cast<const f32x4*>(it.sc + kk),
+                *reinterpret_cast<const f32x4*>(it.sh + kk), *reinterpret_cast<const f32x4*>(it.fl + kk));
+      }
       *reinterpret_cast<f32x4*>(Xs + r * PW_LD + 4 * q) = v;
     }
     for (int i = tid; i < 16 * CT * q4; i += 256) {
@@ -241,6 +318,9 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
       }
     }
   }
+  f32x4 s1[CT], s2[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) { s1[c] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[c] = s1[c]; }
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     const long long m = m0 + wave * 32 + p * 16 + lm;
@@ -249,12 +329,18 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
     for (int c = 0; c < CT; ++c) {
       const int n = n0 + c * 16 + 4 * g;
       if (n >= Nc) continue;
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
-      f32x4 v = acc[p][c] + bv;
-      v = f32x4{act_apply(v.x, act), act_apply(v.y, act), act_apply(v.z, act), act_apply(v.w, act)};
-      if (res) v += *reinterpret_cast<const f32x4*>(res + m * res_ld + n);
+      f32x4 v = acc[p][c];
+      if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+      if (act != ACT_NONE) v = f32x4{act_apply(v.x, act), act_apply(v.y, act), act_apply(v.z, act), act_apply(v.w, act)};
       *reinterpret_cast<f32x4*>(out + m * out_ld + n) = v;
+      s1[c] += v;
+      s2[c] += v * v;
     }
+  }
+  if (stats) {
+    wave_stats_to_lds<CT>(s1, s2, red, lane, Nc - n0);
+    __syncthreads();
+    if (tid < 32 * CT && n0 + (tid >> 1) < Nc) atomicAdd(&stats[2 * n0 + tid], (double)red[tid]);
   }
 }
 
@@ -262,9 +348,9 @@ template <int CT>
 static void launch_pw_ct(const ConvArgs& a, long long M, hipStream_t s) {
   constexpr int KC = (CT > 4) ? 32 : 64;
   dim3 grid((unsigned)((M + PW_BM - 1) / PW_BM), (unsigned)((a.cout + 16 * CT - 1) / (16 * CT)));
-  const size_t smem = (size_t)(PW_BM + 16 * CT) * (KC + 4) * sizeof(float);
-  hipLaunchKernelGGL((pw_mfma_kernel<CT, KC>), grid, dim3(256), smem, s, a.in, a.in_ld, a.w, a.bias, a.out, a.out_ld,
-                     a.res, a.res_ld, M, a.cin, a.cout, a.act, a.skip_flag, a.skip_when);
+  const size_t smem = ((size_t)(PW_BM + 16 * CT) * (KC + 4) + 32 * CT) * sizeof(float);
+  hipLaunchKernelGGL((pw_mfma_kernel<CT, KC>), grid, dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.bias, a.out,
+                     a.out_ld, M, a.cin, a.cout, a.act, a.stats, a.skip_flag, a.skip_when);
 }
 
 int launch_pw(const ConvArgs& a, hipStream_t s) {
@@ -279,11 +365,11 @@ int launch_pw(const ConvArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------
-// SPP: slices 1..3 of `cat` = maxpool 5 / 9 / 13 (stride 1, -inf padding) of slice 0.
-// mp9 = mp5(mp5), mp13 = mp5(mp9); each mp5 is separable.  Block = (image, 32 channels).
+// SPP: slices 1..3 of `cat` = maxpool 5 / 9 / 13 (stride 1, -inf padding) of the ACTIVATION of
+// slice 0 (raw z + table).  mp9 = mp5(mp5), mp13 = mp5(mp9); each mp5 is separable.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void spp_kernel(float* __restrict__ cat, int ld, int h, int H, int W, int cb,
-                                                  const int* __restrict__ skip_flag, int skip_when) {
+                                                  ChanTab it, const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
   extern __shared__ float sp[];
   const int HW = H * W;
@@ -292,7 +378,11 @@ __global__ __launch_bounds__(256) void spp_kernel(float* __restrict__ cat, int l
   const int n = blockIdx.y, c0 = blockIdx.x * cb;
   float* base = cat + (long long)n * HW * ld + c0;
   const int tid = threadIdx.x;
-  for (int e = tid; e < HW * cb; e += 256) A[e] = base[(long long)(e / cb) * ld + (e % cb)];
+  for (int e = tid; e < HW * cb; e += 256) {
+    const int c = e % cb;
+    const float z = base[(long long)(e / cb) * ld + c];
+    A[e] = it.fl[c0 + c] != 0.0f ? silu(fmaf(z, it.sc[c0 + c], it.sh[c0 + c])) : z;
+  }
   __syncthreads();
   for (int stage = 1; stage <= 3; ++stage) {
     for (int e = tid; e < HW * cb; e += 256) {
@@ -319,16 +409,17 @@ __global__ __launch_bounds__(256) void spp_kernel(float* __restrict__ cat, int l
   }
 }
 
-int launch_spp(float* cat, int ld, int h, int H, int W, int N, const int* skip_flag, int skip_when, hipStream_t s) {
+int launch_spp(float* cat, int ld, int h, int H, int W, int N, ChanTab it, const int* skip_flag, int skip_when,
+               hipStream_t s) {
   int cb = 32;                                   // channels per block: keep 2 * HW * cb floats under 48 KB
   while (cb > 4 && (size_t)H * W * cb * 2 * sizeof(float) > 48 * 1024) cb >>= 1;
   dim3 grid(h / cb, N);
   const size_t smem = (size_t)H * W * cb * 2 * sizeof(float);
-  hipLaunchKernelGGL(spp_kernel, grid, dim3(256), smem, s, cat, ld, h, H, W, cb, skip_flag, skip_when);
+  hipLaunchKernelGGL(spp_kernel, grid, dim3(256), smem, s, cat, ld, h, H, W, cb, it, skip_flag, skip_when);
   return 0;
 }
 
-// nearest x2 upsample: out[n][y][x][c] = in[n][y/2][x/2][c]
+// nearest x2 upsample of raw values: out[n][y][x][c] = in[n][y/2][x/2][c]
 __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, int in_ld,
                                                        float* __restrict__ out, int out_ld, int C, int H, int W,
                                                        long long total, const int* __restrict__ skip_flag,
@@ -353,21 +444,83 @@ int launch_upsample(const float* in, int in_ld, float* out, int out_ld, int C, i
   return 0;
 }
 
-// NHWC slice -> contiguous NCHW (boundary export for the parity API; not on the hot loop)
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, int in_ld,
+// Bottleneck shortcut: out = T_res(res) + T_z(z), materialised (table flag 0 on the output).
+__global__ __launch_bounds__(256) void addact_kernel(const float* __restrict__ z, int z_ld, ChanTab zt,
+                                                     const float* __restrict__ res, int res_ld, ChanTab rt,
+                                                     float* __restrict__ out, int out_ld, int C, long long M,
+                                                     const int* __restrict__ skip_flag, int skip_when) {
+  if (skip_flag && *skip_flag >= skip_when) return;
+  const int C4 = C >> 2;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * C4) return;
+  const int c = (int)(idx % C4) * 4;
+  const long long m = idx / C4;
+  const f32x4 a = tf4(*reinterpret_cast<const f32x4*>(z + m * z_ld + c), *reinterpret_cast<const f32x4*>(zt.sc + c),
+                      *reinterpret_cast<const f32x4*>(zt.sh + c), *reinterpret_cast<const f32x4*>(zt.fl + c));
+  const f32x4 r = tf4(*reinterpret_cast<const f32x4*>(res + m * res_ld + c), *reinterpret_cast<const f32x4*>(rt.sc + c),
+                      *reinterpret_cast<const f32x4*>(rt.sh + c), *reinterpret_cast<const f32x4*>(rt.fl + c));
+  *reinterpret_cast<f32x4*>(out + m * out_ld + c) = a + r;
+}
+
+int launch_addact(const float* z, int z_ld, ChanTab zt, const float* res, int res_ld, ChanTab rt, float* out,
+                  int out_ld, int C, long long M, const int* skip_flag, int skip_when, hipStream_t s) {
+  const long long total = M * (C / 4);
+  hipLaunchKernelGGL(addact_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, z_ld, zt, res, res_ld, rt,
+                     out, out_ld, C, M, skip_flag, skip_when);
+  return 0;
+}
+
+// Train-mode BatchNorm2d (eps 1e-3, momentum 0.03): batch mean / biased variance
+// from the fp64 sums -> (scale, shift) of the layer's output channels (and of an alias slice
+// that holds an upsampled copy), saved (mean, invstd) for the backward pass, running stats.
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ run_mean,
+                                   float* __restrict__ run_var, float* __restrict__ save, ChanTab t0, ChanTab t1,
+                                   int C, float eps, float momentum, const int* __restrict__ skip_flag,
+                                   int skip_when) {
+  if (skip_flag && *skip_flag >= skip_when) return;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = stats[2 * c] / count;
+  double var = stats[2 * c + 1] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * invstd;
+  const float sh = beta[c] - (float)mean * sc;
+  t0.sc[c] = sc; t0.sh[c] = sh; t0.fl[c] = 1.0f;
+  if (t1.sc) { t1.sc[c] = sc; t1.sh[c] = sh; t1.fl[c] = 1.0f; }
+  if (save) { save[2 * c] = (float)mean; save[2 * c + 1] = invstd; }
+  if (run_mean) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * (float)mean;
+    run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (float)unbiased;
+  }
+}
+
+int launch_bn_finalize(const double* stats, double count, const float* gamma, const float* beta, float* run_mean,
+                       float* run_var, float* save, ChanTab t0, ChanTab t1, int C, float eps, float momentum,
+                       const int* skip_flag, int skip_when, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, stats, count, gamma, beta, run_mean, run_var,
+                     save, t0, t1, C, eps, momentum, skip_flag, skip_when);
+  return 0;
+}
+
+// NHWC slice (raw z + table) -> contiguous NCHW activations (boundary export for the parity API)
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, int in_ld, ChanTab it,
                                                            float* __restrict__ out, int C, int HW, long long total) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int p = (int)(idx % HW);
   const int c = (int)((idx / HW) % C);
   const long long n = idx / ((long long)HW * C);
-  out[idx] = in[(n * HW + p) * in_ld + c];
+  const float z = in[(n * HW + p) * in_ld + c];
+  out[idx] = it.fl[c] != 0.0f ? silu(fmaf(z, it.sc[c], it.sh[c])) : z;
 }
 
-int launch_nhwc_to_nchw(const float* in, int in_ld, float* out, int C, int HW, int N, hipStream_t s) {
+int launch_nhwc_to_nchw(const float* in, int in_ld, ChanTab it, float* out, int C, int HW, int N, hipStream_t s) {
   const long long total = (long long)N * C * HW;
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, in_ld, out, C, HW,
-                     total);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, in_ld, it, out, C,
+                     HW, total);
   return 0;
 }
 

@@ -63,16 +63,20 @@ struct Builder {
 
   // BaseConv(cin, cout, k, s, groups): conv + BN + SiLU.
   View base_conv(const std::string& name, View in, int cout, int k, int s, bool dw,
-                 const View* dst = nullptr, const View* res = nullptr, int act = ACT_SILU) {
+                 const View* dst = nullptr, const View* res = nullptr) {
     int OH = (k == 1) ? in.H : out_dim(in.H, s), OW = (k == 1) ? in.W : out_dim(in.W, s);
-    View out = dst ? *dst : fresh(OH, OW, cout);
+    // with a shortcut the conv writes raw z to a scratch buffer and OP_ADDACT materialises z + res
+    View out = (dst && !res) ? *dst : fresh(OH, OW, cout);
     Op op;
     op.kind = (k == 1) ? OP_PW : (dw ? OP_DW : OP_CONV3);
-    op.in = in; op.out = out; op.stride = s; op.act = act; op.name = name;
-    if (res) op.res = *res;
+    op.in = in; op.out = out; op.stride = s; op.act = ACT_NONE; op.name = name;
     op.wslot = add_conv(name, in.C, cout, k, dw ? in.C : 1, true, false);
     net.ops.push_back(op);
-    return out;
+    if (!res) return out;
+    Op add; add.kind = OP_ADDACT; add.in = out; add.res = *res; add.act = ACT_NONE; add.name = name + "+shortcut";
+    add.out = dst ? *dst : fresh(OH, OW, cout);
+    net.ops.push_back(add);
+    return add.out;
   }
   // DWConv = depthwise k x k (stride s) + pointwise 1x1.
   View dw_conv(const std::string& name, View in, int cout, int k, int s,
@@ -114,6 +118,9 @@ struct Builder {
     return base_conv(name + ".conv2", cat, cout, 1, 1, false);
   }
   void upsample(View in, View dst) {
+    // the upsampled copy holds raw z of the producing conv: it shares that layer's (scale, shift)
+    for (auto it = net.ops.rbegin(); it != net.ops.rend(); ++it)
+      if (it->wslot >= 0 && it->out.buf == in.buf && it->out.coff == in.coff) { it->alias = dst; break; }
     Op op; op.kind = OP_UPSAMPLE; op.in = in; op.out = dst; op.name = "upsample"; op.act = ACT_NONE;
     net.ops.push_back(op);
   }
@@ -143,7 +150,7 @@ int build_pafpn(Net& net, std::vector<ParamEntry>& params, const std::string& pr
   // ---- CSPDarknet ("backbone.backbone.*") ----
   View stem = b.fresh(H2, H2, bc);
   {
-    Op op; op.kind = OP_STEM; op.out = stem; op.act = ACT_SILU; op.name = "backbone.stem.conv";
+    Op op; op.kind = OP_STEM; op.out = stem; op.act = ACT_NONE; op.name = "backbone.stem.conv";
     op.in.buf = -1; op.in.H = P; op.in.W = P; op.in.C = 3;
     op.wslot = b.add_conv("backbone.stem.conv", 12, bc, 3, 1, true, false);
     net.ops.push_back(op);
@@ -185,6 +192,13 @@ int build_pafpn(Net& net, std::vector<ParamEntry>& params, const std::string& pr
     off += (net.bufs[i].per_image() + 63) / 64 * 64;   // keep every buffer 256-B aligned
   }
   net.per_image_floats = off;
+  net.tab_off.resize(net.bufs.size());
+  int toff = 0;
+  for (size_t i = 0; i < net.bufs.size(); ++i) { net.tab_off[i] = toff; toff += net.bufs[i].C; }
+  net.tab_channels = (toff + 3) / 4 * 4;
+  int soff = 0;
+  for (auto& cw : net.convs) { cw.stat_off = soff; soff += cw.cout; }
+  net.stat_channels = soff;
   return JN_OK;
 }
 

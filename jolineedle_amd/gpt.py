@@ -182,8 +182,20 @@ class GPT(nn.Module):
                                        _lib.current_stream(self.device)), "jn_embed_patches")
         return out.view(B, T, -1)
 
-    def backbone_features(self, patches, net=None):
-        """fpn_outs of the patch encoder (gpt.py:375) or of the detector backbone, NCHW."""
+    def pull_bn_statistics(self):
+        """Copy the BatchNorm running statistics the engine updated in train mode back into this
+        module's buffers (so state_dict() / checkpoints see them)."""
+        eng = self._engine
+        for name, buf in self.named_buffers():
+            if name.endswith("running_mean") or name.endswith("running_var"):
+                host = torch.empty_like(buf, device="cpu")
+                check(eng.lib.jn_read_tensor(eng.handle, name.encode(), host.data_ptr(), host.numel()), "jn_read_tensor")
+                buf.data.copy_(host)
+        self._uploaded_version = self._weights_version()
+
+    def backbone_features(self, patches, net=None, train=False):
+        """fpn_outs of the patch encoder (gpt.py:375) or of the detector backbone, NCHW.
+        train=True: batch-statistics BatchNorm over the given patches (one batch <= max_batch)."""
         self.sync_weights()
         cfg = self._engine.cfg
         if net is None:
@@ -194,9 +206,10 @@ class GPT(nn.Module):
         chans = [int(256 * width), int(512 * width), int(1024 * width)]
         outs = [torch.empty((N, c, P // s, P // s), device=self.device) for c, s in zip(chans, (8, 16, 32))]
         lib = self._engine.lib
+        assert not train or N <= self.max_batch, "train-mode statistics need the whole batch in one pass"
         for i in range(0, N, self.max_batch):
             n = min(self.max_batch, N - i)
-            check(lib.jn_backbone_forward(self._engine.handle, net, ptr(x[i:i + n]), n, ptr(outs[0][i:i + n]),
+            check(lib.jn_backbone_forward(self._engine.handle, net, ptr(x[i:i + n]), n, int(train), ptr(outs[0][i:i + n]),
                                           ptr(outs[1][i:i + n]), ptr(outs[2][i:i + n]),
                                           _lib.current_stream(self.device)), "jn_backbone_forward")
         return tuple(outs)

@@ -109,6 +109,34 @@ def test_nano_backbone_fpn_maps(P, N):
         assert err < TOL_MAP, (i, err)
 
 
+@pytest.mark.parametrize("P,N", [(64, 5), (448, 3)])
+def test_nano_backbone_train_mode_batchnorm(P, N):
+    """Train-mode BN (batch statistics per pass, src/reinforce.py:304) + running-stat update."""
+    product, oracle = make_pair(3, patch_size=P, block_size=6, with_detector=False, image_processor=None)
+    x = torch.rand((N, 3, P, P), generator=torch.Generator().manual_seed(P + 1))
+    oracle.gpt_backbone.train()
+    with torch.no_grad():
+        ref = oracle.gpt_backbone(x)
+        ref = oracle.gpt_backbone(x)            # twice: running stats move twice
+    product.backbone_features(x, train=True)
+    got = product.backbone_features(x, train=True)
+    for i in range(3):
+        err = (got[i].cpu() - ref[i]).abs().max().item()
+        assert err < 1e-3, (i, err)          # batch statistics amplify fp32 rounding; north-star bound
+    product.pull_bn_statistics()
+    osd, psd = oracle.state_dict(), product.state_dict()
+    for k in osd:
+        if k.startswith("gpt_backbone") and ("running_mean" in k or "running_var" in k):
+            assert torch.allclose(psd[k], osd[k], atol=1e-5, rtol=1e-4), k
+    # back to eval: the refreshed running statistics are used
+    oracle.gpt_backbone.eval()
+    with torch.no_grad():
+        ref = oracle.gpt_backbone(x)
+    got = product.backbone_features(x)
+    for i in range(3):
+        assert (got[i].cpu() - ref[i]).abs().max().item() < 1e-3
+
+
 def test_backbone_golden_and_patch_embedding(golden):
     g = golden("g3_gpt_forward.npz")
     product, oracle = make_pair(int(g["seed"]), int(g["bn_seed"]), patch_size=64, block_size=6,
