@@ -161,6 +161,18 @@ int jn_backbone_forward(jn_ctx* ctx, int net, const float* patches_dev, int N, i
 int jn_read_tensor(jn_ctx* ctx, const char* name, float* host_out, size_t numel);
 /* GPT.embed_patches (src/models/gpt.py:356-384): patches [N,3,P,P] -> [N, n_embd]. */
 int jn_embed_patches(jn_ctx* ctx, const float* patches_dev, int N, float* out_dev, void* stream);
+/* ---- training (loss.backward() / optimizer of src/reinforce.py:341-353) ---------------------- */
+/* optimizer.zero_grad(): clears the flat gradient arena. */
+int jn_zero_grad(jn_ctx* ctx, void* stream);
+/* Backward of the most recent train-mode jn_backbone_forward(net, patches, N, train=1): g*_dev are
+ * dL/d(fpn outputs), NCHW f32 (NULL = zero); parameter gradients (conv weights, BN weight/bias)
+ * are ACCUMULATED into the gradient arena (read with jn_read_grad). */
+int jn_backbone_backward(jn_ctx* ctx, int net, const float* patches_dev, int N, const float* g0_dev,
+                         const float* g1_dev, const float* g2_dev, void* stream);
+/* param.grad of a trainable state-dict entry, in the reference's (PyTorch) layout, to host memory.
+ * Synchronises. */
+int jn_read_grad(jn_ctx* ctx, const char* name, float* host_out, size_t numel);
+
 /* GPT.forward (src/models/gpt.py:481-534), eval mode.  patches [B,T,3,P,P] f32 (NULL with
  * no_patch_emb), actions [B,T] int64, positions [B,T,2] int64 (y,x; NULL unless use_pos_emb),
  * prev_embeddings [B,Tp,C] or NULL.  Without prev_embeddings all T tokens are embedded

@@ -63,6 +63,69 @@ int dev_upload(jn_ctx* ctx, float** out, const std::vector<float>& host) {
   return JN_OK;
 }
 
+// ---- flat parameter store ---------------------------------------------------------------
+// Every trainable tensor lives in one contiguous fp32 arena (packed layouts), mirrored by a
+// gradient arena and the AdamW moments: the optimiser and the RCCL all-reduce see ONE buffer.
+enum PackKind { PK_RAW = 0, PK_T, PK_STEM, PK_DW, PK_CONV3, PK_EFPN_LIN };
+
+int store_param(jn_ctx* ctx, const std::string& name, const std::vector<float>& packed, int kind, int d0, int d1,
+                int d2, float** out) {
+  auto it = ctx->seg_index.find(name);
+  if (it == ctx->seg_index.end()) {
+    const size_t padded = (packed.size() + 3) / 4 * 4;
+    JN_CHECK(ctx->params && ctx->arena_used + padded <= ctx->arena_size, JN_ENOMEM, "parameter arena exhausted at '%s'",
+             name.c_str());
+    ParamSeg sg;
+    sg.name = name; sg.kind = kind; sg.d0 = d0; sg.d1 = d1; sg.d2 = d2; sg.off = ctx->arena_used; sg.numel = packed.size();
+    ctx->arena_used += padded;
+    ctx->seg_index[name] = (int)ctx->segs.size();
+    ctx->segs.push_back(sg);
+    it = ctx->seg_index.find(name);
+  }
+  const ParamSeg& sg = ctx->segs[it->second];
+  JN_CHECK(sg.numel == packed.size(), JN_EINVAL, "'%s' changed size between loads", name.c_str());
+  JN_HIP(hipMemcpy(ctx->params + sg.off, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+  *out = ctx->params + sg.off;
+  return JN_OK;
+}
+
+// inverse of the packing: arena layout -> the reference's (PyTorch) layout
+std::vector<float> unpack_param(const ParamSeg& sg, const std::vector<float>& p) {
+  std::vector<float> t(p.size());
+  switch (sg.kind) {
+    case PK_T:        // stored [in][out] -> [out][in]; d0 = out, d1 = in
+      for (int o = 0; o < sg.d0; ++o)
+        for (int i = 0; i < sg.d1; ++i) t[(size_t)o * sg.d1 + i] = p[(size_t)i * sg.d0 + o];
+      break;
+    case PK_STEM:     // [(c*6+dy)*6+dx][oc] -> [oc][q*3+c][ky][kx]; d0 = cout
+      for (int oc = 0; oc < sg.d0; ++oc)
+        for (int c = 0; c < 3; ++c)
+          for (int dy = 0; dy < 6; ++dy)
+            for (int dx = 0; dx < 6; ++dx) {
+              const int ky = dy >> 1, py = dy & 1, kx = dx >> 1, px = dx & 1, q = py + 2 * px;
+              t[(((size_t)oc * 12 + q * 3 + c) * 3 + ky) * 3 + kx] = p[(size_t)((c * 6 + dy) * 6 + dx) * sg.d0 + oc];
+            }
+      break;
+    case PK_DW:       // [tap][c] -> [c][tap]; d0 = C
+      for (int c = 0; c < sg.d0; ++c)
+        for (int k = 0; k < 9; ++k) t[(size_t)c * 9 + k] = p[(size_t)k * sg.d0 + c];
+      break;
+    case PK_CONV3:    // [tap][o][k] -> [o][k][tap]; d0 = cout, d1 = cin
+      for (int o = 0; o < sg.d0; ++o)
+        for (int k = 0; k < sg.d1; ++k)
+          for (int tp = 0; tp < 9; ++tp) t[((size_t)o * sg.d1 + k) * 9 + tp] = p[((size_t)tp * sg.d0 + o) * sg.d1 + k];
+      break;
+    case PK_EFPN_LIN: // [(p*C + ch)][o] -> [o][ch*HW + p]; d0 = C(out), d1 = HW, d2 = C(in)
+      for (int o = 0; o < sg.d0; ++o)
+        for (int ch = 0; ch < sg.d2; ++ch)
+          for (int q = 0; q < sg.d1; ++q)
+            t[(size_t)o * sg.d1 * sg.d2 + (size_t)ch * sg.d1 + q] = p[((size_t)q * sg.d2 + ch) * sg.d0 + o];
+      break;
+    default: t = p;
+  }
+  return t;
+}
+
 struct TensorMap {
   std::map<std::string, const jn_tensor*> m;
   const float* f32(const std::string& name, size_t numel) const {
@@ -90,12 +153,17 @@ std::vector<float> transpose(const float* w, int out, int in) {
 int upload_raw(jn_ctx* ctx, const TensorMap& tm, const std::string& name, size_t n, float** out) {
   const float* p = tm.f32(name, n);
   if (!p) return JN_ENOTFOUND;
+  return store_param(ctx, name, std::vector<float>(p, p + n), PK_RAW, (int)n, 0, 0, out);
+}
+int upload_buf(jn_ctx* ctx, const TensorMap& tm, const std::string& name, size_t n, float** out) {
+  const float* p = tm.f32(name, n);
+  if (!p) return JN_ENOTFOUND;
   return dev_upload(ctx, out, std::vector<float>(p, p + n));
 }
 int upload_t(jn_ctx* ctx, const TensorMap& tm, const std::string& name, int out_f, int in_f, float** out) {
   const float* p = tm.f32(name, (size_t)out_f * in_f);
   if (!p) return JN_ENOTFOUND;
-  return dev_upload(ctx, out, transpose(p, out_f, in_f));
+  return store_param(ctx, name, transpose(p, out_f, in_f), PK_T, out_f, in_f, 0, out);
 }
 
 // YOLOX BaseConv = bias-free conv + BatchNorm2d(eps=1e-3, momentum=0.03) + SiLU.
@@ -113,13 +181,15 @@ int pack_conv(jn_ctx* ctx, const TensorMap& tm, ConvW& cw, OpKind kind) {
     const int co = cw.cout;
     if ((rc = upload_raw(ctx, tm, cw.prefix + ".bn.weight", co, &cw.gamma_dev))) return rc;
     if ((rc = upload_raw(ctx, tm, cw.prefix + ".bn.bias", co, &cw.beta_dev))) return rc;
-    if ((rc = upload_raw(ctx, tm, cw.prefix + ".bn.running_mean", co, &cw.rmean_dev))) return rc;
-    if ((rc = upload_raw(ctx, tm, cw.prefix + ".bn.running_var", co, &cw.rvar_dev))) return rc;
+    if ((rc = upload_buf(ctx, tm, cw.prefix + ".bn.running_mean", co, &cw.rmean_dev))) return rc;
+    if ((rc = upload_buf(ctx, tm, cw.prefix + ".bn.running_var", co, &cw.rvar_dev))) return rc;
   } else if (cw.has_bias) {
     if ((rc = upload_raw(ctx, tm, cw.prefix + ".bias", cw.cout, &cw.b_dev))) return rc;
   }
   std::vector<float> packed;
+  int pk = PK_RAW;
   if (kind == OP_STEM) {
+    pk = PK_STEM;
     // [oc][q*3 + c][ky][kx] (Focus order TL, BL, TR, BR: q = py + 2*px)  ->  [(c*6+dy)*6+dx][oc]
     packed.assign((size_t)108 * cw.cout, 0.0f);
     for (int oc = 0; oc < cw.cout; ++oc)
@@ -130,6 +200,7 @@ int pack_conv(jn_ctx* ctx, const TensorMap& tm, ConvW& cw, OpKind kind) {
             packed[(size_t)((c * 6 + dy) * 6 + dx) * cw.cout + oc] = w[(((size_t)oc * 12 + q * 3 + c) * 3 + ky) * 3 + kx];
           }
   } else if (kind == OP_DW) {
+    pk = PK_DW;
     packed.resize((size_t)9 * cw.cout);
     for (int c = 0; c < cw.cout; ++c)
       for (int t = 0; t < 9; ++t) packed[(size_t)t * cw.cout + c] = w[(size_t)c * 9 + t];
@@ -137,6 +208,7 @@ int pack_conv(jn_ctx* ctx, const TensorMap& tm, ConvW& cw, OpKind kind) {
     packed.assign(w, w + (size_t)cw.cout * cw.cin);
   } else if (kind == OP_CONV3) {
     // [tap][oc][cin]: every tap is a 1x1 GEMM weight
+    pk = PK_CONV3;
     packed.resize((size_t)9 * cw.cout * cw.cin);
     for (int o = 0; o < cw.cout; ++o)
       for (int k = 0; k < cw.cin; ++k)
@@ -144,7 +216,7 @@ int pack_conv(jn_ctx* ctx, const TensorMap& tm, ConvW& cw, OpKind kind) {
   } else {
     return JN_OK;
   }
-  return dev_upload(ctx, &cw.w_dev, packed);
+  return store_param(ctx, wname, packed, pk, cw.cout, cw.cin, 0, &cw.w_dev);
 }
 
 // get_emb(pos * inv_freq) of positional_encodings >= 6 (interleaved sin, cos), SURVEY.md §2.2
@@ -204,7 +276,7 @@ int jn_create(const jn_config* cfg, jn_ctx** out) {
   if (ctx->cfg.det_nms_threshold <= 0) ctx->cfg.det_nms_threshold = 0.45f;
   if (ctx->cfg.max_det_per_patch <= 0) ctx->cfg.max_det_per_patch = 64;
   const int C = cfg->n_embd, nA = cfg->n_actions;
-  auto& P = ctx->params;
+  auto& P = ctx->params_tab;
   // ---- state-dict table in the reference's construction order (src/models/gpt.py:221-318) ----
   add_param(P, "action_head.lm_heads.0.weight", {nA, C}, 0, false, true);
   {
@@ -282,11 +354,11 @@ int jn_destroy(jn_ctx* ctx) {
   return JN_OK;
 }
 
-int jn_param_count(const jn_ctx* ctx) { return ctx ? (int)ctx->params.size() : JN_EINVAL; }
+int jn_param_count(const jn_ctx* ctx) { return ctx ? (int)ctx->params_tab.size() : JN_EINVAL; }
 
 int jn_param_info_at(const jn_ctx* ctx, int index, jn_param_info* out) {
-  JN_CHECK(ctx && out && index >= 0 && index < (int)ctx->params.size(), JN_EINVAL, "jn_param_info_at: bad index %d", index);
-  *out = ctx->params[index].info;
+  JN_CHECK(ctx && out && index >= 0 && index < (int)ctx->params_tab.size(), JN_EINVAL, "jn_param_info_at: bad index %d", index);
+  *out = ctx->params_tab[index].info;
   return JN_OK;
 }
 
@@ -383,6 +455,18 @@ int jn_load_weights(jn_ctx* ctx, const jn_tensor* tensors, size_t n) {
   if (!ctx->kcache) {
     if ((rc = alloc_workspaces(ctx))) return rc;
   }
+  if (!ctx->params) {
+    size_t total = 0;
+    for (const ParamEntry& e : ctx->params_table()) {
+      if (e.info.dtype != 0 || e.info.is_buffer || !e.info.used) continue;
+      size_t n = 1;
+      for (int i = 0; i < e.info.ndim; ++i) n *= (size_t)e.info.shape[i];
+      total += (n + 3) / 4 * 4;
+    }
+    ctx->arena_size = total;
+    if ((rc = dev_alloc(ctx, &ctx->params, total))) return rc;
+    JN_HIP(hipMemset(ctx->params, 0, total * sizeof(float)));
+  }
   const jn_config& c = ctx->cfg;
   const int C = c.n_embd, nA = c.n_actions;
   for (int ni = 0; ni < 2; ++ni) {
@@ -431,7 +515,7 @@ int jn_load_weights(jn_ctx* ctx, const jn_tensor* tensors, size_t n) {
     for (int o = 0; o < C; ++o)
       for (int ch = 0; ch < C; ++ch)
         for (int p = 0; p < HW; ++p) wt[((size_t)p * C + ch) * C + o] = lw[(size_t)o * HW * C + (size_t)ch * HW + p];
-    if ((rc = dev_upload(ctx, &g.efpn_lin_wt, wt))) return rc;
+    if ((rc = store_param(ctx, "embed_fpn.3.weight", wt, PK_EFPN_LIN, C, HW, C, &g.efpn_lin_wt))) return rc;
     if ((rc = upload_raw(ctx, tm, "embed_fpn.3.bias", C, &g.efpn_lin_b))) return rc;
   }
   if ((rc = upload_t(ctx, tm, "action_head.lm_heads.0.weight", nA, C, &g.head_wt))) return rc;
@@ -543,6 +627,103 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
   }
   JN_HIP(hipGetLastError());
   if (train) net.eval_tab_dirty = true;     // running statistics moved
+  return JN_OK;
+}
+
+// ---- training state --------------------------------------------------------------------
+static int ensure_train_state(jn_ctx* ctx) {
+  int rc;
+  if (!ctx->grads) {
+    if ((rc = dev_alloc(ctx, &ctx->grads, ctx->arena_size))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->adam_m, ctx->arena_size))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->adam_v, ctx->arena_size))) return rc;
+    JN_HIP(hipMemset(ctx->grads, 0, ctx->arena_size * sizeof(float)));
+    JN_HIP(hipMemset(ctx->adam_m, 0, ctx->arena_size * sizeof(float)));
+    JN_HIP(hipMemset(ctx->adam_v, 0, ctx->arena_size * sizeof(float)));
+    std::vector<float> id(3 * 2048, 0.0f);
+    for (int i = 0; i < 2048; ++i) id[i] = 1.0f;
+    if ((rc = dev_upload(ctx, &ctx->ident, id))) return rc;
+  }
+  for (int ni = 0; ni < 2; ++ni) {
+    if (!ctx->has_net[ni]) continue;
+    Net& net = ctx->nets[ni];
+    if (net.gact) continue;
+    if ((rc = dev_alloc(ctx, &net.gact, net.per_image_floats * (size_t)ctx->cfg.max_batch))) return rc;
+    if ((rc = dev_alloc(ctx, &net.bred, (size_t)2 * net.stat_channels))) return rc;
+  }
+  return JN_OK;
+}
+
+static inline float* grad_of(const jn_ctx* ctx, const float* param) { return ctx->grads + (param - ctx->params); }
+
+// Backward of one train-mode PAFPN pass (slot `slot`, N patches): g[fpn views] must hold the
+// incoming gradients; parameter gradients are accumulated into ctx->grads.
+static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, hipStream_t s) {
+  Net& net = ctx->nets[ni];
+  const int MB = ctx->cfg.max_batch;
+  JN_HIP(hipMemsetAsync(net.bred, 0, (size_t)2 * net.stat_channels * sizeof(double), s));
+  float* save = slot_save(net, slot);
+  auto ptr = [&](const View& v) { return view_ptr(net, slot, MB, v); };
+  auto gptr = [&](const View& v) { return net.gact + net.buf_off[v.buf] * (size_t)MB + v.coff; };
+  auto tab = [&](const View& v) { return view_tab(net, slot, v); };
+  auto ld = [&](const View& v) { return net.bufs[v.buf].C; };
+  const ChanTab ident{ctx->ident, ctx->ident + 2048, ctx->ident + 4096};
+  for (auto it = net.ops.rbegin(); it != net.ops.rend(); ++it) {
+    const Op& op = *it;
+    if (op.wslot >= 0) {
+      const ConvW& cw = net.convs[op.wslot];
+      JN_CHECK(cw.has_bn, JN_ESTATE, "backward of BN-free conv %s inside a PAFPN", op.name.c_str());
+      const long long M = (long long)N * op.out.H * op.out.W;
+      double* red = net.bred + 2 * cw.stat_off;
+      launch_bn_bwd_reduce(gptr(op.out), ld(op.out), ptr(op.out), ld(op.out), tab(op.out), save + 2 * cw.stat_off, cw.cout,
+                           M, red, s);
+      launch_bn_bwd_gz(gptr(op.out), ld(op.out), ptr(op.out), ld(op.out), tab(op.out), save + 2 * cw.stat_off,
+                       cw.gamma_dev, red, (double)M, grad_of(ctx, cw.gamma_dev), grad_of(ctx, cw.beta_dev), cw.cout, M, s);
+      float* gw = grad_of(ctx, cw.w_dev);
+      if (op.kind == OP_PW) {
+        ConvArgs a{};
+        a.in = gptr(op.out); a.in_ld = ld(op.out); a.itab = ident; a.w = cw.w_dev; a.bias = nullptr;
+        a.out = gptr(op.in); a.out_ld = ld(op.in);
+        a.N = N; a.H = op.out.H; a.W = op.out.W; a.OH = op.out.H; a.OW = op.out.W;
+        a.cin = cw.cout; a.cout = cw.cin; a.stride = 1; a.act = ACT_NONE;
+        a.accumulate = op.acc_in ? 1 : 0; a.w_transposed = 1;
+        launch_pw(a, s);
+        launch_pw_bwd_weight(gptr(op.out), ld(op.out), ptr(op.in), ld(op.in), tab(op.in), gw, M, cw.cout, cw.cin, s);
+      } else if (op.kind == OP_DW) {
+        launch_dw_bwd_data(gptr(op.out), ld(op.out), cw.w_dev, gptr(op.in), ld(op.in), cw.cout, op.in.H, op.in.W, op.out.H,
+                           op.out.W, N, op.stride, op.acc_in ? 1 : 0, s);
+        launch_dw_bwd_weight(gptr(op.out), ld(op.out), ptr(op.in), ld(op.in), tab(op.in), gw, cw.cout, op.in.H, op.in.W,
+                             op.out.H, op.out.W, N, op.stride, s);
+      } else if (op.kind == OP_STEM) {
+        StemArgs a{ss.src, ss.positions, ss.sample_stride, ss.chan_stride, ss.row_stride, net.P, N, cw.cout,
+                   cw.w_dev, nullptr, 0, nullptr, nullptr, 0};
+        launch_stem_bwd_weight(a, gptr(op.out), ld(op.out), gw, s);
+      } else {
+        set_error("backward of dense 3x3 conv (%s) is not implemented", op.name.c_str());
+        return JN_ESTATE;
+      }
+      continue;
+    }
+    switch (op.kind) {
+      case OP_ADDACT: {
+        const long long M = (long long)N * op.out.H * op.out.W;
+        launch_grad_copy(gptr(op.out), ld(op.out), gptr(op.in), ld(op.in), op.out.C, M, op.acc_in ? 1 : 0, s);
+        launch_grad_copy(gptr(op.out), ld(op.out), gptr(op.res), ld(op.res), op.out.C, M, op.acc_res ? 1 : 0, s);
+        break;
+      }
+      case OP_SPP: {
+        const View full = net_full_view(net, op.out.buf);
+        launch_spp_bwd(ptr(full), gptr(full), ld(op.out), op.in.C, op.in.H, op.in.W, N, tab(op.in), s);
+        break;
+      }
+      case OP_UPSAMPLE:
+        launch_upsample_bwd(gptr(op.out), ld(op.out), gptr(op.in), ld(op.in), op.in.C, op.in.H, op.in.W, N,
+                            op.acc_in ? 1 : 0, s);
+        break;
+      default: break;
+    }
+  }
+  JN_HIP(hipGetLastError());
   return JN_OK;
 }
 
@@ -703,6 +884,58 @@ int jn_read_tensor(jn_ctx* ctx, const char* name, float* host_out, size_t numel)
   }
   set_error("jn_read_tensor: '%s' is not a tensor the engine updates", name);
   return JN_ENOTFOUND;
+}
+
+int jn_zero_grad(jn_ctx* ctx, void* stream) {
+  JN_CHECK(ctx && ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  int rc = ensure_train_state(ctx);
+  if (rc) return rc;
+  JN_HIP(hipMemsetAsync(ctx->grads, 0, ctx->arena_size * sizeof(float), (hipStream_t)stream));
+  return JN_OK;
+}
+
+int jn_backbone_backward(jn_ctx* ctx, int net, const float* patches_dev, int N, const float* g0_dev,
+                         const float* g1_dev, const float* g2_dev, void* stream) {
+  JN_CHECK(ctx && patches_dev, JN_EINVAL, "jn_backbone_backward: null argument");
+  JN_CHECK(net >= 0 && net < 2 && ctx->has_net[net], JN_EINVAL, "network %d is not part of this context", net);
+  JN_CHECK(ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
+  JN_CHECK(N >= 1 && N <= ctx->cfg.max_batch, JN_EINVAL, "N=%d exceeds max_batch=%d", N, ctx->cfg.max_batch);
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  int rc = ensure_train_state(ctx);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  Net& n = ctx->nets[net];
+  const int P = ctx->cfg.patch_size, MB = ctx->cfg.max_batch;
+  const float* gs[3] = {g0_dev, g1_dev, g2_dev};
+  for (int i = 0; i < 3; ++i) {
+    const View& f = n.fpn[i];
+    float* gp = n.gact + n.buf_off[f.buf] * (size_t)MB + f.coff;
+    if (gs[i]) {
+      launch_nchw_to_nhwc_grad(gs[i], gp, n.bufs[f.buf].C, f.C, f.H * f.W, N, 0, s);
+    } else {
+      JN_CHECK(n.bufs[f.buf].C == f.C, JN_ESTATE, "fpn output is a slice");
+      JN_HIP(hipMemsetAsync(gp, 0, (size_t)N * f.H * f.W * f.C * sizeof(float), s));
+    }
+  }
+  StemSrc ss{patches_dev, nullptr, 3LL * P * P, (long long)P * P, P};
+  return run_net_backward(ctx, net, N, ss, 0, s);
+}
+
+int jn_read_grad(jn_ctx* ctx, const char* name, float* host_out, size_t numel) {
+  JN_CHECK(ctx && name && host_out, JN_EINVAL, "jn_read_grad: null argument");
+  JN_CHECK(ctx->grads, JN_ESTATE, "no gradient has been computed yet");
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  auto it = ctx->seg_index.find(name);
+  JN_CHECK(it != ctx->seg_index.end(), JN_ENOTFOUND, "jn_read_grad: '%s' is not a trainable tensor", name);
+  const ParamSeg& sg = ctx->segs[it->second];
+  JN_CHECK(sg.numel == numel, JN_EINVAL, "'%s' has %zu elements, not %zu", name, sg.numel, numel);
+  std::vector<float> packed(numel);
+  JN_HIP(hipDeviceSynchronize());
+  JN_HIP(hipMemcpy(packed.data(), ctx->grads + sg.off, numel * sizeof(float), hipMemcpyDeviceToHost));
+  const std::vector<float> t = unpack_param(sg, packed);
+  std::memcpy(host_out, t.data(), numel * sizeof(float));
+  return JN_OK;
 }
 
 int jn_detect(jn_ctx* ctx, const float*, int, float*, int32_t*, float*, void*) {

@@ -64,6 +64,8 @@ struct Op {
   int stride = 1;
   int act = ACT_SILU;
   int wslot = -1;           // index into Net::convs (packed weights)
+  bool acc_in = false;      // backward: add into g[in] (another consumer, later in forward order, wrote it first)
+  bool acc_res = false;     // backward: same for g[res]
   std::string name;         // module prefix, e.g. "backbone.dark2.0.dconv"
 };
 
@@ -100,11 +102,20 @@ struct Net {
   float* tab = nullptr;           // [n_slots][3][tab_channels]
   float* save = nullptr;          // [n_slots][2 * stat_channels]  (mean, invstd)
   double* stats = nullptr;        // [n_slots][2 * stat_channels]  (sum, sumsq)
+  float* gact = nullptr;          // gradient buffers, one slot: mirror of `act`
+  double* bred = nullptr;         // [2 * stat_channels] backward reductions (sum g_y, sum g_y * zhat)
   bool eval_tab_dirty = true;     // slot-0 table must be rebuilt from the running statistics
 };
 
 struct ParamEntry {
   jn_param_info info;
+};
+
+// One trainable tensor inside the flat parameter arena.
+struct ParamSeg {
+  std::string name;          // the reference's state-dict name
+  int kind = 0, d0 = 0, d1 = 0, d2 = 0;   // packing (api.hip: PackKind) and its dimensions
+  size_t off = 0, numel = 0;
 };
 
 struct GptW {   // device, packed
@@ -138,7 +149,13 @@ struct EnvState {
 
 struct jn_ctx {
   jn_config cfg;
-  std::vector<jnr::ParamEntry> params;
+  std::vector<jnr::ParamEntry> params_tab;
+  const std::vector<jnr::ParamEntry>& params_table() const { return params_tab; }
+  // flat trainable-parameter arena + gradient / AdamW mirrors
+  float* params = nullptr; float* grads = nullptr; float* adam_m = nullptr; float* adam_v = nullptr;
+  size_t arena_size = 0, arena_used = 0;
+  std::vector<jnr::ParamSeg> segs;
+  std::map<std::string, int> seg_index;
   jnr::Net nets[2];                // [JN_NET_GPT_BACKBONE], [JN_NET_DETECTOR]
   bool has_net[2] = {false, false};
   int enc_net = 0;                // which net encodes patches for the GPT
@@ -150,6 +167,7 @@ struct jn_ctx {
   float* emb_part = nullptr;      // [B][KS][C] split-K partials of embed_fpn.3
   int KS = 8;
   int32_t* found = nullptr;       // [B] visited bbox tiles
+  float* ident = nullptr;         // identity table (scale 1, shift 0, flag 0) for gradient operands
   float* tok_emb = nullptr;       // [B][T][C] patch embeddings of jn_gpt_forward
   jnr::EnvState env;
   // rollout workspaces

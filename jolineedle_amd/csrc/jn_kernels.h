@@ -32,6 +32,8 @@ struct ConvArgs {
   const float* w; const float* bias;     // bias only for BN-free layers
   float* out; int out_ld;
   int N, H, W, OH, OW, cin, cout, stride, act;
+  int accumulate;                        // out += (gradient buffers)
+  int w_transposed;                      // pw: w is [cin][cout] and read transposed (data-gradient)
   double* stats;
   const int* skip_flag; int skip_when;
 };
@@ -51,6 +53,27 @@ int launch_bn_finalize(const double* stats, double count, const float* gamma, co
 int launch_nhwc_to_nchw(const float* in, int in_ld, ChanTab it, float* out, int C, int HW, int N, hipStream_t s);
 int launch_efpn_linear(const float* e, const float* wt, float* part, int N, int K, int Co, int KS,
                        const int* skip_flag, int skip_when, hipStream_t s);
+
+// ---- backward of the conv stack (kernels_bwd.hip) ----------------------------------------
+int launch_bn_bwd_reduce(const float* g, int g_ld, const float* z, int z_ld, ChanTab t, const float* save, int C,
+                         long long M, double* red_out, hipStream_t s);
+int launch_bn_bwd_gz(float* g, int g_ld, const float* z, int z_ld, ChanTab t, const float* save, const float* gamma,
+                     const double* red, double count, float* g_gamma, float* g_beta, int C, long long M,
+                     hipStream_t s);
+int launch_pw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw, long long M, int N,
+                         int K, hipStream_t s);
+int launch_dw_bwd_data(const float* gz, int g_ld, const float* w, float* gin, int gin_ld, int C, int H, int W, int OH,
+                       int OW, int N, int stride, int accumulate, hipStream_t s);
+int launch_dw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw, int C, int H,
+                         int W, int OH, int OW, int N, int stride, hipStream_t s);
+int launch_stem_bwd_weight(const StemArgs& a, const float* gz, int g_ld, float* gw, hipStream_t s);
+int launch_spp_bwd(const float* cat, float* gcat, int ld, int h, int H, int W, int N, ChanTab it, hipStream_t s);
+int launch_upsample_bwd(const float* gdst, int dst_ld, float* gsrc, int src_ld, int C, int H, int W, int N,
+                        int accumulate, hipStream_t s);
+int launch_grad_copy(const float* src, int src_ld, float* dst, int dst_ld, int C, long long M, int accumulate,
+                     hipStream_t s);
+int launch_nchw_to_nhwc_grad(const float* in, float* out, int out_ld, int C, int HW, int N, int accumulate,
+                             hipStream_t s);
 
 // ---- env / rollout primitives (kernels_env.hip) -------------------------------------
 int launch_gather(const float* images, const int64_t* positions, float* out, long long out_sample_stride,

@@ -1,0 +1,529 @@
+// Backward kernels of the PAFPN patch encoder (train-mode BatchNorm) for gfx950.
+//
+// Per conv layer with output z (raw), a = silu(y), y = sc*z + sh, batch statistics (mean, invstd):
+//   1. bn_bwd_reduce   sum_y = sum g_a*silu'(y),  sum_yz = sum g_a*silu'(y)*zhat      (fp64 atomics)
+//   2. bn_bwd_gz       g_z = gamma*invstd*(g_y - sum_y/n - zhat*sum_yz/n), in place over g_a;
+//                      dgamma += sum_yz, dbeta += sum_y
+//   3. data gradient   g_a(in) (=|+=) conv^T(g_z, W)     pw: pw_mfma_kernel<.., WT>; dw: dw_bwd_data
+//   4. weight gradient dW += g_z (*) a(in)                pw / dw / stem kernels below (fp32 atomics)
+// g buffers mirror the activation buffers (NHWC fp32, same views).
+#include <hip/hip_runtime.h>
+
+#include "jn_kernels.h"
+
+namespace jnr {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ float sigmoidf_(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+__device__ __forceinline__ float silu_(float v) { return v * sigmoidf_(v); }
+__device__ __forceinline__ float dsilu_(float y) {
+  const float s = sigmoidf_(y);
+  return s * (1.0f + y * (1.0f - s));
+}
+__device__ __forceinline__ f32x4 tf4_(f32x4 z, f32x4 sc, f32x4 sh, f32x4 fl) {
+  f32x4 r;
+  r.x = fl.x != 0.0f ? silu_(fmaf(z.x, sc.x, sh.x)) : z.x;
+  r.y = fl.y != 0.0f ? silu_(fmaf(z.y, sc.y, sh.y)) : z.y;
+  r.z = fl.z != 0.0f ? silu_(fmaf(z.z, sc.z, sh.z)) : z.z;
+  r.w = fl.w != 0.0f ? silu_(fmaf(z.w, sc.w, sh.w)) : z.w;
+  return r;
+}
+
+// ---- 1. per-channel reductions ------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, int g_ld,
+                                                            const float* __restrict__ z, int z_ld, ChanTab t,
+                                                            const float* __restrict__ save, int C, long long M,
+                                                            int rows_per_block, double* __restrict__ red_out) {
+  extern __shared__ float red[];    // [C][2]
+  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.0f;
+  __syncthreads();
+  const int C4 = C >> 2;
+  const int c = (threadIdx.x % C4) * 4;
+  const int rstep = 256 / C4;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  if ((int)(threadIdx.x / C4) < rstep) {
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(t.sc + c), sh = *reinterpret_cast<const f32x4*>(t.sh + c);
+    f32x4 mean, istd;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { mean[q] = save[2 * (c + q)]; istd[q] = save[2 * (c + q) + 1]; }
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    for (long long m = r0 + threadIdx.x / C4; m < r1; m += rstep) {
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(g + m * g_ld + c);
+      const f32x4 zv = *reinterpret_cast<const f32x4*>(z + m * z_ld + c);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float gy = gv[q] * dsilu_(fmaf(zv[q], sc[q], sh[q]));
+        s1[q] += gy;
+        s2[q] += gy * (zv[q] - mean[q]) * istd[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      atomicAdd(&red[2 * (c + q)], s1[q]);
+      atomicAdd(&red[2 * (c + q) + 1], s2[q]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&red_out[i], (double)red[i]);
+}
+
+int launch_bn_bwd_reduce(const float* g, int g_ld, const float* z, int z_ld, ChanTab t, const float* save, int C,
+                         long long M, double* red_out, hipStream_t s) {
+  const int rstep = 256 / (C / 4) > 0 ? 256 / (C / 4) : 1;
+  const int rows_per_block = rstep * 32;
+  const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(256), (size_t)2 * C * sizeof(float), s, g, g_ld, z, z_ld, t,
+                     save, C, M, rows_per_block, red_out);
+  return 0;
+}
+
+// ---- 2. g_a -> g_z in place; BN affine gradients ---------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_gz_kernel(float* __restrict__ g, int g_ld, const float* __restrict__ z,
+                                                        int z_ld, ChanTab t, const float* __restrict__ save,
+                                                        const float* __restrict__ gamma, const double* __restrict__ red,
+                                                        double count, float* __restrict__ g_gamma,
+                                                        float* __restrict__ g_beta, int C, long long M) {
+  const int C4 = C >> 2;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      g_beta[c] += (float)red[2 * c];
+      g_gamma[c] += (float)red[2 * c + 1];
+    }
+  }
+  if (idx >= M * C4) return;
+  const int c = (int)(idx % C4) * 4;
+  const long long m = idx / C4;
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(t.sc + c), sh = *reinterpret_cast<const f32x4*>(t.sh + c);
+  const f32x4 gv = *reinterpret_cast<const f32x4*>(g + m * g_ld + c);
+  const f32x4 zv = *reinterpret_cast<const f32x4*>(z + m * z_ld + c);
+  f32x4 out;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float mean = save[2 * (c + q)], istd = save[2 * (c + q) + 1];
+    const float c1 = (float)(red[2 * (c + q)] / count), c2 = (float)(red[2 * (c + q) + 1] / count);
+    const float zh = (zv[q] - mean) * istd;
+    const float gy = gv[q] * dsilu_(fmaf(zv[q], sc[q], sh[q]));
+    out[q] = gamma[c + q] * istd * (gy - c1 - zh * c2);
+  }
+  *reinterpret_cast<f32x4*>(g + m * g_ld + c) = out;
+}
+
+int launch_bn_bwd_gz(float* g, int g_ld, const float* z, int z_ld, ChanTab t, const float* save, const float* gamma,
+                     const double* red, double count, float* g_gamma, float* g_beta, int C, long long M,
+                     hipStream_t s) {
+  const long long total = M * (C / 4);
+  hipLaunchKernelGGL(bn_bwd_gz_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, g_ld, z, z_ld, t, save,
+                     gamma, red, count, g_gamma, g_beta, C, M);
+  return 0;
+}
+
+// ---- 4a. pointwise weight gradient: dW[n][k] += sum_m gz[m][n] * T(x[m][k]) ---------------------
+// Workgroup = (row chunk, 16*CTN channels of n, 16*CTK channels of k); 64 rows staged per
+// iteration in LDS, each wave contracts 16 of them per iteration on v_mfma_f32_16x16x4_f32.
+constexpr int WG_RB = 64;
+
+template <int CTN, int CTK>
+__global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const float* __restrict__ gz, int g_ld,
+                                                            const float* __restrict__ x, int x_ld, ChanTab it,
+                                                            float* __restrict__ gw, long long M, int N, int K,
+                                                            int rows_per_block) {
+  constexpr int LDN = 16 * CTN + 4, LDK = 16 * CTK + 4;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Gs = sm;                      // [WG_RB][LDN]
+  float* As = sm + WG_RB * LDN;        // [WG_RB][LDK]
+  float* Ts = As + WG_RB * LDK;        // [16*CTN][16*CTK] block partial
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.y * 16 * CTN, k0 = blockIdx.z * 16 * CTK;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  for (int i = tid; i < 256 * CTN * CTK; i += 256) Ts[i] = 0.0f;
+  f32x4 acc[CTN][CTK];
+#pragma unroll
+  for (int a = 0; a < CTN; ++a)
+#pragma unroll
+    for (int b = 0; b < CTK; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (long long rb = r0; rb < r1; rb += WG_RB) {
+    __syncthreads();
+    for (int i = tid; i < WG_RB * 4 * CTN; i += 256) {
+      const int r = i / (4 * CTN), q = i % (4 * CTN);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (rb + r < r1 && n0 + 4 * q < N) v = *reinterpret_cast<const f32x4*>(gz + (rb + r) * g_ld + n0 + 4 * q);
+      *reinterpret_cast<f32x4*>(Gs + r * LDN + 4 * q) = v;
+    }
+    for (int i = tid; i < WG_RB * 4 * CTK; i += 256) {
+      const int r = i / (4 * CTK), q = i % (4 * CTK);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int kk = k0 + 4 * q;
+      if (rb + r < r1 && kk < K)
+        v = tf4_(*reinterpret_cast<const f32x4*>(x + (rb + r) * x_ld + kk), *reinterpret_cast<const f32x4*>(it.sc + kk),
+                 *reinterpret_cast<const f32x4*>(it.sh + kk), *reinterpret_cast<const f32x4*>(it.fl + kk));
+      *reinterpret_cast<f32x4*>(As + r * LDK + 4 * q) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int row = wave * 16 + 4 * st + g;
+      float av[CTN], bv[CTK];
+#pragma unroll
+      for (int a = 0; a < CTN; ++a) av[a] = Gs[row * LDN + 16 * a + lm];
+#pragma unroll
+      for (int b = 0; b < CTK; ++b) bv[b] = As[row * LDK + 16 * b + lm];
+#pragma unroll
+      for (int a = 0; a < CTN; ++a)
+#pragma unroll
+        for (int b = 0; b < CTK; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < CTN; ++a)
+#pragma unroll
+    for (int b = 0; b < CTK; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&Ts[(16 * a + 4 * g + r) * (16 * CTK) + 16 * b + lm], acc[a][b][r]);
+  __syncthreads();
+  for (int i = tid; i < 256 * CTN * CTK; i += 256) {
+    const int n = n0 + i / (16 * CTK), k = k0 + i % (16 * CTK);
+    if (n < N && k < K) atomicAdd(&gw[(long long)n * K + k], Ts[i]);
+  }
+}
+
+template <int CTN, int CTK>
+static void launch_pw_bw_t(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw, long long M,
+                           int N, int K, hipStream_t s) {
+  const int rows_per_block = M > 65536 ? 1024 : 256;
+  dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block), (N + 16 * CTN - 1) / (16 * CTN),
+            (K + 16 * CTK - 1) / (16 * CTK));
+  const size_t smem = ((size_t)WG_RB * (16 * CTN + 4 + 16 * CTK + 4) + 256 * CTN * CTK) * sizeof(float);
+  hipLaunchKernelGGL((pw_bwd_weight_kernel<CTN, CTK>), grid, dim3(256), smem, s, gz, g_ld, x, x_ld, it, gw, M, N, K,
+                     rows_per_block);
+}
+
+int launch_pw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw, long long M, int N,
+                         int K, hipStream_t s) {
+  const int tn = (N + 15) / 16, tk = (K + 15) / 16;
+  const int cn = tn >= 4 ? 4 : (tn == 3 ? 3 : tn), ck = tk >= 4 ? 4 : (tk == 3 ? 3 : tk);
+#define JN_BW(A, B) if (cn == A && ck == B) { launch_pw_bw_t<A, B>(gz, g_ld, x, x_ld, it, gw, M, N, K, s); return 0; }
+  JN_BW(1, 1) JN_BW(1, 2) JN_BW(1, 3) JN_BW(1, 4) JN_BW(2, 1) JN_BW(2, 2) JN_BW(2, 3) JN_BW(2, 4)
+  JN_BW(3, 1) JN_BW(3, 2) JN_BW(3, 3) JN_BW(3, 4) JN_BW(4, 1) JN_BW(4, 2) JN_BW(4, 3) JN_BW(4, 4)
+#undef JN_BW
+  return -1;
+}
+
+// ---- 3b. depthwise data gradient ----------------------------------------------------------------
+// g_in[iy][ix][c] (=|+=) sum_{ky,kx} gz[(iy+1-ky)/S][(ix+1-kx)/S][c] * w[ky][kx][c]   (where divisible)
+template <int S>
+__global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restrict__ gz, int g_ld,
+                                                          const float* __restrict__ w, float* __restrict__ gin,
+                                                          int gin_ld, int C, int H, int W, int OH, int OW, int N,
+                                                          int accumulate) {
+  const int C4 = C >> 2;
+  const long long total = (long long)N * H * W * C4;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C4) * 4;
+  const int ix = (int)((idx / C4) % W);
+  const int iy = (int)((idx / ((long long)C4 * W)) % H);
+  const long long n = idx / ((long long)C4 * W * H);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ty = iy + 1 - ky;
+    if (ty < 0 || (S == 2 && (ty & 1))) continue;
+    const int oy = ty / S;
+    if (oy >= OH) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int tx = ix + 1 - kx;
+      if (tx < 0 || (S == 2 && (tx & 1))) continue;
+      const int ox = tx / S;
+      if (ox >= OW) continue;
+      acc += *reinterpret_cast<const f32x4*>(gz + ((n * OH + oy) * OW + ox) * g_ld + c) *
+             *reinterpret_cast<const f32x4*>(w + (ky * 3 + kx) * C + c);
+    }
+  }
+  float* op = gin + ((n * H + iy) * W + ix) * gin_ld + c;
+  if (accumulate) acc += *reinterpret_cast<const f32x4*>(op);
+  *reinterpret_cast<f32x4*>(op) = acc;
+}
+
+int launch_dw_bwd_data(const float* gz, int g_ld, const float* w, float* gin, int gin_ld, int C, int H, int W, int OH,
+                       int OW, int N, int stride, int accumulate, hipStream_t s) {
+  const long long total = (long long)N * H * W * (C / 4);
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (stride == 1)
+    hipLaunchKernelGGL(dw_bwd_data_kernel<1>, dim3(blocks), dim3(256), 0, s, gz, g_ld, w, gin, gin_ld, C, H, W, OH, OW, N,
+                       accumulate);
+  else
+    hipLaunchKernelGGL(dw_bwd_data_kernel<2>, dim3(blocks), dim3(256), 0, s, gz, g_ld, w, gin, gin_ld, C, H, W, OH, OW, N,
+                       accumulate);
+  return 0;
+}
+
+// ---- 4b. depthwise weight gradient: dW[tap][c] += sum gz[oy][ox][c] * T(x)[oy*S-1+ky][ox*S-1+kx][c]
+template <int S>
+__global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ gz, int g_ld,
+                                                            const float* __restrict__ x, int x_ld, ChanTab it,
+                                                            float* __restrict__ gw, int C, int H, int W, int OH, int OW,
+                                                            int N) {
+  extern __shared__ float red[];   // [9][C]
+  for (int i = threadIdx.x; i < 9 * C; i += 256) red[i] = 0.0f;
+  __syncthreads();
+  const int C4 = C >> 2;
+  const int YS = (OH + 3) >> 2;
+  const long long total = (long long)N * YS * OW * C4;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx < total) {
+    const int c = (int)(idx % C4) * 4;
+    const int ox = (int)((idx / C4) % OW);
+    const int ys = (int)((idx / ((long long)C4 * OW)) % YS);
+    const long long n = idx / ((long long)C4 * OW * YS);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(it.sc + c), sh = *reinterpret_cast<const f32x4*>(it.sh + c),
+                fl = *reinterpret_cast<const f32x4*>(it.fl + c);
+    f32x4 dw[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dw[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 gv[4];
+    const int oy0 = ys * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      gv[j] = (oy0 + j < OH) ? *reinterpret_cast<const f32x4*>(gz + ((n * OH + oy0 + j) * OW + ox) * g_ld + c)
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int R = 3 * S + 3;
+    const float* xb = x + n * H * W * (long long)x_ld + c;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int iy = oy0 * S - 1 + r;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * S - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        const f32x4 v = tf4_(*reinterpret_cast<const f32x4*>(xb + ((long long)iy * W + ix) * x_ld), sc, sh, fl);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ky = r - j * S;
+          if (ky >= 0 && ky < 3) dw[ky * 3 + kx] += v * gv[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) atomicAdd(&red[t * C + c + q], dw[t][q]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 9 * C; i += 256) atomicAdd(&gw[i], red[i]);
+}
+
+int launch_dw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw, int C, int H,
+                         int W, int OH, int OW, int N, int stride, hipStream_t s) {
+  const int YS = (OH + 3) / 4;
+  const long long total = (long long)N * YS * OW * (C / 4);
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  const size_t smem = (size_t)9 * C * sizeof(float);
+  if (stride == 1)
+    hipLaunchKernelGGL(dw_bwd_weight_kernel<1>, dim3(blocks), dim3(256), smem, s, gz, g_ld, x, x_ld, it, gw, C, H, W, OH,
+                       OW, N);
+  else
+    hipLaunchKernelGGL(dw_bwd_weight_kernel<2>, dim3(blocks), dim3(256), smem, s, gz, g_ld, x, x_ld, it, gw, C, H, W, OH,
+                       OW, N);
+  return 0;
+}
+
+// ---- 4c. stem weight gradient: dW[(c,dy,dx)][oc] += sum_pixels gz[p][oc] * img[c][2oy-2+dy][2ox-2+dx]
+constexpr int SB_TY = 8, SB_TX = 32, SB_IH = 2 * SB_TY + 4, SB_IW = 2 * SB_TX + 4;
+
+__global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
+    const float* __restrict__ src, const long long* __restrict__ pos, long long sample_stride, long long chan_stride,
+    int row_stride, int P, const float* __restrict__ gz, int g_ld, int cout, int ocg, float* __restrict__ gw) {
+  __shared__ __attribute__((aligned(16))) float tile[3 * SB_IH * SB_IW];
+  __shared__ float Gz[SB_TY * SB_TX * 16];
+  __shared__ float Ts[16 * 112];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, g = lane >> 4;
+  const int n = blockIdx.z / ocg, og = blockIdx.z % ocg;
+  const int OH = P / 2;
+  const int oy0 = blockIdx.y * SB_TY, ox0 = blockIdx.x * SB_TX;
+  const float* base = src + (long long)n * sample_stride;
+  if (pos) base += pos[2 * n] * (long long)P * row_stride + pos[2 * n + 1] * (long long)P;
+  for (int i = tid; i < 3 * SB_IH * SB_IW; i += 256) {
+    const int c = i / (SB_IH * SB_IW), r = (i / SB_IW) % SB_IH, q = i % SB_IW;
+    const int iy = 2 * oy0 - 2 + r, ix = 2 * ox0 - 2 + q;
+    float v = 0.0f;
+    if (iy >= 0 && iy < P && ix >= 0 && ix < P) v = base[c * chan_stride + (long long)iy * row_stride + ix];
+    tile[i] = v;
+  }
+  for (int i = tid; i < SB_TY * SB_TX * 4; i += 256) {
+    const int p = i >> 2, q = i & 3, ty = p / SB_TX, tx = p % SB_TX;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (oy0 + ty < OH && ox0 + tx < OH)
+      v = *reinterpret_cast<const f32x4*>(gz + (((long long)n * OH + oy0 + ty) * OH + ox0 + tx) * g_ld + og * 16 + 4 * q);
+    *reinterpret_cast<f32x4*>(&Gz[p * 16 + 4 * q]) = v;
+  }
+  for (int i = tid; i < 16 * 112; i += 256) Ts[i] = 0.0f;
+  int koff[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) {
+    const int k = 16 * t + lm;
+    const int c = k / 36, dy = (k % 36) / 6, dx = k % 6;
+    koff[t] = k < 108 ? (c * SB_IH + dy) * SB_IW + dx : 0;
+  }
+  __syncthreads();
+  f32x4 acc[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int st = 0; st < SB_TY * SB_TX / 16; ++st) {
+    const int p = wave * (SB_TY * SB_TX / 4) + 4 * st + g;   // pixel of this k-step for this lane group
+    const int ty = p / SB_TX, tx = p % SB_TX;
+    const float av = Gz[p * 16 + lm];                     // A[i = oc][kk = pixel]
+    const int pbase = (2 * ty) * SB_IW + 2 * tx;
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, tile[pbase + koff[t]], acc[t], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(&Ts[(4 * g + r) * 112 + 16 * t + lm], acc[t][r]);
+  __syncthreads();
+  for (int i = tid; i < 16 * 108; i += 256) {
+    const int oc = i / 108, k = i % 108;
+    atomicAdd(&gw[(long long)k * cout + og * 16 + oc], Ts[oc * 112 + k]);
+  }
+}
+
+int launch_stem_bwd_weight(const StemArgs& a, const float* gz, int g_ld, float* gw, hipStream_t s) {
+  const int OH = a.P / 2, ocg = a.cout / 16;
+  dim3 grid((OH + SB_TX - 1) / SB_TX, (OH + SB_TY - 1) / SB_TY, a.N * ocg);
+  hipLaunchKernelGGL(stem_bwd_weight_kernel, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.sample_stride,
+                     a.chan_stride, a.row_stride, a.P, gz, g_ld, a.cout, ocg, gw);
+  return 0;
+}
+
+// ---- SPP backward: g0 += route(g1, argmax5) + route(g2, argmax9) + route(g3, argmax13) ----------
+__global__ __launch_bounds__(256) void spp_bwd_kernel(const float* __restrict__ cat, float* __restrict__ gcat, int ld,
+                                                      int h, int H, int W, int cb, ChanTab it) {
+  extern __shared__ float sp[];
+  const int HW = H * W;
+  float* A = sp;                 // activation of slice 0
+  float* G = sp + HW * cb;       // gradient accumulator for slice 0
+  const int n = blockIdx.y, c0 = blockIdx.x * cb;
+  const float* base = cat + (long long)n * HW * ld + c0;
+  float* gbase = gcat + (long long)n * HW * ld + c0;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < HW * cb; e += 256) {
+    const int c = e % cb;
+    const float z = base[(long long)(e / cb) * ld + c];
+    A[e] = it.fl[c0 + c] != 0.0f ? silu_(fmaf(z, it.sc[c0 + c], it.sh[c0 + c])) : z;
+    G[e] = 0.0f;
+  }
+  __syncthreads();
+  for (int e = tid; e < HW * cb; e += 256) {
+    const int p = e / cb, c = e % cb, y = p / W, x = p - y * W;
+    for (int stage = 1; stage <= 3; ++stage) {
+      const int rad = 2 * stage;
+      float best = -INFINITY;
+      int bi = p;
+      for (int yy = max(0, y - rad); yy <= min(H - 1, y + rad); ++yy)
+        for (int xx = max(0, x - rad); xx <= min(W - 1, x + rad); ++xx) {
+          const float v = A[(yy * W + xx) * cb + c];
+          if (v > best) { best = v; bi = yy * W + xx; }
+        }
+      atomicAdd(&G[bi * cb + c], gbase[(long long)p * ld + stage * h + c]);
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < HW * cb; e += 256) gbase[(long long)(e / cb) * ld + (e % cb)] += G[e];
+}
+
+int launch_spp_bwd(const float* cat, float* gcat, int ld, int h, int H, int W, int N, ChanTab it, hipStream_t s) {
+  int cb = 32;
+  while (cb > 4 && (size_t)H * W * cb * 2 * sizeof(float) > 48 * 1024) cb >>= 1;
+  dim3 grid(h / cb, N);
+  hipLaunchKernelGGL(spp_bwd_kernel, grid, dim3(256), (size_t)H * W * cb * 2 * sizeof(float), s, cat, gcat, ld, h, H, W,
+                     cb, it);
+  return 0;
+}
+
+// upsample backward: g_src (=|+=) sum of the 2x2 children
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ gdst, int dst_ld,
+                                                           float* __restrict__ gsrc, int src_ld, int C, int H, int W,
+                                                           long long total, int accumulate) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int C4 = C >> 2;
+  const int c = (int)(idx % C4) * 4;
+  const int x = (int)((idx / C4) % W);
+  const int y = (int)((idx / ((long long)C4 * W)) % H);
+  const long long n = idx / ((long long)C4 * W * H);
+  const int OW = 2 * W, OH = 2 * H;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx)
+      acc += *reinterpret_cast<const f32x4*>(gdst + ((n * OH + 2 * y + dy) * OW + 2 * x + dx) * dst_ld + c);
+  float* op = gsrc + ((n * H + y) * W + x) * src_ld + c;
+  if (accumulate) acc += *reinterpret_cast<const f32x4*>(op);
+  *reinterpret_cast<f32x4*>(op) = acc;
+}
+
+int launch_upsample_bwd(const float* gdst, int dst_ld, float* gsrc, int src_ld, int C, int H, int W, int N,
+                        int accumulate, hipStream_t s) {
+  const long long total = (long long)N * H * W * (C / 4);
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gdst, dst_ld, gsrc,
+                     src_ld, C, H, W, total, accumulate);
+  return 0;
+}
+
+// dst (=|+=) src over a [M][C] view (shortcut backward, gradient seeding)
+__global__ __launch_bounds__(256) void grad_copy_kernel(const float* __restrict__ src, int src_ld,
+                                                        float* __restrict__ dst, int dst_ld, int C, long long M,
+                                                        int accumulate) {
+  const int C4 = C >> 2;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= M * C4) return;
+  const int c = (int)(idx % C4) * 4;
+  const long long m = idx / C4;
+  f32x4 v = *reinterpret_cast<const f32x4*>(src + m * src_ld + c);
+  if (accumulate) v += *reinterpret_cast<const f32x4*>(dst + m * dst_ld + c);
+  *reinterpret_cast<f32x4*>(dst + m * dst_ld + c) = v;
+}
+
+int launch_grad_copy(const float* src, int src_ld, float* dst, int dst_ld, int C, long long M, int accumulate,
+                     hipStream_t s) {
+  const long long total = M * (C / 4);
+  hipLaunchKernelGGL(grad_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, src_ld, dst, dst_ld,
+                     C, M, accumulate);
+  return 0;
+}
+
+// NCHW gradient (boundary, parity API) -> NHWC view (=|+=)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_grad_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                int out_ld, int C, int HW, long long total,
+                                                                int accumulate) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const int p = (int)((idx / C) % HW);
+  const long long n = idx / ((long long)HW * C);
+  float v = in[(n * C + c) * HW + p];
+  float* op = out + (n * HW + p) * out_ld + c;
+  if (accumulate) v += *op;
+  *op = v;
+}
+
+int launch_nchw_to_nhwc_grad(const float* in, float* out, int out_ld, int C, int HW, int N, int accumulate,
+                             hipStream_t s) {
+  const long long total = (long long)N * C * HW;
+  hipLaunchKernelGGL(nchw_to_nhwc_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, out_ld, C,
+                     HW, total, accumulate);
+  return 0;
+}
+
+}  // namespace jnr

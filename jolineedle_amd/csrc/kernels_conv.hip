@@ -254,11 +254,13 @@ int launch_dw(const ConvArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------
 constexpr int PW_BM = 128;     // pixels per workgroup (4 waves x 2 tiles of 16)
 
-template <int CT, int PW_KC>
+// WT: `w` is stored [K][Nc] (the forward weight of the layer whose data-gradient is computed) and is
+// read transposed; accumulate: out += result (gradient buffers with several contributors).
+template <int CT, int PW_KC, bool WT>
 __global__ __launch_bounds__(256) void pw_mfma_kernel(
     const float* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, const float* __restrict__ bias,
-    float* __restrict__ out, int out_ld, long long M, int K, int Nc, int act, double* __restrict__ stats,
-    const int* __restrict__ skip_flag, int skip_when) {
+    float* __restrict__ out, int out_ld, long long M, int K, int Nc, int act, int accumulate,
+    double* __restrict__ stats, const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
   constexpr int PW_LD = PW_KC + 4;        // K chunk staged in LDS (+4 floats: bank spread, 16-B rows)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -295,7 +297,14 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
     for (int i = tid; i < 16 * CT * q4; i += 256) {
       const int r = i / q4, q = i - r * q4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (n0 + r < Nc) v = *reinterpret_cast<const f32x4*>(w + (long long)(n0 + r) * K + k0 + 4 * q);
+      if (n0 + r < Nc) {
+        if (WT) {
+          const float* wp = w + (long long)(k0 + 4 * q) * Nc + n0 + r;
+          v = f32x4{wp[0], wp[Nc], wp[2 * Nc], wp[3 * Nc]};
+        } else {
+          v = *reinterpret_cast<const f32x4*>(w + (long long)(n0 + r) * K + k0 + 4 * q);
+        }
+      }
       *reinterpret_cast<f32x4*>(Ws + r * PW_LD + 4 * q) = v;
     }
     __syncthreads();
@@ -332,6 +341,7 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
       f32x4 v = acc[p][c];
       if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
       if (act != ACT_NONE) v = f32x4{act_apply(v.x, act), act_apply(v.y, act), act_apply(v.z, act), act_apply(v.w, act)};
+      if (accumulate) v += *reinterpret_cast<const f32x4*>(out + m * out_ld + n);
       *reinterpret_cast<f32x4*>(out + m * out_ld + n) = v;
       s1[c] += v;
       s2[c] += v * v;
@@ -349,8 +359,12 @@ static void launch_pw_ct(const ConvArgs& a, long long M, hipStream_t s) {
   constexpr int KC = (CT > 4) ? 32 : 64;
   dim3 grid((unsigned)((M + PW_BM - 1) / PW_BM), (unsigned)((a.cout + 16 * CT - 1) / (16 * CT)));
   const size_t smem = ((size_t)(PW_BM + 16 * CT) * (KC + 4) + 32 * CT) * sizeof(float);
-  hipLaunchKernelGGL((pw_mfma_kernel<CT, KC>), grid, dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.bias, a.out,
-                     a.out_ld, M, a.cin, a.cout, a.act, a.stats, a.skip_flag, a.skip_when);
+  if (a.w_transposed)
+    hipLaunchKernelGGL((pw_mfma_kernel<CT, KC, true>), grid, dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.bias,
+                       a.out, a.out_ld, M, a.cin, a.cout, a.act, a.accumulate, a.stats, a.skip_flag, a.skip_when);
+  else
+    hipLaunchKernelGGL((pw_mfma_kernel<CT, KC, false>), grid, dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.bias,
+                       a.out, a.out_ld, M, a.cin, a.cout, a.act, a.accumulate, a.stats, a.skip_flag, a.skip_when);
 }
 
 int launch_pw(const ConvArgs& a, hipStream_t s) {

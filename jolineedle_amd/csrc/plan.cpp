@@ -199,6 +199,35 @@ int build_pafpn(Net& net, std::vector<ParamEntry>& params, const std::string& pr
   int soff = 0;
   for (auto& cw : net.convs) { cw.stat_off = soff; soff += cw.cout; }
   net.stat_channels = soff;
+
+  // Backward bookkeeping: walking the ops in reverse, the first contributor to a gradient view
+  // writes it, later ones accumulate.  The three FPN outputs are seeded from outside first.
+  std::vector<std::vector<char>> written(net.bufs.size());
+  for (size_t i = 0; i < net.bufs.size(); ++i) written[i].assign(net.bufs[i].C, 0);
+  auto mark = [&](const View& v, bool& acc, const char* what, const std::string& name) -> int {
+    int n_w = 0;
+    for (int c = 0; c < v.C; ++c) n_w += written[v.buf][v.coff + c];
+    JN_CHECK(n_w == 0 || n_w == v.C, JN_EINVAL, "backward plan: partially written gradient view (%s of %s)", what,
+             name.c_str());
+    acc = n_w == v.C;
+    for (int c = 0; c < v.C; ++c) written[v.buf][v.coff + c] = 1;
+    return JN_OK;
+  };
+  for (int i = 0; i < 3; ++i) { bool dummy; int rc = mark(net.fpn[i], dummy, "fpn", "seed"); if (rc) return rc; }
+  for (auto it = net.ops.rbegin(); it != net.ops.rend(); ++it) {
+    Op& op = *it;
+    int rc = JN_OK;
+    switch (op.kind) {
+      case OP_STEM: break;
+      case OP_SPP: op.acc_in = true; break;                       // adds into slice 0, written by the cat consumer
+      case OP_ADDACT:
+        if ((rc = mark(op.in, op.acc_in, "in", op.name))) return rc;
+        if ((rc = mark(op.res, op.acc_res, "res", op.name))) return rc;
+        break;
+      default:
+        if ((rc = mark(op.in, op.acc_in, "in", op.name))) return rc;
+    }
+  }
   return JN_OK;
 }
 

@@ -214,6 +214,35 @@ class GPT(nn.Module):
                                           _lib.current_stream(self.device)), "jn_backbone_forward")
         return tuple(outs)
 
+    # ---- training hooks (engine-side gradients) -------------------------------------------
+    def engine_zero_grad(self):
+        self.sync_weights()
+        eng = self._engine
+        check(eng.lib.jn_zero_grad(eng.handle, _lib.current_stream(self.device)), "jn_zero_grad")
+
+    def backbone_backward(self, patches, grads, net=None):
+        """Backward of the last ``backbone_features(patches, train=True)``: `grads` = dL/d(fpn_outs)
+        (NCHW, entries may be None).  Parameter gradients accumulate inside the engine."""
+        cfg = self._engine.cfg
+        if net is None:
+            net = _lib.JN_NET_GPT_BACKBONE if cfg.gpt_bb_width > 0 else _lib.JN_NET_DETECTOR
+        x = patches.to(self.device, torch.float32).contiguous()
+        gs = [None if g is None else g.to(self.device, torch.float32).contiguous() for g in grads]
+        eng = self._engine
+        check(eng.lib.jn_backbone_backward(eng.handle, net, ptr(x), x.shape[0], ptr(gs[0]), ptr(gs[1]), ptr(gs[2]),
+                                           _lib.current_stream(self.device)), "jn_backbone_backward")
+
+    def engine_grads(self, prefix=""):
+        """{state-dict name: gradient tensor (reference layout)} of the trainable tensors."""
+        eng, out = self._engine, {}
+        for name, p in self.named_parameters():
+            if not name.startswith(prefix) or not p.requires_grad:
+                continue
+            host = torch.empty(p.shape, dtype=torch.float32)
+            check(eng.lib.jn_read_grad(eng.handle, name.encode(), host.data_ptr(), host.numel()), "jn_read_grad")
+            out[name] = host
+        return out
+
     def configure_optimizers(self, train_config):
         """gpt.py:547-562: everything not under ``yolox`` vs the detector."""
         optim_gpt = torch.optim.AdamW(

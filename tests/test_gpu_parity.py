@@ -137,6 +137,40 @@ def test_nano_backbone_train_mode_batchnorm(P, N):
         assert (got[i].cpu() - ref[i]).abs().max().item() < 1e-3
 
 
+@pytest.mark.parametrize("P,N", [(64, 4), (448, 2)])
+def test_nano_backbone_backward_vs_autograd(P, N):
+    """Gradients of every conv weight and BN weight/bias of the patch encoder (train-mode BN)
+    for loss = sum_i <fpn_i, R_i>, against torch autograd on the CPU oracle."""
+    product, oracle = make_pair(3, patch_size=P, block_size=6, with_detector=False, image_processor=None)
+    g = torch.Generator().manual_seed(17)
+    x = torch.rand((N, 3, P, P), generator=g)
+    net = oracle.gpt_backbone.train()
+    outs = net(x)
+    R = [torch.randn(o.shape, generator=g) for o in outs]
+    loss = sum((o * r).sum() for o, r in zip(outs, R))
+    net.zero_grad()
+    loss.backward()
+    product.engine_zero_grad()
+    product.backbone_features(x, train=True)
+    product.backbone_backward(x, R)
+    got = product.engine_grads("gpt_backbone.")
+    torch.cuda.synchronize()
+    worst = 0.0
+    for name, p in net.named_parameters():
+        gp = got["gpt_backbone." + name]
+        ref = p.grad
+        scale = ref.abs().max().item() + 1e-6
+        err = (gp - ref).abs().max().item() / scale
+        worst = max(worst, err)
+        assert err < 2e-3, (name, err, scale)
+    # accumulation: a second backward doubles the gradients
+    product.backbone_features(x, train=True)
+    product.backbone_backward(x, R)
+    got2 = product.engine_grads("gpt_backbone.")
+    k = "gpt_backbone.backbone.dark3.1.conv3.conv.weight"
+    assert torch.allclose(got2[k], 2 * got[k], rtol=1e-3, atol=1e-3 * got[k].abs().max().item())
+
+
 def test_backbone_golden_and_patch_embedding(golden):
     g = golden("g3_gpt_forward.npz")
     product, oracle = make_pair(int(g["seed"]), int(g["bn_seed"]), patch_size=64, block_size=6,
