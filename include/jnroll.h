@@ -169,6 +169,33 @@ int jn_zero_grad(jn_ctx* ctx, void* stream);
  * are ACCUMULATED into the gradient arena (read with jn_read_grad). */
 int jn_backbone_backward(jn_ctx* ctx, int net, const float* patches_dev, int N, const float* g0_dev,
                          const float* g1_dev, const float* g2_dev, void* stream);
+/* Options of one REINFORCE iteration (src/reinforce.py:217-265, 341). */
+typedef struct jn_train_opts {
+  int32_t struct_size;
+  int32_t reward_norm;      /* config.reward_norm: advantages = (returns - mean) / (std + 1e-8)      */
+  float ret_mean, ret_std;  /* last_return_mean / last_return_std of the previous optimiser window */
+  float entropy_weight;     /* --entropy-weight                                                      */
+  float loss_scale;         /* 1 / gradient_accumulation                                             */
+} jn_train_opts;
+
+/* One REINFORCE iteration minus the optimiser (src/reinforce.py:326-341): train-mode rollout
+ * (batch-statistics BatchNorm per glimpse step, running statistics updated), loss + metrics, and
+ * loss.backward() into the gradient arena (accumulating).  metrics_dev[8] = action_loss,
+ * entropy_loss, loss, returns, episode_length, steps.  Synchronises once (to read the step count). */
+int jn_reinforce_step(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev,
+                      const int64_t* start_positions_dev, uint64_t seed, int stop_early,
+                      const jn_train_opts* opts, const jn_rollout_out* out, float* metrics_dev, void* stream);
+/* clip_grad_value_(clip_value) + AdamW (torch defaults) over the optim_gpt parameters
+ * (src/reinforce.py:344-346, src/models/gpt.py:552-557); grad_scale multiplies the gradients first
+ * (1/world_size after a SUM all-reduce). */
+int jn_optimizer_step(jn_ctx* ctx, float lr, float weight_decay, float clip_value, float grad_scale, void* stream);
+/* Sizes of the flat parameter/gradient arena (floats): whole arena, and its optim_gpt prefix. */
+int jn_arena_info(jn_ctx* ctx, size_t* total_numel, size_t* optim_gpt_numel);
+/* Use caller-owned device memory (>= arena floats, zeroed) as the gradient arena, e.g. a torch
+ * tensor that is handed to one RCCL all-reduce per optimiser step. */
+int jn_set_grad_arena(jn_ctx* ctx, float* grads_dev, size_t numel);
+/* Current value of a trainable state-dict entry (reference layout) to host memory.  Synchronises. */
+int jn_read_param(jn_ctx* ctx, const char* name, float* host_out, size_t numel);
 /* param.grad of a trainable state-dict entry, in the reference's (PyTorch) layout, to host memory.
  * Synchronises. */
 int jn_read_grad(jn_ctx* ctx, const char* name, float* host_out, size_t numel);

@@ -44,6 +44,11 @@ class JnParamInfo(C.Structure):
                 ("shape", C.c_int64 * 4), ("is_buffer", C.c_int32), ("used", C.c_int32)]
 
 
+class JnTrainOpts(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("reward_norm", C.c_int32), ("ret_mean", C.c_float),
+                ("ret_std", C.c_float), ("entropy_weight", C.c_float), ("loss_scale", C.c_float)]
+
+
 class JnRolloutOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "rewards_dev", "returns_dev", "logprobs_dev", "entropies_dev", "masks_dev", "logit_masks_dev",
@@ -72,6 +77,12 @@ SIGNATURES = {
                                       C.c_void_p, C.c_void_p]),
     "jn_read_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
     "jn_embed_patches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "jn_reinforce_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,
+                                    C.POINTER(JnTrainOpts), C.POINTER(JnRolloutOut), C.c_void_p, C.c_void_p]),
+    "jn_optimizer_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "jn_arena_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "jn_set_grad_arena": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "jn_read_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
     "jn_zero_grad": (C.c_int, [C.c_void_p, C.c_void_p]),
     "jn_backbone_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),

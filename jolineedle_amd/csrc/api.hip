@@ -469,15 +469,19 @@ int jn_load_weights(jn_ctx* ctx, const jn_tensor* tensors, size_t n) {
   }
   const jn_config& c = ctx->cfg;
   const int C = c.n_embd, nA = c.n_actions;
-  for (int ni = 0; ni < 2; ++ni) {
-    if (!ctx->has_net[ni]) continue;
+  auto pack_net = [&](int ni) -> int {
+    if (!ctx->has_net[ni]) return JN_OK;
     Net& net = ctx->nets[ni];
     for (const Op& op : net.ops) {
       if (op.wslot < 0) continue;
-      if ((rc = pack_conv(ctx, tm, net.convs[op.wslot], op.kind))) return rc;
+      int r = pack_conv(ctx, tm, net.convs[op.wslot], op.kind);
+      if (r) return r;
     }
     net.eval_tab_dirty = true;
-  }
+    return JN_OK;
+  };
+  // arena order: [gpt_backbone | decision model] = what optim_gpt updates (gpt.py:552-557), then yolox.*
+  if ((rc = pack_net(JN_NET_GPT_BACKBONE))) return rc;
   GptW& g = ctx->gpt;
   if ((rc = upload_raw(ctx, tm, "transformer.wte.weight", (size_t)nA * C, &g.wte))) return rc;
   if (!c.decoder_pos_encoding) {
@@ -547,6 +551,8 @@ int jn_load_weights(jn_ctx* ctx, const jn_tensor* tensors, size_t n) {
     JN_HIP(hipMemcpy(d, lp.data(), lp.size() * sizeof(GptLayerPtrs), hipMemcpyHostToDevice));
     ctx->layers_dev = d;
   }
+  if (!ctx->gpt_arena_end) ctx->gpt_arena_end = ctx->arena_used;
+  if ((rc = pack_net(JN_NET_DETECTOR))) return rc;
   JN_HIP(hipDeviceSynchronize());
   ctx->weights_loaded = true;
   return JN_OK;
@@ -560,6 +566,7 @@ static View net_full_view(const Net& net, int buf) {
 
 struct StemSrc {
   const float* src; const int64_t* positions; long long sample_stride, chan_stride; int row_stride;
+  int pos_stride = 2;
 };
 
 // One pass of a PAFPN over N patches in workspace slot `slot`.  train != 0: batch-statistics
@@ -588,7 +595,7 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
     switch (op.kind) {
       case OP_STEM: {
         const ConvW& cw = net.convs[op.wslot];
-        StemArgs a{ss.src, ss.positions, ss.sample_stride, ss.chan_stride, ss.row_stride, net.P, N, cw.cout,
+        StemArgs a{ss.src, ss.positions, ss.pos_stride, ss.sample_stride, ss.chan_stride, ss.row_stride, net.P, N, cw.cout,
                    cw.w_dev, ptr(op.out), ld(op.out), train ? stats + 2 * cw.stat_off : nullptr, skip_flag, skip_when};
         launch_stem(a, s);
         finalize(op, cw);
@@ -695,7 +702,7 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
         launch_dw_bwd_weight(gptr(op.out), ld(op.out), ptr(op.in), ld(op.in), tab(op.in), gw, cw.cout, op.in.H, op.in.W,
                              op.out.H, op.out.W, N, op.stride, s);
       } else if (op.kind == OP_STEM) {
-        StemArgs a{ss.src, ss.positions, ss.sample_stride, ss.chan_stride, ss.row_stride, net.P, N, cw.cout,
+        StemArgs a{ss.src, ss.positions, ss.pos_stride, ss.sample_stride, ss.chan_stride, ss.row_stride, net.P, N, cw.cout,
                    cw.w_dev, nullptr, 0, nullptr, nullptr, 0};
         launch_stem_bwd_weight(a, gptr(op.out), ld(op.out), gw, s);
       } else {
@@ -729,18 +736,20 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
 
 // embed_fpn (src/models/gpt.py:294-306, 382) on the last FPN map of the encoder for N patches:
 // 1x1 conv + ReLU, then the split-K partial sums of the Linear (finished by the consumer).
-static int run_embed_fpn(jn_ctx* ctx, int N, int slot, const int* skip_flag, int skip_when, hipStream_t s) {
+static int run_embed_fpn(jn_ctx* ctx, int N, int slot, float* e_buf, const int* skip_flag, int skip_when,
+                         hipStream_t s) {
+  if (!e_buf) e_buf = ctx->efpn_act;
   const Net& net = ctx->nets[ctx->enc_net];
   jn_ctx& x = *ctx;
   const int C = ctx->cfg.n_embd, MB = ctx->cfg.max_batch;
   const View& f = net.fpn[2];
   ConvArgs a{};
   a.in = view_ptr(net, slot, MB, f); a.in_ld = net.bufs[f.buf].C; a.itab = view_tab(net, slot, f);
-  a.w = ctx->gpt.efpn_w; a.bias = nullptr; a.out = ctx->efpn_act; a.out_ld = C;
+  a.w = ctx->gpt.efpn_w; a.bias = nullptr; a.out = e_buf; a.out_ld = C;
   a.N = N; a.H = f.H; a.W = f.W; a.OH = f.H; a.OW = f.W; a.cin = f.C; a.cout = C; a.stride = 1; a.act = ACT_RELU;
   a.skip_flag = skip_flag; a.skip_when = skip_when;
   launch_pw(a, s);
-  launch_efpn_linear(ctx->efpn_act, ctx->gpt.efpn_lin_wt, x.emb_part, N, f.H * f.W * C, C, x.KS, skip_flag, skip_when, s);
+  launch_efpn_linear(e_buf, ctx->gpt.efpn_lin_wt, x.emb_part, N, f.H * f.W * C, C, x.KS, skip_flag, skip_when, s);
   JN_HIP(hipGetLastError());
   return JN_OK;
 }
@@ -786,7 +795,7 @@ int jn_embed_patches(jn_ctx* ctx, const float* patches_dev, int N, float* out_de
   int rc = jn_backbone_forward(ctx, ctx->enc_net, patches_dev, N, 0, nullptr, nullptr, nullptr, stream);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if ((rc = run_embed_fpn(ctx, N, 0, nullptr, 0, s))) return rc;
+  if ((rc = run_embed_fpn(ctx, N, 0, nullptr, nullptr, 0, s))) return rc;
   const int C = ctx->cfg.n_embd;
   hipLaunchKernelGGL(emb_finish_kernel, dim3((N * C + 255) / 256), dim3(256), 0, s, ctx->emb_part,
                      ctx->gpt.efpn_lin_b, out_dev, (long long)C, N, ctx->KS, C);
@@ -835,7 +844,7 @@ int jn_gpt_forward(jn_ctx* ctx, const float* patches_dev, const int64_t* actions
     for (int i = 0; i < n_new; ++i) {
       StemSrc ss{patches_dev + (size_t)(i0 + i) * 3 * P * P, nullptr, (long long)T * 3 * P * P, (long long)P * P, P};
       if ((rc = run_net(ctx, ctx->enc_net, B, ss, 0, 0, nullptr, 0, s))) return rc;
-      if ((rc = run_embed_fpn(ctx, B, 0, nullptr, 0, s))) return rc;
+      if ((rc = run_embed_fpn(ctx, B, 0, nullptr, nullptr, 0, s))) return rc;
       hipLaunchKernelGGL(emb_finish_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, ctx->emb_part, ctx->gpt.efpn_lin_b,
                          ctx->tok_emb + (size_t)i * C, (long long)n_new * C, B, ctx->KS, C);
     }
@@ -1040,8 +1049,9 @@ int jn_set_profiling(jn_ctx* ctx, int enabled) {
   return JN_OK;
 }
 
-int jn_rollout(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, const int64_t* start_positions_dev,
-               uint64_t seed, int do_detection, int stop_early, const jn_rollout_out* out, void* stream) {
+static int rollout_impl(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, const int64_t* start_positions_dev,
+                        uint64_t seed, int do_detection, int stop_early, const jn_rollout_out* out, int train,
+                        void* stream) {
   JN_CHECK(ctx && out, JN_EINVAL, "jn_rollout: null argument");
   JN_CHECK(ctx->env.ready, JN_ESTATE, "jn_env_init has not been called");
   JN_CHECK(ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
@@ -1087,13 +1097,25 @@ int jn_rollout(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, const i
   ctx->conv_ev_used = 0;
   StemSrc ss{e.images, e.positions, 3LL * e.H * e.W, (long long)e.H * e.W, e.W};
   int rc;
+  if (train) {
+    if ((rc = ensure_slots(ctx, ctx->nets[ctx->enc_net], T + 1))) return rc;
+    if ((rc = ensure_train_state(ctx))) return rc;
+    if (!ctx->efpn_train) {
+      const size_t MBt = (size_t)c.max_batch * c.block_size;
+      if ((rc = dev_alloc(ctx, &ctx->efpn_train, MBt * ctx->efpn_h * ctx->efpn_w * C))) return rc;
+      if ((rc = dev_alloc(ctx, &ctx->tok_emb_train, MBt * C))) return rc;
+      if ((rc = dev_alloc(ctx, &ctx->d_tok_emb, MBt * C))) return rc;
+      if ((rc = dev_alloc(ctx, &ctx->dlogits, MBt * nA))) return rc;
+      if ((rc = dev_alloc(ctx, &ctx->de_ws, (size_t)c.max_batch * ctx->efpn_h * ctx->efpn_w * C))) return rc;
+    }
+  }
   for (int t = 0; t < T; ++t) {
     const int* flag = stop_early ? ctx->n_done + t : nullptr;
     if (!c.no_patch_emb) {
       if (ctx->profiling) JN_HIP(hipEventRecord(ctx->conv_ev[2 * t], s));
-      if ((rc = run_net(ctx, ctx->enc_net, B, ss, 0, 0, flag, B, s))) return rc;
+      if ((rc = run_net(ctx, ctx->enc_net, B, ss, train ? t + 1 : 0, train, flag, B, s))) return rc;
       if (ctx->profiling) { JN_HIP(hipEventRecord(ctx->conv_ev[2 * t + 1], s)); ctx->conv_ev_used = 2 * (t + 1); }
-      if ((rc = run_embed_fpn(ctx, B, 0, flag, B, s))) return rc;
+      if ((rc = run_embed_fpn(ctx, B, train ? t + 1 : 0, train ? ctx->efpn_train + (size_t)t * B * ctx->efpn_h * ctx->efpn_w * C : nullptr, flag, B, s))) return rc;
     }
     GptStepArgs a{};
     a.C = C; a.n_head = c.n_head; a.n_layer = c.n_layer; a.nA = nA; a.Tmax = c.block_size + 1; a.B = B; a.T = T;
@@ -1109,6 +1131,7 @@ int jn_rollout(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, const i
     a.src_mode = GPT_SRC_ENV; a.pos_index = 0; a.emb_stride = T + 1;
     a.env = ep; a.out = r; a.n_done = ctx->n_done;
     a.skip_flag = flag; a.skip_when = B;
+    a.tok_emb_out = train ? ctx->tok_emb_train : nullptr;
     launch_gpt_step(a, s);
     if (out->patches_dev)
       launch_gather(e.images, e.positions, out->patches_dev + (long long)(t + 1) * 3 * P * P, patch_stride, B, 3, e.H, e.W,
@@ -1119,6 +1142,159 @@ int jn_rollout(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, const i
   if (ctx->ev[1]) JN_HIP(hipEventRecord(ctx->ev[1], s));
   JN_HIP(hipGetLastError());
   ctx->last_T = T;
+  return JN_OK;
+}
+
+int jn_rollout(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, const int64_t* start_positions_dev,
+               uint64_t seed, int do_detection, int stop_early, const jn_rollout_out* out, void* stream) {
+  return rollout_impl(ctx, mode, forced_actions_dev, start_positions_dev, seed, do_detection, stop_early, out, 0, stream);
+}
+
+int jn_rollout_steps(jn_ctx* ctx, int* n_steps, void* stream);
+
+// ---- REINFORCE iteration ------------------------------------------------------------------
+int jn_arena_info(jn_ctx* ctx, size_t* total_numel, size_t* optim_gpt_numel) {
+  JN_CHECK(ctx && ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
+  if (total_numel) *total_numel = ctx->arena_size;
+  if (optim_gpt_numel) *optim_gpt_numel = ctx->gpt_arena_end;
+  return JN_OK;
+}
+
+int jn_set_grad_arena(jn_ctx* ctx, float* grads_dev, size_t numel) {
+  JN_CHECK(ctx && grads_dev && ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
+  JN_CHECK(numel >= ctx->arena_size, JN_EINVAL, "gradient arena needs %zu floats, got %zu", ctx->arena_size, numel);
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  int rc = ensure_train_state(ctx);
+  if (rc) return rc;
+  ctx->grads = grads_dev;         // caller-owned (e.g. a torch tensor handed to RCCL all-reduce)
+  ctx->g_layers_dev = nullptr;    // gradient pointer table must be rebuilt
+  return JN_OK;
+}
+
+static int build_grad_layer_table(jn_ctx* ctx) {
+  if (ctx->g_layers_dev) return JN_OK;
+  const int nL = ctx->cfg.n_layer;
+  std::vector<GptLayerPtrs> gl(nL);
+  for (int l = 0; l < nL; ++l) {
+    const GptW::Layer& L = ctx->gpt.layers[l];
+    gl[l] = GptLayerPtrs{grad_of(ctx, L.ln1_w), grad_of(ctx, L.ln1_b), grad_of(ctx, L.qkv_wt), grad_of(ctx, L.qkv_b),
+                         grad_of(ctx, L.proj_wt), grad_of(ctx, L.proj_b), grad_of(ctx, L.ln2_w), grad_of(ctx, L.ln2_b),
+                         grad_of(ctx, L.fc_wt), grad_of(ctx, L.fc_b), grad_of(ctx, L.fc2_wt), grad_of(ctx, L.fc2_b)};
+  }
+  GptLayerPtrs* d = nullptr;
+  int rc = dev_alloc(ctx, &d, (size_t)nL);
+  if (rc) return rc;
+  JN_HIP(hipMemcpy(d, gl.data(), gl.size() * sizeof(GptLayerPtrs), hipMemcpyHostToDevice));
+  ctx->g_layers_dev = d;
+  return JN_OK;
+}
+
+int jn_reinforce_step(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, const int64_t* start_positions_dev,
+                      uint64_t seed, int stop_early, const jn_train_opts* opts, const jn_rollout_out* out,
+                      float* metrics_dev, void* stream) {
+  JN_CHECK(ctx && opts && out && metrics_dev, JN_EINVAL, "jn_reinforce_step: null argument");
+  JN_CHECK(opts->struct_size == (int)sizeof(jn_train_opts), JN_EINVAL, "jn_train_opts.struct_size mismatch");
+  JN_CHECK(out->logits_dev && out->actions_dev && out->returns_dev && out->logit_masks_dev && out->positions_dev &&
+               out->final_emb_dev && out->rewards_dev && out->masks_dev,
+           JN_EINVAL, "training needs logits/actions/returns/logit_masks/positions/final_emb/rewards/masks outputs");
+  JN_CHECK(!ctx->cfg.no_patch_emb, JN_ESTATE, "training without a patch encoder is not supported");
+  JN_CHECK(ctx->cfg.block_size <= 62, JN_EINVAL, "training supports block_size <= 62");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = rollout_impl(ctx, mode, forced_actions_dev, start_positions_dev, seed, 0, stop_early, out, 1, stream);
+  if (rc) return rc;
+  if ((rc = build_grad_layer_table(ctx))) return rc;
+  const jn_config& c = ctx->cfg;
+  const EnvState& e = ctx->env;
+  const int B = e.B, T = e.T, C = c.n_embd, nA = c.n_actions, P = c.patch_size;
+  int S = 0;
+  if ((rc = jn_rollout_steps(ctx, &S, stream))) return rc;      // the one host sync of the iteration
+
+  LossArgs la{};
+  la.logits = out->logits_dev; la.actions = out->actions_dev; la.returns = out->returns_dev; la.rewards = out->rewards_dev;
+  la.logit_masks = out->logit_masks_dev; la.n_done = ctx->n_done; la.dlogits = ctx->dlogits; la.metrics = metrics_dev;
+  la.B = B; la.T = T; la.nA = nA; la.stop_early = stop_early ? 1 : 0; la.reward_norm = opts->reward_norm;
+  la.ret_mean = opts->ret_mean; la.ret_std = opts->ret_std; la.entropy_weight = opts->entropy_weight;
+  la.scale = opts->loss_scale;
+  launch_reinforce_loss(la, s);
+
+  const int L = T + 1, nL = c.n_layer, nh = c.n_head;
+  const long long per_agent = (long long)(nL + 1) * L * C + (long long)nL * (11LL * L * C + (long long)nh * L * L) +
+                              12LL * L * C + (long long)nh * L * L + 4LL * C + 64;
+  if (!ctx->gpt_bwd_scratch || ctx->gpt_bwd_scratch_floats < (size_t)per_agent * c.max_batch) {
+    if ((rc = dev_alloc(ctx, &ctx->gpt_bwd_scratch, (size_t)per_agent * c.max_batch))) return rc;
+    ctx->gpt_bwd_scratch_floats = (size_t)per_agent * c.max_batch;
+  }
+  const GptW& g = ctx->gpt;
+  GptBwdArgs ba{};
+  ba.C = C; ba.n_head = nh; ba.n_layer = nL; ba.nA = nA; ba.B = B; ba.T = T; ba.stop_early = stop_early ? 1 : 0;
+  ba.use_pos_emb = c.use_pos_emb; ba.no_patch_emb = c.no_patch_emb; ba.concat_emb = c.concat_emb;
+  ba.dec_pos_enc = c.decoder_pos_encoding; ba.pe2_ch = (int)std::ceil(C / 4.0) * 2;
+  ba.n_done = ctx->n_done; ba.final_emb = out->final_emb_dev; ba.dlogits = ctx->dlogits; ba.actions = out->actions_dev;
+  ba.positions = out->positions_dev; ba.tok_emb = ctx->tok_emb_train; ba.d_tok_emb = ctx->d_tok_emb;
+  ba.wte = g.wte; ba.wpe = g.wpe; ba.proj_wt = g.proj_wt; ba.pos1d = g.pos1d; ba.pe2 = g.pos2d_col; ba.head_wt = g.head_wt;
+  ba.lnf_w = g.lnf_w; ba.lnf_b = g.lnf_b; ba.layers = ctx->layers_dev; ba.g_layers = ctx->g_layers_dev;
+  ba.g_wte = grad_of(ctx, g.wte); ba.g_wpe = g.wpe ? grad_of(ctx, g.wpe) : nullptr;
+  ba.g_embed_class = grad_of(ctx, g.embed_class);
+  ba.g_proj_wt = g.proj_wt ? grad_of(ctx, g.proj_wt) : nullptr; ba.g_proj_b = g.proj_b ? grad_of(ctx, g.proj_b) : nullptr;
+  ba.g_head_wt = grad_of(ctx, g.head_wt); ba.g_lnf_w = grad_of(ctx, g.lnf_w); ba.g_lnf_b = grad_of(ctx, g.lnf_b);
+  ba.scratch = ctx->gpt_bwd_scratch; ba.scratch_per_agent = per_agent;
+  launch_gpt_backward(ba, s);
+
+  // per executed glimpse step, newest first: embed_fpn backward, then the patch encoder
+  Net& net = ctx->nets[ctx->enc_net];
+  const int MB = c.max_batch, HW = ctx->efpn_h * ctx->efpn_w, K = HW * C;
+  const View& f2 = net.fpn[2];
+  const ChanTab ident{ctx->ident, ctx->ident + 2048, ctx->ident + 4096};
+  for (int t = S - 1; t >= 0; --t) {
+    const int slot = t + 1;
+    const float* e_t = ctx->efpn_train + (size_t)t * B * K;
+    launch_efpn_linear_bwd(e_t, g.efpn_lin_wt, ctx->d_tok_emb + (size_t)t * C, (long long)T * C, ctx->de_ws,
+                           grad_of(ctx, g.efpn_lin_wt), grad_of(ctx, g.efpn_lin_b), B, K, C, s);
+    float* g_f2 = net.gact + net.buf_off[f2.buf] * (size_t)MB + f2.coff;
+    ConvArgs a{};
+    a.in = ctx->de_ws; a.in_ld = C; a.itab = ident; a.w = g.efpn_w; a.bias = nullptr;
+    a.out = g_f2; a.out_ld = net.bufs[f2.buf].C;
+    a.N = B; a.H = f2.H; a.W = f2.W; a.OH = f2.H; a.OW = f2.W; a.cin = C; a.cout = f2.C; a.stride = 1; a.act = ACT_NONE;
+    a.accumulate = 0; a.w_transposed = 1;
+    launch_pw(a, s);
+    launch_pw_bwd_weight(ctx->de_ws, C, view_ptr(net, slot, MB, f2), net.bufs[f2.buf].C, view_tab(net, slot, f2),
+                         grad_of(ctx, g.efpn_w), (long long)B * HW, C, f2.C, s);
+    for (int i = 0; i < 2; ++i) {
+      const View& f = net.fpn[i];
+      JN_HIP(hipMemsetAsync(net.gact + net.buf_off[f.buf] * (size_t)MB + f.coff, 0,
+                            (size_t)B * f.H * f.W * f.C * sizeof(float), s));
+    }
+    StemSrc ss{e.images, out->positions_dev + 2 * t, 3LL * e.H * e.W, (long long)e.H * e.W, e.W};
+    ss.pos_stride = 2 * (T + 1);
+    if ((rc = run_net_backward(ctx, ctx->enc_net, B, ss, slot, s))) return rc;
+  }
+  (void)P;
+  JN_HIP(hipGetLastError());
+  return JN_OK;
+}
+
+int jn_optimizer_step(jn_ctx* ctx, float lr, float weight_decay, float clip_value, float grad_scale, void* stream) {
+  JN_CHECK(ctx && ctx->grads, JN_ESTATE, "no gradients: run jn_reinforce_step first");
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  ctx->adam_step += 1;
+  launch_adamw(ctx->params, ctx->grads, ctx->adam_m, ctx->adam_v, (long long)ctx->gpt_arena_end, lr, 0.9f, 0.999f, 1e-8f,
+               weight_decay, ctx->adam_step, clip_value, grad_scale, (hipStream_t)stream);
+  JN_HIP(hipGetLastError());
+  return JN_OK;
+}
+
+int jn_read_param(jn_ctx* ctx, const char* name, float* host_out, size_t numel) {
+  JN_CHECK(ctx && name && host_out && ctx->params, JN_EINVAL, "jn_read_param: bad argument");
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  auto it = ctx->seg_index.find(name);
+  JN_CHECK(it != ctx->seg_index.end(), JN_ENOTFOUND, "jn_read_param: '%s' is not a trainable tensor", name);
+  const ParamSeg& sg = ctx->segs[it->second];
+  JN_CHECK(sg.numel == numel, JN_EINVAL, "'%s' has %zu elements, not %zu", name, sg.numel, numel);
+  std::vector<float> packed(numel);
+  JN_HIP(hipDeviceSynchronize());
+  JN_HIP(hipMemcpy(packed.data(), ctx->params + sg.off, numel * sizeof(float), hipMemcpyDeviceToHost));
+  const std::vector<float> t = unpack_param(sg, packed);
+  std::memcpy(host_out, t.data(), numel * sizeof(float));
   return JN_OK;
 }
 

@@ -153,7 +153,15 @@ struct jn_ctx {
   const std::vector<jnr::ParamEntry>& params_table() const { return params_tab; }
   // flat trainable-parameter arena + gradient / AdamW mirrors
   float* params = nullptr; float* grads = nullptr; float* adam_m = nullptr; float* adam_v = nullptr;
-  size_t arena_size = 0, arena_used = 0;
+  size_t arena_size = 0, arena_used = 0, gpt_arena_end = 0;   // [0, gpt_arena_end) = optim_gpt parameters
+  int adam_step = 0;
+  jnr::GptLayerPtrs* g_layers_dev = nullptr;
+  float* efpn_train = nullptr;    // [T][B][h*w*C] embed_fpn.0 activations of every glimpse step
+  float* tok_emb_train = nullptr; // [B][T][C] patch embeddings of every glimpse step
+  float* d_tok_emb = nullptr;     // [B][T][C] their gradients
+  float* dlogits = nullptr;       // [B][T][nA]
+  float* de_ws = nullptr;         // [B][h*w*C] gradient of embed_fpn.0 activations (one step)
+  float* gpt_bwd_scratch = nullptr; size_t gpt_bwd_scratch_floats = 0;
   std::vector<jnr::ParamSeg> segs;
   std::map<std::string, int> seg_index;
   jnr::Net nets[2];                // [JN_NET_GPT_BACKBONE], [JN_NET_DETECTOR]

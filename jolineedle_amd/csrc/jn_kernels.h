@@ -19,7 +19,7 @@ struct ChanTab {
 };
 
 struct StemArgs {
-  const float* src; const int64_t* positions;
+  const float* src; const int64_t* positions; int pos_stride;   // positions[pos_stride * n + {0,1}] = (y, x)
   long long sample_stride, chan_stride; int row_stride;
   int P, N, cout;
   const float* w; float* out; int out_ld;
@@ -106,7 +106,7 @@ int launch_rollout_epilogue(const RolloutBuffers& r, const int32_t* n_done, int 
 
 // ---- decision transformer step (kernels_gpt.hip) -------------------------------------
 struct GptLayerPtrs {
-  const float *ln1_w, *ln1_b, *qkv_wt, *qkv_b, *proj_wt, *proj_b, *ln2_w, *ln2_b, *fc_wt, *fc_b, *fc2_wt, *fc2_b;
+  float *ln1_w, *ln1_b, *qkv_wt, *qkv_b, *proj_wt, *proj_b, *ln2_w, *ln2_b, *fc_wt, *fc_b, *fc2_wt, *fc2_b;
 };
 
 enum { GPT_SRC_ENV = 0, GPT_SRC_TEACH = 1, GPT_SRC_GIVEN = 2, GPT_SRC_CLASS = 3 };
@@ -134,8 +134,42 @@ struct GptStepArgs {
   EnvPtrs env;
   RolloutBuffers out;
   int32_t* n_done;                  // [T+1]
+  float* tok_emb_out;               // [B][T][C] finished patch embedding of this step (training) or null
   const int* skip_flag; int skip_when;
 };
 int launch_gpt_step(const GptStepArgs& a, hipStream_t s);
+
+// ---- training of the decision side (kernels_train.hip) ------------------------------------
+struct LossArgs {
+  const float* logits; const int64_t* actions; const float* returns; const float* rewards;
+  const uint8_t* logit_masks; const int32_t* n_done;
+  float* dlogits;                   // [B][T][nA]
+  float* metrics;                   // [8]: action_loss, entropy_loss, loss, returns, episode_length, S
+  int B, T, nA, stop_early, reward_norm;
+  float ret_mean, ret_std, entropy_weight, scale;
+};
+int launch_reinforce_loss(const LossArgs& a, hipStream_t s);
+
+struct GptBwdArgs {
+  int C, n_head, n_layer, nA, B, T, stop_early;
+  int use_pos_emb, no_patch_emb, concat_emb, dec_pos_enc, pe2_ch;
+  const int32_t* n_done;
+  const float* final_emb;           // [B][T+1][C]
+  const float* dlogits;             // [B][T][nA]
+  const int64_t* actions;           // [B][T]
+  const int64_t* positions;         // [B][T+1][2]
+  const float* tok_emb;             // [B][T][C] patch embeddings
+  float* d_tok_emb;                 // [B][T][C] out
+  const float *wte, *wpe, *proj_wt, *pos1d, *pe2, *head_wt, *lnf_w, *lnf_b;
+  const GptLayerPtrs* layers;       // weights
+  const GptLayerPtrs* g_layers;     // gradients (same layout, non-const use)
+  float *g_wte, *g_wpe, *g_embed_class, *g_proj_wt, *g_proj_b, *g_head_wt, *g_lnf_w, *g_lnf_b;
+  float* scratch; long long scratch_per_agent;
+};
+int launch_gpt_backward(const GptBwdArgs& a, hipStream_t s);
+int launch_efpn_linear_bwd(const float* e, const float* wt, const float* dpe, long long dpe_stride, float* de,
+                           float* gwt, float* gb, int N, int K, int Co, hipStream_t s);
+int launch_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                 float eps, float wd, int step, float clip, float grad_scale, hipStream_t s);
 
 }  // namespace jnr

@@ -339,8 +339,8 @@ int launch_dw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, Ch
 constexpr int SB_TY = 8, SB_TX = 32, SB_IH = 2 * SB_TY + 4, SB_IW = 2 * SB_TX + 4;
 
 __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
-    const float* __restrict__ src, const long long* __restrict__ pos, long long sample_stride, long long chan_stride,
-    int row_stride, int P, const float* __restrict__ gz, int g_ld, int cout, int ocg, float* __restrict__ gw) {
+    const float* __restrict__ src, const long long* __restrict__ pos, int pos_stride, long long sample_stride,
+    long long chan_stride, int row_stride, int P, const float* __restrict__ gz, int g_ld, int cout, int ocg, float* __restrict__ gw) {
   __shared__ __attribute__((aligned(16))) float tile[3 * SB_IH * SB_IW];
   __shared__ float Gz[SB_TY * SB_TX * 16];
   __shared__ float Ts[16 * 112];
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
   const int OH = P / 2;
   const int oy0 = blockIdx.y * SB_TY, ox0 = blockIdx.x * SB_TX;
   const float* base = src + (long long)n * sample_stride;
-  if (pos) base += pos[2 * n] * (long long)P * row_stride + pos[2 * n + 1] * (long long)P;
+  if (pos) base += pos[(long long)pos_stride * n] * (long long)P * row_stride + pos[(long long)pos_stride * n + 1] * (long long)P;
   for (int i = tid; i < 3 * SB_IH * SB_IW; i += 256) {
     const int c = i / (SB_IH * SB_IW), r = (i / SB_IW) % SB_IH, q = i % SB_IW;
     const int iy = 2 * oy0 - 2 + r, ix = 2 * ox0 - 2 + q;
@@ -400,8 +400,8 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
 int launch_stem_bwd_weight(const StemArgs& a, const float* gz, int g_ld, float* gw, hipStream_t s) {
   const int OH = a.P / 2, ocg = a.cout / 16;
   dim3 grid((OH + SB_TX - 1) / SB_TX, (OH + SB_TY - 1) / SB_TY, a.N * ocg);
-  hipLaunchKernelGGL(stem_bwd_weight_kernel, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.sample_stride,
-                     a.chan_stride, a.row_stride, a.P, gz, g_ld, a.cout, ocg, gw);
+  hipLaunchKernelGGL(stem_bwd_weight_kernel, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.pos_stride,
+                     a.sample_stride, a.chan_stride, a.row_stride, a.P, gz, g_ld, a.cout, ocg, gw);
   return 0;
 }
 

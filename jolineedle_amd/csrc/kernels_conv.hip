@@ -87,7 +87,7 @@ constexpr int ST_IH = 2 * ST_TY + 4, ST_IW = 2 * ST_TX + 4;   // 36 x 68
 constexpr int ST_KS = 27;                                     // 108 / 4 k-steps
 
 __global__ __launch_bounds__(256) void stem_mfma_kernel(
-    const float* __restrict__ src, const long long* __restrict__ pos, long long sample_stride,
+    const float* __restrict__ src, const long long* __restrict__ pos, int pos_stride, long long sample_stride,
     long long chan_stride, int row_stride, int P, const float* __restrict__ w, float* __restrict__ out,
     int out_ld, int cout, int ocg, double* __restrict__ stats, const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(
   const int OH = P / 2;
   const int oy0 = blockIdx.y * ST_TY, ox0 = blockIdx.x * ST_TX;
   const float* base = src + (long long)n * sample_stride;
-  if (pos) base += pos[2 * n] * (long long)P * row_stride + pos[2 * n + 1] * (long long)P;
+  if (pos) base += pos[(long long)pos_stride * n] * (long long)P * row_stride + pos[(long long)pos_stride * n + 1] * (long long)P;
   if (tid < 32) red[tid] = 0.0f;
   for (int i = tid; i < 3 * ST_IH * ST_IW; i += 256) {
     const int c = i / (ST_IH * ST_IW), r = (i / ST_IW) % ST_IH, q = i % ST_IW;
@@ -150,8 +150,8 @@ int launch_stem(const StemArgs& a, hipStream_t s) {
   const int OH = a.P / 2;
   const int ocg = a.cout / 16;
   dim3 grid((OH + ST_TX - 1) / ST_TX, (OH + ST_TY - 1) / ST_TY, a.N * ocg);
-  hipLaunchKernelGGL(stem_mfma_kernel, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.sample_stride,
-                     a.chan_stride, a.row_stride, a.P, a.w, a.out, a.out_ld, a.cout, ocg, a.stats, a.skip_flag,
+  hipLaunchKernelGGL(stem_mfma_kernel, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.pos_stride,
+                     a.sample_stride, a.chan_stride, a.row_stride, a.P, a.w, a.out, a.out_ld, a.cout, ocg, a.stats, a.skip_flag,
                      a.skip_when);
   return 0;
 }

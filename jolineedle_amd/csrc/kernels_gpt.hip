@@ -112,6 +112,7 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
             float s = a.efpn_lin_b[i];
             for (int ks = 0; ks < a.KS; ++ks) s += a.emb_part[((long long)b * a.KS + ks) * C + i];
             parts[p * C + i] = s;
+            if (a.tok_emb_out) a.tok_emb_out[((long long)b * a.T + t) * C + i] = s;
           }
         } else {
           const float* pe = a.tok_emb + ((long long)b * a.tok_emb_stride + a.tok_emb_index) * C;

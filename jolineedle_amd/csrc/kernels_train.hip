@@ -1,0 +1,528 @@
+// Training kernels of the decision side: REINFORCE loss gradient, teacher-forced backward of
+// the GPT blocks over each agent's whole trajectory, token-embedding / embed_fpn backward,
+// and the fused clip + AdamW update over the flat parameter arena.
+//
+// The reference back-propagates through T growing prefixes (src/reinforce.py:150-153, 341);
+// with a causal mask and dropout 0 that is one causal pass over the T+1 token embeddings of
+// each agent, which is what gpt_backward_kernel recomputes and differentiates.
+#include <hip/hip_runtime.h>
+
+#include "jn_kernels.h"
+
+namespace jnr {
+
+constexpr int TB = 256;
+
+// ---- REINFORCE loss (src/reinforce.py:217-265) and d loss / d logits --------------------------
+// loss = -sum(logp*adv*m)/sum(m) + w * (-sum(H*m)/sum(m)),  adv = (returns - mean)/(std + 1e-8)
+// dlogits[b,t,j] = scale * m/sum(m) * ( -adv*(1[j==a] - p_j) + w * p_j*(log p_j + H) )
+__global__ __launch_bounds__(TB) void reinforce_loss_kernel(LossArgs a) {
+  __shared__ float red[TB];
+  __shared__ float tot[4];
+  const int tid = threadIdx.x;
+  int S = a.T;
+  if (a.stop_early)
+    for (int t = 1; t <= a.T; ++t)
+      if (a.n_done[t] >= a.B) { S = t; break; }
+  float cnt = 0.0f;
+  for (int i = tid; i < a.B * S; i += TB) {
+    const int b = i / S, t = i - b * S;
+    cnt += a.logit_masks[(long long)b * a.T + t] ? 1.0f : 0.0f;
+  }
+  red[tid] = cnt;
+  __syncthreads();
+  for (int o = TB / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  const float msum = red[0];
+  __syncthreads();
+  float la = 0.0f, le = 0.0f, lr = 0.0f;
+  for (int i = tid; i < a.B * a.T; i += TB) {
+    const int b = i / a.T, t = i - b * a.T;
+    float* dl = a.dlogits + (long long)i * a.nA;
+    const bool m = t < S && a.logit_masks[i];
+    if (!m) { for (int j = 0; j < a.nA; ++j) dl[j] = 0.0f; continue; }
+    const float* lg = a.logits + (long long)i * a.nA;
+    float mx = -INFINITY;
+    for (int j = 0; j < a.nA; ++j) mx = fmaxf(mx, lg[j]);
+    float se = 0.0f;
+    for (int j = 0; j < a.nA; ++j) se += expf(lg[j] - mx);
+    const float lse = mx + logf(se);
+    float H = 0.0f;
+    for (int j = 0; j < a.nA; ++j) { const float lp = lg[j] - lse; H -= lp * expf(lp); }
+    const int act = (int)a.actions[i];
+    const float adv = a.reward_norm ? (a.returns[i] - a.ret_mean) / (a.ret_std + 1e-8f) : a.returns[i];
+    const float k = a.scale / msum;
+    for (int j = 0; j < a.nA; ++j) {
+      const float lp = lg[j] - lse, p = expf(lp);
+      dl[j] = k * (-adv * ((j == act ? 1.0f : 0.0f) - p) + a.entropy_weight * p * (lp + H));
+    }
+    la -= (lg[act] - lse) * adv;
+    le -= H;
+    lr += a.rewards[i];
+  }
+  red[tid] = la; __syncthreads();
+  for (int o = TB / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  if (tid == 0) tot[0] = red[0];
+  __syncthreads();
+  red[tid] = le; __syncthreads();
+  for (int o = TB / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  if (tid == 0) tot[1] = red[0];
+  __syncthreads();
+  red[tid] = lr; __syncthreads();
+  for (int o = TB / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  if (tid == 0) {
+    a.metrics[0] = tot[0] / msum;                                  // action_loss
+    a.metrics[1] = tot[1] / msum;                                  // entropy_loss
+    a.metrics[2] = a.metrics[0] + a.entropy_weight * a.metrics[1]; // loss
+    a.metrics[3] = red[0] / a.B;                                   // returns (mean masked reward sum)
+    a.metrics[4] = msum / a.B;                                     // episode_length
+    a.metrics[5] = (float)S;
+  }
+}
+
+int launch_reinforce_loss(const LossArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(reinforce_loss_kernel, dim3(1), dim3(TB), 0, s, a);
+  return 0;
+}
+
+// ---- helpers on per-agent global scratch (all threads of the block, barrier at the end) --------
+__device__ __forceinline__ void lin_fwd(float* out, const float* in, const float* __restrict__ wt,
+                                        const float* __restrict__ b, int L, int K, int N) {
+  for (int e = threadIdx.x; e < L * N; e += TB) {
+    const int i = e / N, n = e - i * N;
+    float acc = b ? b[n] : 0.0f;
+    const float* ip = in + i * K;
+    for (int k = 0; k < K; ++k) acc = fmaf(ip[k], wt[(long long)k * N + n], acc);
+    out[e] = acc;
+  }
+  __syncthreads();
+}
+// din[i][k] = sum_n dout[i][n] * wt[k][n]
+__device__ __forceinline__ void lin_bwd_data(float* din, const float* dout, const float* __restrict__ wt, int L, int K,
+                                             int N, bool accumulate) {
+  for (int e = threadIdx.x; e < L * K; e += TB) {
+    const int i = e / K, k = e - i * K;
+    float acc = 0.0f;
+    const float* dp = dout + i * N;
+    const float* wp = wt + (long long)k * N;
+    for (int n = 0; n < N; ++n) acc = fmaf(dp[n], wp[n], acc);
+    din[e] = accumulate ? din[e] + acc : acc;
+  }
+  __syncthreads();
+}
+// gwt[k][n] += sum_i in[i][k] * dout[i][n];  gb[n] += sum_i dout[i][n]
+__device__ __forceinline__ void lin_bwd_weight(float* __restrict__ gwt, float* __restrict__ gb, const float* in,
+                                               const float* dout, int L, int K, int N, int i0) {
+  for (int e = threadIdx.x; e < K * N; e += TB) {
+    const int k = e / N, n = e - k * N;
+    float acc = 0.0f;
+    for (int i = i0; i < L; ++i) acc = fmaf(in[i * K + k], dout[i * N + n], acc);
+    atomicAdd(&gwt[e], acc);
+  }
+  if (gb)
+    for (int n = threadIdx.x; n < N; n += TB) {
+      float acc = 0.0f;
+      for (int i = i0; i < L; ++i) acc += dout[i * N + n];
+      atomicAdd(&gb[n], acc);
+    }
+  __syncthreads();
+}
+__device__ __forceinline__ void ln_fwd(float* out, const float* in, const float* __restrict__ w,
+                                       const float* __restrict__ b, float* mu, float* rs, int L, int C) {
+  for (int i = threadIdx.x; i < L; i += TB) {
+    const float* x = in + i * C;
+    float m = 0.0f;
+    for (int c = 0; c < C; ++c) m += x[c];
+    m /= C;
+    float v = 0.0f;
+    for (int c = 0; c < C; ++c) { const float d = x[c] - m; v += d * d; }
+    mu[i] = m;
+    rs[i] = 1.0f / sqrtf(v / C + 1e-5f);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < L * C; e += TB) {
+    const int i = e / C, c = e - i * C;
+    out[e] = (in[e] - mu[i]) * rs[i] * w[c] + b[c];
+  }
+  __syncthreads();
+}
+// din (+)= LN^T(dout);  gw += sum dout*xhat, gb += sum dout
+__device__ __forceinline__ void ln_bwd(float* din, const float* dout, const float* in, const float* __restrict__ w,
+                                       float* __restrict__ gw, float* __restrict__ gb, const float* mu, const float* rs,
+                                       int L, int C, bool accumulate, int i0) {
+  for (int c = threadIdx.x; c < C; c += TB) {
+    float a = 0.0f, b = 0.0f;
+    for (int i = i0; i < L; ++i) { const float d = dout[i * C + c]; a += d * (in[i * C + c] - mu[i]) * rs[i]; b += d; }
+    atomicAdd(&gw[c], a);
+    atomicAdd(&gb[c], b);
+  }
+  for (int i = threadIdx.x; i < L; i += TB) {
+    const float* x = in + i * C;
+    const float* d = dout + i * C;
+    float m1 = 0.0f, m2 = 0.0f;
+    for (int c = 0; c < C; ++c) { const float dx = d[c] * w[c]; m1 += dx; m2 += dx * (x[c] - mu[i]) * rs[i]; }
+    m1 /= C; m2 /= C;
+    for (int c = 0; c < C; ++c) {
+      const float xh = (x[c] - mu[i]) * rs[i];
+      const float v = rs[i] * (d[c] * w[c] - m1 - xh * m2);
+      din[i * C + c] = accumulate ? din[i * C + c] + v : v;
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float gelu_f(float x) {
+  return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+__device__ __forceinline__ float gelu_d(float x) {
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  const float th = tanhf(u);
+  return 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+}
+
+// ---- GPT backward, one workgroup per agent ------------------------------------------------------
+__global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
+  __shared__ float mu[64], rs[64];
+  __shared__ int s_S;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int C = a.C, nh = a.n_head, hs = C / nh, nL = a.n_layer;
+  if (tid == 0) {
+    int S = a.T;
+    if (a.stop_early)
+      for (int t = 1; t <= a.T; ++t)
+        if (a.n_done[t] >= a.B) { S = t; break; }
+    s_S = S;
+  }
+  __syncthreads();
+  const int S = s_S, L = S + 1;
+  const float scale = 1.0f / sqrtf((float)hs);
+  float* sc = a.scratch + (long long)b * a.scratch_per_agent;
+  float* X = sc;                                   // [(nL+1)][L][C]
+  float* lay = X + (nL + 1) * L * C;               // per layer block
+  const int lay_sz = L * 11 * C + nh * L * L;
+  float* tmp = lay + nL * lay_sz;                  // backward temporaries
+  float* dX = tmp;                 // [L][C]
+  float* dXM = dX + L * C;         // [L][C]
+  float* dH = dXM + L * C;         // [L][C]
+  float* dQKV = dH + L * C;        // [L][3C]
+  float* dF = dQKV + L * 3 * C;    // [L][4C]
+  float* dY = dF + L * 4 * C;      // [L][C]
+  float* dP = dY + L * C;          // [nh][L][L]
+  float* HF = dP + nh * L * L;     // [L][C]   ln_f output
+  float* PARTS = HF + L * C;       // [4C]
+
+  // ---------------- forward recompute ----------------
+  for (int e = tid; e < L * C; e += TB) X[e] = a.final_emb[((long long)b * (a.T + 1)) * C + e];
+  __syncthreads();
+  for (int l = 0; l < nL; ++l) {
+    const GptLayerPtrs W = a.layers[l];
+    float* x = X + l * L * C;
+    float* H1 = lay + l * lay_sz;
+    float* QKV = H1 + L * C;
+    float* ATT = QKV + L * 3 * C;
+    float* Y = ATT + nh * L * L;
+    float* XM = Y + L * C;
+    float* H2 = XM + L * C;
+    float* Fp = H2 + L * C;         // [L][4C] pre-activation
+    ln_fwd(H1, x, W.ln1_w, W.ln1_b, mu, rs, L, C);
+    lin_fwd(QKV, H1, W.qkv_wt, W.qkv_b, L, C, 3 * C);
+    for (int e = tid; e < nh * L * L; e += TB) {
+      const int h = e / (L * L), i = (e / L) % L, j = e % L;
+      float d = -INFINITY;
+      if (j <= i) {
+        d = 0.0f;
+        for (int q = 0; q < hs; ++q) d = fmaf(QKV[i * 3 * C + h * hs + q], QKV[j * 3 * C + C + h * hs + q], d);
+        d *= scale;
+      }
+      ATT[e] = d;
+    }
+    __syncthreads();
+    for (int e = tid; e < nh * L; e += TB) {
+      float* row = ATT + e * L;
+      const int i = e % L;
+      float m = -INFINITY;
+      for (int j = 0; j <= i; ++j) m = fmaxf(m, row[j]);
+      float s = 0.0f;
+      for (int j = 0; j <= i; ++j) { row[j] = expf(row[j] - m); s += row[j]; }
+      for (int j = 0; j < L; ++j) row[j] = j <= i ? row[j] / s : 0.0f;
+    }
+    __syncthreads();
+    for (int e = tid; e < L * C; e += TB) {
+      const int i = e / C, c = e - i * C, h = c / hs;
+      float acc = 0.0f;
+      for (int j = 0; j <= i; ++j) acc = fmaf(ATT[(h * L + i) * L + j], QKV[j * 3 * C + 2 * C + c], acc);
+      Y[e] = acc;
+    }
+    __syncthreads();
+    lin_fwd(XM, Y, W.proj_wt, W.proj_b, L, C, C);
+    for (int e = tid; e < L * C; e += TB) XM[e] += x[e];
+    __syncthreads();
+    ln_fwd(H2, XM, W.ln2_w, W.ln2_b, mu, rs, L, C);
+    lin_fwd(Fp, H2, W.fc_wt, W.fc_b, L, C, 4 * C);
+    float* xo = X + (l + 1) * L * C;
+    // mlp out: needs gelu(F); use dF as a temporary activation buffer
+    for (int e = tid; e < L * 4 * C; e += TB) dF[e] = gelu_f(Fp[e]);
+    __syncthreads();
+    lin_fwd(xo, dF, W.fc2_wt, W.fc2_b, L, 4 * C, C);
+    for (int e = tid; e < L * C; e += TB) xo[e] += XM[e];
+    __syncthreads();
+  }
+  float* xl = X + nL * L * C;
+  ln_fwd(HF, xl, a.lnf_w, a.lnf_b, mu, rs, L, C);
+
+  // ---------------- head + ln_f backward ----------------
+  // dHF[i][c] = sum_a dlogits[b][i-1][a] * head_wt[c][a]   (token 0 has no logits)
+  for (int e = tid; e < L * C; e += TB) {
+    const int i = e / C, c = e - i * C;
+    float acc = 0.0f;
+    if (i >= 1) {
+      const float* dl = a.dlogits + ((long long)b * a.T + (i - 1)) * a.nA;
+      for (int q = 0; q < a.nA; ++q) acc = fmaf(dl[q], a.head_wt[c * a.nA + q], acc);
+    }
+    dH[e] = acc;
+  }
+  for (int e = tid; e < C * a.nA; e += TB) {
+    const int c = e / a.nA, q = e - c * a.nA;
+    float acc = 0.0f;
+    for (int i = 1; i < L; ++i) acc = fmaf(HF[i * C + c], a.dlogits[((long long)b * a.T + (i - 1)) * a.nA + q], acc);
+    atomicAdd(&a.g_head_wt[e], acc);
+  }
+  __syncthreads();
+  ln_bwd(dX, dH, xl, a.lnf_w, a.g_lnf_w, a.g_lnf_b, mu, rs, L, C, false, 0);
+
+  // ---------------- blocks, last to first ----------------
+  for (int l = nL - 1; l >= 0; --l) {
+    const GptLayerPtrs W = a.layers[l];
+    const GptLayerPtrs G = a.g_layers[l];
+    float* x = X + l * L * C;
+    float* H1 = lay + l * lay_sz;
+    float* QKV = H1 + L * C;
+    float* ATT = QKV + L * 3 * C;
+    float* Y = ATT + nh * L * L;
+    float* XM = Y + L * C;
+    float* H2 = XM + L * C;
+    float* Fp = H2 + L * C;
+    // mlp: xo = XM + fc2(gelu(fc(H2)))
+    lin_bwd_data(dF, dX, W.fc2_wt, L, 4 * C, C, false);                     // dA
+    // weight grad of fc2 needs gelu(F): recompute into dQKV/dY-sized temp is too small -> use dP? no: reuse Y? keep simple:
+    for (int e = tid; e < 4 * C * C; e += TB) {
+      const int k = e / C, c = e - k * C;
+      float acc = 0.0f;
+      for (int i = 0; i < L; ++i) acc = fmaf(gelu_f(Fp[i * 4 * C + k]), dX[i * C + c], acc);
+      atomicAdd(&G.fc2_wt[e], acc);
+    }
+    for (int c = tid; c < C; c += TB) {
+      float acc = 0.0f;
+      for (int i = 0; i < L; ++i) acc += dX[i * C + c];
+      atomicAdd(&G.fc2_b[c], acc);
+    }
+    for (int e = tid; e < L * 4 * C; e += TB) dF[e] *= gelu_d(Fp[e]);
+    __syncthreads();
+    lin_bwd_data(dH, dF, W.fc_wt, L, C, 4 * C, false);
+    lin_bwd_weight(G.fc_wt, G.fc_b, H2, dF, L, C, 4 * C, 0);
+    // ln2 statistics of XM
+    for (int i = tid; i < L; i += TB) {
+      const float* xx = XM + i * C;
+      float m = 0.0f;
+      for (int c = 0; c < C; ++c) m += xx[c];
+      m /= C;
+      float v = 0.0f;
+      for (int c = 0; c < C; ++c) { const float d = xx[c] - m; v += d * d; }
+      mu[i] = m; rs[i] = 1.0f / sqrtf(v / C + 1e-5f);
+    }
+    __syncthreads();
+    for (int e = tid; e < L * C; e += TB) dXM[e] = dX[e];
+    __syncthreads();
+    ln_bwd(dXM, dH, XM, W.ln2_w, G.ln2_w, G.ln2_b, mu, rs, L, C, true, 0);
+    // attention output projection: XM = x + proj(Y)
+    lin_bwd_data(dY, dXM, W.proj_wt, L, C, C, false);
+    lin_bwd_weight(G.proj_wt, G.proj_b, Y, dXM, L, C, C, 0);
+    // dP[h][i][j] = sum_d dY[i][h,d] * v[j][h,d]
+    for (int e = tid; e < nh * L * L; e += TB) {
+      const int h = e / (L * L), i = (e / L) % L, j = e % L;
+      float acc = 0.0f;
+      if (j <= i)
+        for (int q = 0; q < hs; ++q) acc = fmaf(dY[i * C + h * hs + q], QKV[j * 3 * C + 2 * C + h * hs + q], acc);
+      dP[e] = acc;
+    }
+    __syncthreads();
+    // dV[j][c] = sum_{i>=j} P[h][i][j] * dY[i][c]
+    for (int e = tid; e < L * C; e += TB) {
+      const int j = e / C, c = e - j * C, h = c / hs;
+      float acc = 0.0f;
+      for (int i = j; i < L; ++i) acc = fmaf(ATT[(h * L + i) * L + j], dY[i * C + c], acc);
+      dQKV[j * 3 * C + 2 * C + c] = acc;
+    }
+    // softmax backward in place: dS = P * (dP - sum_j P*dP)
+    for (int e = tid; e < nh * L; e += TB) {
+      float* dp = dP + e * L;
+      const float* pr = ATT + e * L;
+      const int i = e % L;
+      float dot = 0.0f;
+      for (int j = 0; j <= i; ++j) dot = fmaf(pr[j], dp[j], dot);
+      for (int j = 0; j < L; ++j) dp[j] = j <= i ? pr[j] * (dp[j] - dot) * scale : 0.0f;
+    }
+    __syncthreads();
+    for (int e = tid; e < L * C; e += TB) {
+      const int i = e / C, c = e - i * C, h = c / hs;
+      float dq = 0.0f, dk = 0.0f;
+      for (int j = 0; j <= i; ++j) dq = fmaf(dP[(h * L + i) * L + j], QKV[j * 3 * C + C + c], dq);
+      for (int ii = i; ii < L; ++ii) dk = fmaf(dP[(h * L + ii) * L + i], QKV[ii * 3 * C + c], dk);
+      dQKV[i * 3 * C + c] = dq;
+      dQKV[i * 3 * C + C + c] = dk;
+    }
+    __syncthreads();
+    lin_bwd_data(dH, dQKV, W.qkv_wt, L, C, 3 * C, false);
+    lin_bwd_weight(G.qkv_wt, G.qkv_b, H1, dQKV, L, C, 3 * C, 0);
+    for (int i = tid; i < L; i += TB) {
+      const float* xx = x + i * C;
+      float m = 0.0f;
+      for (int c = 0; c < C; ++c) m += xx[c];
+      m /= C;
+      float v = 0.0f;
+      for (int c = 0; c < C; ++c) { const float d = xx[c] - m; v += d * d; }
+      mu[i] = m; rs[i] = 1.0f / sqrtf(v / C + 1e-5f);
+    }
+    __syncthreads();
+    for (int e = tid; e < L * C; e += TB) dX[e] = dXM[e];
+    __syncthreads();
+    ln_bwd(dX, dH, x, W.ln1_w, G.ln1_w, G.ln1_b, mu, rs, L, C, true, 0);
+  }
+
+  // ---------------- token embeddings ----------------
+  for (int c = tid; c < C; c += TB) atomicAdd(&a.g_embed_class[c], dX[c]);          // class token id 0
+  for (int i = 1; i < L; ++i) {
+    const int t = i - 1;
+    const int act = (i == 1) ? 0 : (int)a.actions[(long long)b * a.T + (i - 2)];
+    const int row = (int)a.positions[((long long)b * (a.T + 1) + t) * 2];
+    const int col = (int)a.positions[((long long)b * (a.T + 1) + t) * 2 + 1];
+    int p = 0;
+    for (int c = tid; c < C; c += TB) PARTS[c] = a.wte[act * C + c];
+    ++p;
+    for (int c = tid; c < C; c += TB) PARTS[p * C + c] = a.dec_pos_enc ? a.pos1d[c] : a.wpe[c];
+    const int p_pos = p; ++p;
+    int p_patch = -1, p_pos2 = -1;
+    if (!a.no_patch_emb) {
+      p_patch = p;
+      for (int c = tid; c < C; c += TB) PARTS[p * C + c] = a.tok_emb[((long long)b * a.T + t) * C + c];
+      ++p;
+    }
+    if (a.use_pos_emb) {
+      p_pos2 = p;
+      for (int c = tid; c < C; c += TB)
+        PARTS[p * C + c] = (c < a.pe2_ch) ? a.pe2[col * a.pe2_ch + c] : a.pe2[row * a.pe2_ch + (c - a.pe2_ch)];
+      ++p;
+    }
+    __syncthreads();
+    const float* dx = dX + i * C;
+    float* dparts = dF;   // [p*C] scratch (dF holds >= 4C floats and is free now)
+    if (a.concat_emb) {
+      for (int k = tid; k < p * C; k += TB) {
+        float acc = 0.0f;
+        for (int c = 0; c < C; ++c) acc = fmaf(dx[c], a.proj_wt[(long long)k * C + c], acc);
+        dparts[k] = acc;
+      }
+      for (int e = tid; e < p * C * C; e += TB) atomicAdd(&a.g_proj_wt[e], PARTS[e / C] * dx[e % C]);
+      for (int c = tid; c < C; c += TB) atomicAdd(&a.g_proj_b[c], dx[c]);
+    } else {
+      for (int k = tid; k < p * C; k += TB) dparts[k] = dx[k % C] / p;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += TB) atomicAdd(&a.g_wte[act * C + c], dparts[c]);
+    if (!a.dec_pos_enc && a.g_wpe)
+      for (int c = tid; c < C; c += TB) atomicAdd(&a.g_wpe[c], dparts[p_pos * C + c]);
+    if (p_patch >= 0)
+      for (int c = tid; c < C; c += TB) a.d_tok_emb[((long long)b * a.T + t) * C + c] = dparts[p_patch * C + c];
+    (void)p_pos2;
+    __syncthreads();
+  }
+  // steps that were never executed get a zero patch-embedding gradient
+  for (int t = S; t < a.T; ++t)
+    for (int c = tid; c < C; c += TB) a.d_tok_emb[((long long)b * a.T + t) * C + c] = 0.0f;
+}
+
+int launch_gpt_backward(const GptBwdArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(gpt_backward_kernel, dim3(a.B), dim3(TB), 0, s, a);
+  return 0;
+}
+
+// ---- embed_fpn backward for one glimpse step ---------------------------------------------------
+// patch_emb[n][o] = b[o] + sum_k e[n][k] * Wt[k][o],  e = relu(conv1x1(a))   (k = hw*C + c)
+// de[n][k] = (e > 0) * sum_o dpe[n][o] * Wt[k][o];   gWt[k][o] += sum_n e[n][k]*dpe[n][o];  gb += sum_n dpe
+__global__ __launch_bounds__(TB) void efpn_linear_bwd_kernel(const float* __restrict__ e, const float* __restrict__ wt,
+                                                             const float* __restrict__ dpe, long long dpe_stride,
+                                                             float* __restrict__ de, float* __restrict__ gwt,
+                                                             float* __restrict__ gb, int N, int K, int Co) {
+  extern __shared__ float sd[];     // [N][Co] dpe
+  for (int i = threadIdx.x; i < N * Co; i += TB) sd[i] = dpe[(long long)(i / Co) * dpe_stride + (i % Co)];
+  __syncthreads();
+  const int k = blockIdx.x * TB + threadIdx.x;
+  if (blockIdx.x == 0)
+    for (int o = threadIdx.x; o < Co; o += TB) {
+      float acc = 0.0f;
+      for (int n = 0; n < N; ++n) acc += sd[n * Co + o];
+      gb[o] += acc;
+    }
+  if (k >= K) return;
+  float w[8];
+  for (int o0 = 0; o0 < Co; o0 += 8) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w[q] = (o0 + q < Co) ? wt[(long long)k * Co + o0 + q] : 0.0f;
+    float gacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int n = 0; n < N; ++n) {
+      const float ev = e[(long long)n * K + k];
+      float d = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (o0 + q < Co) {
+          const float dv = sd[n * Co + o0 + q];
+          d = fmaf(dv, w[q], d);
+          gacc[q] = fmaf(ev, dv, gacc[q]);
+        }
+      }
+      const float prev = o0 ? de[(long long)n * K + k] : 0.0f;
+      de[(long long)n * K + k] = prev + d;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (o0 + q < Co) gwt[(long long)k * Co + o0 + q] += gacc[q];
+  }
+  for (int n = 0; n < N; ++n)
+    if (e[(long long)n * K + k] <= 0.0f) de[(long long)n * K + k] = 0.0f;     // ReLU mask
+}
+
+int launch_efpn_linear_bwd(const float* e, const float* wt, const float* dpe, long long dpe_stride, float* de,
+                           float* gwt, float* gb, int N, int K, int Co, hipStream_t s) {
+  hipLaunchKernelGGL(efpn_linear_bwd_kernel, dim3((K + TB - 1) / TB), dim3(TB), (size_t)N * Co * sizeof(float), s, e, wt,
+                     dpe, dpe_stride, de, gwt, gb, N, K, Co);
+  return 0;
+}
+
+// ---- clip_grad_value_(1) + AdamW (src/reinforce.py:344-346; torch defaults betas .9/.999, eps 1e-8,
+// weight_decay .01) over the flat arena; grad_scale folds the 1/world_size of the all-reduce ----
+__global__ __launch_bounds__(TB) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long long n, float lr,
+                                                   float beta1, float beta2, float eps, float wd, float bc1, float bc2,
+                                                   float clip, float grad_scale) {
+  const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+  if (i >= n) return;
+  float gr = g[i] * grad_scale;
+  if (clip > 0.0f) gr = fminf(fmaxf(gr, -clip), clip);
+  float pv = p[i];
+  pv *= 1.0f - lr * wd;
+  const float mi = beta1 * m[i] + (1.0f - beta1) * gr;
+  const float vi = beta2 * v[i] + (1.0f - beta2) * gr * gr;
+  m[i] = mi; v[i] = vi;
+  const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+  pv -= (lr / bc1) * (mi / denom);
+  p[i] = pv;
+}
+
+int launch_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                 float eps, float wd, int step, float clip, float grad_scale, hipStream_t s) {
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + TB - 1) / TB)), dim3(TB), 0, s, p, g, m, v, n, lr, beta1, beta2,
+                     eps, wd, bc1, bc2, clip, grad_scale);
+  return 0;
+}
+
+}  // namespace jnr

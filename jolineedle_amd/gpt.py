@@ -232,6 +232,18 @@ class GPT(nn.Module):
         check(eng.lib.jn_backbone_backward(eng.handle, net, ptr(x), x.shape[0], ptr(gs[0]), ptr(gs[1]), ptr(gs[2]),
                                            _lib.current_stream(self.device)), "jn_backbone_backward")
 
+    def pull_parameters(self):
+        """Copy the engine's (optimiser-updated) parameters and BN statistics back into this module."""
+        eng = self._engine
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if name.startswith("yolox") or not p.requires_grad:
+                    continue
+                host = torch.empty(p.shape, dtype=torch.float32)
+                check(eng.lib.jn_read_param(eng.handle, name.encode(), host.data_ptr(), host.numel()), "jn_read_param")
+                p.copy_(host)
+        self.pull_bn_statistics()
+
     def engine_grads(self, prefix=""):
         """{state-dict name: gradient tensor (reference layout)} of the trainable tensors."""
         eng, out = self._engine, {}

@@ -7,7 +7,7 @@ from typing import Dict
 import torch
 
 from . import _lib
-from ._lib import JnRolloutOut, check, ptr
+from ._lib import JnRolloutOut, JnTrainOpts, check, ptr
 from .env import NeedleGeneralEnv
 
 
@@ -36,7 +36,7 @@ class ReinforceTrainer:
 
     @torch.no_grad()
     def _compute_last_returns_mean_std(self):
-        allv = torch.cat(self.last_return_values) if self.last_return_values else torch.zeros(0)
+        allv = torch.cat([v.float().cpu() for v in self.last_return_values]) if self.last_return_values else torch.zeros(0)
         if len(allv) == 0:
             mean, std = 0, 1
         elif len(allv) == 1:
@@ -100,6 +100,85 @@ class ReinforceTrainer:
             "final_emb": buf["final_emb"][:, :S + 1],
         }
         return res
+
+    # ---- training: one REINFORCE iteration (src/reinforce.py:302-353) ------------------------
+    def _grad_arena(self):
+        """Flat fp32 gradient buffer shared with the engine (torch-owned so that RCCL can
+        all-reduce it in ONE call per optimiser step)."""
+        if getattr(self, "_flat_grads", None) is None:
+            eng = self.model.engine()
+            tot, gpt = C.c_size_t(), C.c_size_t()
+            check(eng.lib.jn_arena_info(eng.handle, C.byref(tot), C.byref(gpt)), "jn_arena_info")
+            self._flat_grads = torch.zeros(tot.value, device=self.device, dtype=torch.float32)
+            self._optim_numel = gpt.value
+            check(eng.lib.jn_set_grad_arena(eng.handle, ptr(self._flat_grads), tot.value), "jn_set_grad_arena")
+        return self._flat_grads
+
+    def train_iteration(self, env: NeedleGeneralEnv, sample_actions: bool = True, forced_actions=None,
+                        start_positions=None, stop_early: bool = True, optimizer_step: bool = True,
+                        process_group=None) -> Dict[str, torch.Tensor]:
+        """rollout (train-mode BatchNorm) -> compute_metrics -> backward -> [all-reduce] -> clip + AdamW,
+        all inside the engine.  Returns the metrics of src/reinforce.py:243-252."""
+        model, dev = self.model, self.device
+        model.sync_weights()
+        eng = model.engine()
+        env.bind(eng)
+        grads = self._grad_arena()
+        B, T, P = env.batch_size, env.max_ep_len, env.patch_size
+        C_, nA = model.n_embd, eng.cfg.n_actions
+        f32 = dict(device=dev, dtype=torch.float32)
+        buf = {
+            "rewards": torch.empty((B, T), **f32), "returns": torch.empty((B, T), **f32),
+            "logprobs": torch.empty((B, T), **f32), "entropies": torch.empty((B, T), **f32),
+            "masks": torch.empty((B, T + 1), device=dev, dtype=torch.uint8),
+            "logit_masks": torch.empty((B, T), device=dev, dtype=torch.uint8),
+            "positions": torch.empty((B, T + 1, 2), device=dev, dtype=torch.int64),
+            "actions": torch.empty((B, T), device=dev, dtype=torch.int64),
+            "logits": torch.empty((B, T, nA), **f32),
+            "final_emb": torch.empty((B, T + 1, C_), **f32),
+        }
+        out = JnRolloutOut()
+        for k, t in buf.items():
+            setattr(out, k + "_dev", t.data_ptr())
+        if forced_actions is not None:
+            mode = _lib.JN_MODE_FORCED
+            forced_actions = forced_actions.to(dev, torch.int64).contiguous()
+        else:
+            mode = _lib.JN_MODE_SAMPLE if sample_actions else _lib.JN_MODE_GREEDY
+        if start_positions is not None:
+            start_positions = start_positions.to(dev, torch.int64).contiguous()
+        self._rollouts += 1
+        self.iter_num = getattr(self, "iter_num", 0) + 1
+        ga = int(getattr(self.config, "gradient_accumulation", 1))
+        opts = JnTrainOpts(struct_size=C.sizeof(JnTrainOpts), reward_norm=int(bool(self.config.reward_norm)),
+                           ret_mean=float(self.last_return_mean), ret_std=float(self.last_return_std),
+                           entropy_weight=float(self.entropy_weight), loss_scale=1.0 / ga)
+        metrics_dev = torch.zeros(8, **f32)
+        seed = (self.seed * 1000003 + self._rollouts) & 0xFFFFFFFFFFFFFFFF
+        stream = _lib.current_stream(dev)
+        check(eng.lib.jn_reinforce_step(eng.handle, mode, ptr(forced_actions), ptr(start_positions), seed,
+                                        int(stop_early), C.byref(opts), C.byref(out), ptr(metrics_dev), stream),
+              "jn_reinforce_step")
+        m = metrics_dev.cpu()
+        S = int(m[5])
+        if self.config.reward_norm:
+            lm = buf["logit_masks"][:, :S].bool()
+            self.last_return_values.append(buf["returns"][:, :S][lm].clone())
+        if optimizer_step and self.iter_num % ga == 0:
+            world = 1
+            if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+                import torch.distributed as dist
+                world = dist.get_world_size(process_group)
+                if world > 1:      # the ONE exchange step of the iteration: flat gradient all-reduce over xGMI
+                    dist.all_reduce(grads[:self._optim_numel], op=dist.ReduceOp.SUM, group=process_group)
+            lr = float(getattr(self.config, "learning_rate", 1e-4))
+            check(eng.lib.jn_optimizer_step(eng.handle, lr, 0.01, 1.0, 1.0 / world, stream), "jn_optimizer_step")
+            grads.zero_()
+            if self.config.reward_norm:
+                self._compute_last_returns_mean_std()
+        self._last_train_buffers = buf
+        return {"action_loss": m[0], "entropy_loss": m[1], "loss": m[2], "returns": m[3], "episode_length": m[4],
+                "steps": S}
 
     def compute_metrics(self, rollout: Dict[str, torch.Tensor], env: NeedleGeneralEnv = None):
         """src/reinforce.py:217-265."""

@@ -395,3 +395,87 @@ def test_full_size_c3_properties():
                 acts = torch.cat((torch.zeros(1, 1, dtype=torch.long), forced[b:b + 1, :t]), 1)
                 lg, e = oracle(pt, acts, torch.zeros(1, dtype=torch.long), ro["positions"][b:b + 1, :t + 1].cpu(), e)
                 assert (lg[0, -1] - ro["logits"][b, t].cpu()).abs().max() < 1e-3
+
+
+# --------------------------------------------------------------------------------------
+# training: one REINFORCE iteration (src/reinforce.py:302-353)
+# --------------------------------------------------------------------------------------
+def _oracle_reinforce_grads(oracle, images, bboxes, start, forced, P, Tn, stop, mean, std, ew):
+    from oracle import env_ref, rollout_ref
+    oracle.train()
+    oracle.zero_grad()
+    env = env_ref.EnvRef(images, bboxes, P, Tn, 1, stop)
+    ro = rollout_ref.rollout(oracle, env, forced_actions=forced, start_positions=start)
+    norm = rollout_ref.ReturnNormaliser()
+    norm.mean, norm.std = mean, std
+    m = rollout_ref.reinforce_metrics(ro, ew, norm)
+    m["loss"].backward()
+    return ro, m
+
+
+@pytest.mark.parametrize("stop,B,P,Tn", [(True, 3, 64, 4), (False, 2, 96, 3)])
+def test_reinforce_iteration_gradients_vs_oracle(stop, B, P, Tn):
+    """loss.backward() of a whole REINFORCE iteration (train-mode BN per glimpse step, T backbone
+    passes, causal GPT over the trajectory) against torch autograd on the CPU oracle."""
+    nA = 9 if stop else 8
+    product, oracle = make_pair(5, patch_size=P, block_size=Tn, nclasses=nA, with_detector=False, image_processor=None)
+    images, bboxes, start = synth_batch(B, 3, 4, P, seed=41)
+    forced = torch.randint(0, 8, (B, Tn), generator=torch.Generator().manual_seed(3))
+    ro, m = _oracle_reinforce_grads(oracle, images, bboxes, start, forced, P, Tn, stop, 0.25, 1.5, 0.01)
+    cfg = _cfg(T=Tn, stop=stop, learning_rate=1e-3, gradient_accumulation=1)
+    tr = ja.ReinforceTrainer(cfg, product)
+    tr.last_return_mean, tr.last_return_std = 0.25, 1.5
+    env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, stop)
+    got_m = tr.train_iteration(env, forced_actions=forced, start_positions=start, optimizer_step=False)
+    for k in ("action_loss", "entropy_loss", "loss", "returns", "episode_length"):
+        assert abs(float(got_m[k]) - float(m[k])) < 2e-4, (k, float(got_m[k]), float(m[k]))
+    grads = product.engine_grads()
+    checked = 0
+    for name, p in oracle.named_parameters():
+        if name.startswith("yolox") or p.grad is None or not p.requires_grad:
+            continue
+        gp, ref = grads[name], p.grad
+        scale = ref.abs().max().item()
+        if scale < 1e-12:
+            assert gp.abs().max().item() < 1e-9, name
+            continue
+        err = (gp - ref).abs().max().item() / scale
+        assert err < 5e-3, (name, err, scale)
+        checked += 1
+    assert checked > 150
+    # running statistics moved Tn times, as in the reference's train-mode rollout
+    product.pull_bn_statistics()
+    k = "gpt_backbone.backbone.dark2.0.pconv.bn.running_mean"
+    assert torch.allclose(product.state_dict()[k], oracle.state_dict()[k], atol=1e-5, rtol=1e-3)
+
+
+def test_optimizer_step_matches_adamw_with_clip():
+    P, Tn, B = 64, 3, 2
+    product, oracle = make_pair(5, patch_size=P, block_size=Tn, with_detector=False, image_processor=None)
+    images, bboxes, start = synth_batch(B, 3, 4, P, seed=43)
+    forced = torch.randint(0, 8, (B, Tn), generator=torch.Generator().manual_seed(5))
+    _oracle_reinforce_grads(oracle, images, bboxes, start, forced, P, Tn, True, 0.0, 1.0, 0.01)
+    params = [p for n, p in oracle.named_parameters() if not n.startswith("yolox")]
+    before = {n: p.detach().clone() for n, p in oracle.named_parameters()}
+    ograds = {n: p.grad.detach().clone() for n, p in oracle.named_parameters() if p.grad is not None}
+    opt = torch.optim.AdamW(params, lr=1e-3)
+    torch.nn.utils.clip_grad_value_(params, 1)
+    opt.step()
+    cfg = _cfg(T=Tn, learning_rate=1e-3, gradient_accumulation=1)
+    tr = ja.ReinforceTrainer(cfg, product)
+    env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True)
+    tr.train_iteration(env, forced_actions=forced, start_positions=start, optimizer_step=True)
+    product.pull_parameters()
+    psd = dict(product.named_parameters())
+    for name, p in oracle.named_parameters():
+        if name.startswith("yolox") or not p.requires_grad:
+            continue
+        # AdamW's first step moves a weight by ~lr * sign(g): compare where the sign of g is well defined
+        g = ograds.get(name)
+        if g is None:
+            continue
+        sig = g.abs() > 1e-2 * g.abs().max()
+        got_upd = (psd[name].detach().cpu() - before[name])[sig]
+        ref_upd = (p.detach() - before[name])[sig]
+        assert torch.allclose(got_upd, ref_upd, atol=5e-5), (name, (got_upd - ref_upd).abs().max())
+        assert ref_upd.abs().max() > 5e-4
