@@ -7,9 +7,12 @@
 Workload (BASELINE.json configs[2]/[3], the configuration the metric is quoted on):
 gpt-nano + yolox-nano patch encoder, 448 px patches, seq-len 20, --enable-stop, batch 64
 agents per GPU on synthetic 4480x4480 fp32 images with 1-3 random boxes, one rank per GPU
-(weak scaling: configs[3] is 512 = 8 x 64).  One "step" = env build + one whole-batch
-rollout of 20 glimpse steps (forced non-STOP actions so that S == T: a fixed amount of
-work) + the REINFORCE loss.  Inputs are resident in HBM before timing.
+(weak scaling: configs[3] is 512 = 8 x 64).  One "step" = one REINFORCE iteration
+(src/reinforce.py:302-353): env build + whole-batch rollout of 20 glimpse steps with train-mode
+BatchNorm (forced non-STOP actions so that S == T: a fixed amount of work) +
+REINFORCE loss + backward through all 20 steps + ONE flat-gradient all-reduce (N > 1) +
+clip_grad_value_ + AdamW.  `--mode rollout` times the forward-only (eval) rollout instead.
+Inputs are resident in HBM before timing.
 
 Prints ONE JSON line on rank 0 (schema in the task contract) with `roofline` for the nano
 PAFPN conv stack (HIP events around the conv section of every glimpse step, on the stream
@@ -48,31 +51,44 @@ def synth_inputs(B, G, P, seed, device):
     return images, bboxes, start
 
 
-def cpu_baseline(P, T, seed):
+def cpu_baseline(P, T, seed, train):
     """CPU oracle (pure PyTorch fp32 restatement, oracle/) on the host cores: a bounded sample of
     the same workload — B=4 agents, T glimpse steps, 4480x4480 images would need 1 GB/agent on the
     host, so the sample uses a 3x3 grid (patch content is what costs; the grid size does not)."""
     from oracle import env_ref, rollout_ref
     from oracle.gpt_ref import build_gpt_ref
     torch.manual_seed(seed)
-    B, G = 4, 3
-    oracle = build_gpt_ref(1, patch_size=P, block_size=T, with_detector=False, image_processor=None).eval()
+    B, G = (2, 3) if train else (4, 3)
+    T = min(T, 10) if train else T
+    oracle = build_gpt_ref(1, patch_size=P, block_size=T, with_detector=False, image_processor=None)
+    oracle.train(train)
+    params = [p for n, p in oracle.named_parameters()]
+    opt = torch.optim.AdamW(params, lr=1e-4)
     images = torch.rand(B, 3, G * P, G * P)
     bboxes = torch.tensor([[[10, 10, 200, 200]]] * B)
     forced = torch.randint(0, 8, (B, T))
     start = torch.randint(0, G, (B, 2))
     times = []
-    for it in range(3):
+    for it in range(2 if train else 3):
         env = env_ref.EnvRef(images, bboxes, P, T, 1, True)
         t0 = time.perf_counter()
-        with torch.no_grad():
+        if train:
+            opt.zero_grad()
             ro = rollout_ref.rollout(oracle, env, forced_actions=forced, start_positions=start)
-            rollout_ref.reinforce_metrics(ro, 0.01, rollout_ref.ReturnNormaliser())
+            m = rollout_ref.reinforce_metrics(ro, 0.01, rollout_ref.ReturnNormaliser())
+            m["loss"].backward()
+            torch.nn.utils.clip_grad_value_(params, 1)
+            opt.step()
+        else:
+            with torch.no_grad():
+                ro = rollout_ref.rollout(oracle, env, forced_actions=forced, start_positions=start)
+                rollout_ref.reinforce_metrics(ro, 0.01, rollout_ref.ReturnNormaliser())
         times.append(time.perf_counter() - t0)
-    best = sorted(times)[1] if len(times) >= 3 else min(times)
+    best = sorted(times)[len(times) // 2] if len(times) >= 3 else min(times)
+    what = "full REINFORCE iteration (fwd + bwd + clip + AdamW)" if train else "forward rollout + loss"
     return {"value": round(B * T / best, 2), "unit": "glimpse-patches/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"B=4 agents x T={T} steps, {P}px patches, 3x3-patch images, forced actions, "
-            f"forward rollout + loss, median of 3 ({best:.2f} s)"}
+            "kind": "port", "sample": f"B={B} agents x T={T} steps, {P}px patches, 3x3-patch images, forced actions, "
+            f"{what}, best-of-{len(times)} ({best:.2f} s)"}
 
 
 def main():
@@ -85,6 +101,7 @@ def main():
     ap.add_argument("--patch-size", type=int, default=448)
     ap.add_argument("--grid", type=int, default=10, help="image side in patches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["train", "rollout"], default="train")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -108,15 +125,21 @@ def main():
     model = ja.GPT(model_config(patch_size=P, block_size=T, with_detector=False, image_processor=None),
                    max_batch=B, device=f"cuda:{local_rank}")
     model.sync_weights()
-    cfg = ja.CfgNode(max_seq_len=T, entropy_weight=0.01, stop_enabled=True, reward_norm=True, seed=12345 + rank)
+    cfg = ja.CfgNode(max_seq_len=T, entropy_weight=0.01, stop_enabled=True, reward_norm=True, seed=12345 + rank,
+                     learning_rate=1e-4, gradient_accumulation=1)
     trainer = ja.ReinforceTrainer(cfg, model)
     images, bboxes, start = synth_inputs(B, G, P, 12345 + rank, dev)
     forced = torch.randint(0, 8, (B, T), generator=torch.Generator().manual_seed(777 + rank)).to(dev)
     eng = model.engine()
     eng.lib.jn_set_profiling(eng.handle, 1)
 
+    train = args.mode == "train"
+
     def one_step():
         env = ja.NeedleGeneralEnv(images, bboxes, P, T, 1, True, engine=eng)
+        if train:
+            m = trainer.train_iteration(env, forced_actions=forced, start_positions=start)
+            return m["steps"], m["loss"]
         ro = trainer.rollout(env, forced_actions=forced, start_positions=start, keep_patches=False)
         m = trainer.compute_metrics(ro)
         return ro["rewards"].shape[1], m["loss"]
@@ -165,18 +188,21 @@ def main():
                                    f"seq-len {T}, --enable-stop, {B} agents/GPU x {world} GPU, "
                                    f"{G * P}x{G * P} synthetic images, forced non-STOP actions (S=T)",
                        "global_batch": B * world, "seq_len": T,
-                       "phase": "env build + whole-batch rollout (forward, eval-mode BN) + REINFORCE loss; "
-                                "backward/optimizer step not implemented yet in this round",
-                       "parallelism": f"dp{world} (independent agents per rank, no data-path collective)"},
-            "roofline": {"bound": "hbm", "kernel": "yolox-nano PAFPN conv stack (stem/dw3x3/pw_mfma/spp/upsample, "
-                                                   "one pass over the batch per glimpse step)",
+                       "phase": ("full REINFORCE iteration: env build + rollout (train-mode BN) + loss + backward + "
+                                 "flat-gradient all-reduce + clip + AdamW") if train else
+                                "env build + whole-batch rollout (forward, eval-mode BN) + REINFORCE loss",
+                       "parallelism": f"dp{world} (independent agents per rank; one RCCL all-reduce of the flat "
+                                      f"gradient per iteration)"},
+            "roofline": {"bound": "hbm", "kernel": "yolox-nano PAFPN forward conv stack (stem/dw3x3/pw_mfma/spp/upsample"
+                                                   + ("/bn_finalize, train-mode BN" if train else "") +
+                                                   "), one pass over the batch per glimpse step",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "ms_per_launch": round(conv_ms_per_launch, 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(P, T, 12345)
+            out["cpu_baseline"] = cpu_baseline(P, T, 12345, train)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -165,14 +165,11 @@ class ReinforceTrainer:
             lm = buf["logit_masks"][:, :S].bool()
             self.last_return_values.append(buf["returns"][:, :S][lm].clone())
         if optimizer_step and self.iter_num % ga == 0:
-            world = 1
-            if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-                import torch.distributed as dist
-                world = dist.get_world_size(process_group)
-                if world > 1:      # the ONE exchange step of the iteration: flat gradient all-reduce over xGMI
-                    dist.all_reduce(grads[:self._optim_numel], op=dist.ReduceOp.SUM, group=process_group)
+            # the ONE exchange step of the iteration: flat gradient all-reduce (RCCL over xGMI)
+            from .dist import allreduce_gradients
+            scale = allreduce_gradients(grads, self._optim_numel, process_group)
             lr = float(getattr(self.config, "learning_rate", 1e-4))
-            check(eng.lib.jn_optimizer_step(eng.handle, lr, 0.01, 1.0, 1.0 / world, stream), "jn_optimizer_step")
+            check(eng.lib.jn_optimizer_step(eng.handle, lr, 0.01, 1.0, scale, stream), "jn_optimizer_step")
             grads.zero_()
             if self.config.reward_norm:
                 self._compute_last_returns_mean_std()
