@@ -246,7 +246,7 @@ inline ChanTab view_tab(const Net& net, int slot, const View& v) {
   float* t = net.tab + (size_t)slot * 3 * net.tab_channels + net.tab_off[v.buf] + v.coff;
   return ChanTab{t, t + net.tab_channels, t + 2 * net.tab_channels};
 }
-inline double* slot_stats(const Net& net, int slot) { return net.stats + (size_t)slot * 2 * net.stat_channels; }
+inline double* slot_stats(const Net& net, int slot) { return net.stats + (size_t)slot * JN_NREP * 2 * net.stat_channels; }
 inline float* slot_save(const Net& net, int slot) { return net.save + (size_t)slot * 2 * net.stat_channels; }
 
 }  // namespace jnr
@@ -390,7 +390,7 @@ static int ensure_slots(jn_ctx* ctx, Net& net, int n_slots) {
   if ((rc = dev_alloc(ctx, &act, (size_t)n_slots * net.per_image_floats * MB))) return rc;
   if ((rc = dev_alloc(ctx, &tab, (size_t)n_slots * 3 * net.tab_channels))) return rc;
   if ((rc = dev_alloc(ctx, &save, (size_t)n_slots * 2 * net.stat_channels))) return rc;
-  if ((rc = dev_alloc(ctx, &stats, (size_t)n_slots * 2 * net.stat_channels))) return rc;
+  if ((rc = dev_alloc(ctx, &stats, (size_t)n_slots * JN_NREP * 2 * net.stat_channels))) return rc;
   // old (smaller) allocations stay owned by the context until jn_destroy; slots are grown once per config
   net.act = act; net.tab = tab; net.save = save; net.stats = stats; net.n_slots = n_slots;
   for (int sl = 0; sl < n_slots; ++sl) {
@@ -579,7 +579,8 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
   if (!train && (rc = refresh_eval_table(ctx, net, s))) return rc;
   double* stats = train ? slot_stats(net, slot) : nullptr;
   float* save = train ? slot_save(net, slot) : nullptr;
-  if (train) JN_HIP(hipMemsetAsync(stats, 0, (size_t)2 * net.stat_channels * sizeof(double), s));
+  if (train) JN_HIP(hipMemsetAsync(stats, 0, (size_t)JN_NREP * 2 * net.stat_channels * sizeof(double), s));
+  const long long rep_stride = 2LL * net.stat_channels;
   auto ptr = [&](const View& v) { return view_ptr(net, slot, MB, v); };
   auto tab = [&](const View& v) { return view_tab(net, slot, v); };
   auto ld = [&](const View& v) { return net.bufs[v.buf].C; };
@@ -587,7 +588,7 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
     if (!train || !cw.has_bn) return;
     ChanTab t1{nullptr, nullptr, nullptr};
     if (op.alias.buf >= 0) t1 = tab(op.alias);
-    launch_bn_finalize(stats + 2 * cw.stat_off, (double)N * op.out.H * op.out.W, cw.gamma_dev, cw.beta_dev, cw.rmean_dev,
+    launch_bn_finalize(stats + 2 * cw.stat_off, rep_stride, (double)N * op.out.H * op.out.W, cw.gamma_dev, cw.beta_dev, cw.rmean_dev,
                        cw.rvar_dev, save + 2 * cw.stat_off, tab(op.out), t1, cw.cout, kBnEps, kBnMomentum, skip_flag,
                        skip_when, s);
   };
@@ -596,7 +597,8 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
       case OP_STEM: {
         const ConvW& cw = net.convs[op.wslot];
         StemArgs a{ss.src, ss.positions, ss.pos_stride, ss.sample_stride, ss.chan_stride, ss.row_stride, net.P, N, cw.cout,
-                   cw.w_dev, ptr(op.out), ld(op.out), train ? stats + 2 * cw.stat_off : nullptr, skip_flag, skip_when};
+                   cw.w_dev, ptr(op.out), ld(op.out), train ? stats + 2 * cw.stat_off : nullptr, rep_stride, skip_flag,
+                   skip_when};
         launch_stem(a, s);
         finalize(op, cw);
         break;
@@ -610,6 +612,7 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
         a.N = N; a.H = op.in.H; a.W = op.in.W; a.OH = op.out.H; a.OW = op.out.W;
         a.cin = op.in.C; a.cout = op.out.C; a.stride = op.stride; a.act = op.act;
         a.stats = (train && cw.has_bn) ? stats + 2 * cw.stat_off : nullptr;
+        a.stats_rep_stride = rep_stride;
         a.skip_flag = skip_flag; a.skip_when = skip_when;
         if (op.kind == OP_PW) launch_pw(a, s); else launch_dw(a, s);
         finalize(op, cw);
@@ -650,13 +653,16 @@ static int ensure_train_state(jn_ctx* ctx) {
     std::vector<float> id(3 * 2048, 0.0f);
     for (int i = 0; i < 2048; ++i) id[i] = 1.0f;
     if ((rc = dev_upload(ctx, &ctx->ident, id))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->wpart, (size_t)JN_NREP * JN_WPART_MAX))) return rc;
+    JN_HIP(hipMemset(ctx->wpart, 0, (size_t)JN_NREP * JN_WPART_MAX * sizeof(float)));
   }
   for (int ni = 0; ni < 2; ++ni) {
     if (!ctx->has_net[ni]) continue;
     Net& net = ctx->nets[ni];
     if (net.gact) continue;
     if ((rc = dev_alloc(ctx, &net.gact, net.per_image_floats * (size_t)ctx->cfg.max_batch))) return rc;
-    if ((rc = dev_alloc(ctx, &net.bred, (size_t)2 * net.stat_channels))) return rc;
+    if ((rc = dev_alloc(ctx, &net.bred, (size_t)JN_NREP * 2 * net.stat_channels))) return rc;
+    if ((rc = dev_alloc(ctx, &net.bconsts, (size_t)3 * net.stat_channels))) return rc;
   }
   return JN_OK;
 }
@@ -668,7 +674,8 @@ static inline float* grad_of(const jn_ctx* ctx, const float* param) { return ctx
 static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, hipStream_t s) {
   Net& net = ctx->nets[ni];
   const int MB = ctx->cfg.max_batch;
-  JN_HIP(hipMemsetAsync(net.bred, 0, (size_t)2 * net.stat_channels * sizeof(double), s));
+  JN_HIP(hipMemsetAsync(net.bred, 0, (size_t)JN_NREP * 2 * net.stat_channels * sizeof(double), s));
+  const long long rep_stride = 2LL * net.stat_channels;
   float* save = slot_save(net, slot);
   auto ptr = [&](const View& v) { return view_ptr(net, slot, MB, v); };
   auto gptr = [&](const View& v) { return net.gact + net.buf_off[v.buf] * (size_t)MB + v.coff; };
@@ -682,10 +689,13 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
       JN_CHECK(cw.has_bn, JN_ESTATE, "backward of BN-free conv %s inside a PAFPN", op.name.c_str());
       const long long M = (long long)N * op.out.H * op.out.W;
       double* red = net.bred + 2 * cw.stat_off;
+      float* consts = net.bconsts + 3 * cw.stat_off;
       launch_bn_bwd_reduce(gptr(op.out), ld(op.out), ptr(op.out), ld(op.out), tab(op.out), save + 2 * cw.stat_off, cw.cout,
-                           M, red, s);
-      launch_bn_bwd_gz(gptr(op.out), ld(op.out), ptr(op.out), ld(op.out), tab(op.out), save + 2 * cw.stat_off,
-                       cw.gamma_dev, red, (double)M, grad_of(ctx, cw.gamma_dev), grad_of(ctx, cw.beta_dev), cw.cout, M, s);
+                           M, red, rep_stride, s);
+      launch_bn_bwd_consts(red, rep_stride, (double)M, cw.gamma_dev, save + 2 * cw.stat_off, consts,
+                           grad_of(ctx, cw.gamma_dev), grad_of(ctx, cw.beta_dev), cw.cout, s);
+      launch_bn_bwd_gz(gptr(op.out), ld(op.out), ptr(op.out), ld(op.out), tab(op.out), save + 2 * cw.stat_off, consts,
+                       cw.cout, M, s);
       float* gw = grad_of(ctx, cw.w_dev);
       if (op.kind == OP_PW) {
         ConvArgs a{};
@@ -695,16 +705,17 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
         a.cin = cw.cout; a.cout = cw.cin; a.stride = 1; a.act = ACT_NONE;
         a.accumulate = op.acc_in ? 1 : 0; a.w_transposed = 1;
         launch_pw(a, s);
-        launch_pw_bwd_weight(gptr(op.out), ld(op.out), ptr(op.in), ld(op.in), tab(op.in), gw, M, cw.cout, cw.cin, s);
+        launch_pw_bwd_weight(gptr(op.out), ld(op.out), ptr(op.in), ld(op.in), tab(op.in), gw, ctx->wpart, M, cw.cout,
+                             cw.cin, s);
       } else if (op.kind == OP_DW) {
         launch_dw_bwd_data(gptr(op.out), ld(op.out), cw.w_dev, gptr(op.in), ld(op.in), cw.cout, op.in.H, op.in.W, op.out.H,
                            op.out.W, N, op.stride, op.acc_in ? 1 : 0, s);
-        launch_dw_bwd_weight(gptr(op.out), ld(op.out), ptr(op.in), ld(op.in), tab(op.in), gw, cw.cout, op.in.H, op.in.W,
-                             op.out.H, op.out.W, N, op.stride, s);
+        launch_dw_bwd_weight(gptr(op.out), ld(op.out), ptr(op.in), ld(op.in), tab(op.in), gw, ctx->wpart, cw.cout, op.in.H,
+                             op.in.W, op.out.H, op.out.W, N, op.stride, s);
       } else if (op.kind == OP_STEM) {
         StemArgs a{ss.src, ss.positions, ss.pos_stride, ss.sample_stride, ss.chan_stride, ss.row_stride, net.P, N, cw.cout,
-                   cw.w_dev, nullptr, 0, nullptr, nullptr, 0};
-        launch_stem_bwd_weight(a, gptr(op.out), ld(op.out), gw, s);
+                   cw.w_dev, nullptr, 0, nullptr, 0, nullptr, 0};
+        launch_stem_bwd_weight(a, gptr(op.out), ld(op.out), gw, ctx->wpart, s);
       } else {
         set_error("backward of dense 3x3 conv (%s) is not implemented", op.name.c_str());
         return JN_ESTATE;
@@ -1258,7 +1269,7 @@ int jn_reinforce_step(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, 
     a.accumulate = 0; a.w_transposed = 1;
     launch_pw(a, s);
     launch_pw_bwd_weight(ctx->de_ws, C, view_ptr(net, slot, MB, f2), net.bufs[f2.buf].C, view_tab(net, slot, f2),
-                         grad_of(ctx, g.efpn_w), (long long)B * HW, C, f2.C, s);
+                         grad_of(ctx, g.efpn_w), ctx->wpart, (long long)B * HW, C, f2.C, s);
     for (int i = 0; i < 2; ++i) {
       const View& f = net.fpn[i];
       JN_HIP(hipMemsetAsync(net.gact + net.buf_off[f.buf] * (size_t)MB + f.coff, 0,

@@ -103,7 +103,8 @@ struct Net {
   float* save = nullptr;          // [n_slots][2 * stat_channels]  (mean, invstd)
   double* stats = nullptr;        // [n_slots][2 * stat_channels]  (sum, sumsq)
   float* gact = nullptr;          // gradient buffers, one slot: mirror of `act`
-  double* bred = nullptr;         // [2 * stat_channels] backward reductions (sum g_y, sum g_y * zhat)
+  double* bred = nullptr;         // [JN_NREP][2 * stat_channels] backward reductions (sum g_y, sum g_y * zhat)
+  float* bconsts = nullptr;       // [3 * stat_channels] per-channel backward constants
   bool eval_tab_dirty = true;     // slot-0 table must be rebuilt from the running statistics
 };
 
@@ -176,6 +177,7 @@ struct jn_ctx {
   int KS = 8;
   int32_t* found = nullptr;       // [B] visited bbox tiles
   float* ident = nullptr;         // identity table (scale 1, shift 0, flag 0) for gradient operands
+  float* wpart = nullptr;         // [JN_NREP][JN_WPART_MAX] replicated weight-gradient partials (kept zero)
   float* tok_emb = nullptr;       // [B][T][C] patch embeddings of jn_gpt_forward
   jnr::EnvState env;
   // rollout workspaces

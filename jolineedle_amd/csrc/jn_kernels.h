@@ -10,6 +10,12 @@ namespace jnr {
 
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
 
+// Atomic accumulators (BN statistics, weight-gradient partials) are replicated JN_NREP times and a
+// workgroup adds into replica (block id % JN_NREP): same-address contention drops 32x; the consumer
+// (finalize / reduce kernels) sums the replicas.
+constexpr int JN_NREP = 32;
+constexpr int JN_WPART_MAX = 16384;   // floats per replica of the weight-gradient scratch
+
 // Every hot-loop kernel takes (skip_flag, skip_when): it returns at once when
 // *skip_flag >= skip_when.  The rollout points skip_flag at n_done[t] with skip_when = B,
 // which reproduces the reference's early `break` (src/reinforce.py:181-184) with no host sync.
@@ -23,7 +29,8 @@ struct StemArgs {
   long long sample_stride, chan_stride; int row_stride;
   int P, N, cout;
   const float* w; float* out; int out_ld;
-  double* stats;                    // [cout][2] sum / sumsq accumulators (train mode) or null
+  double* stats;                    // [JN_NREP][rep_stride]: [cout][2] sum / sumsq accumulators (train) or null
+  long long stats_rep_stride;
   const int* skip_flag; int skip_when;
 };
 
@@ -34,7 +41,7 @@ struct ConvArgs {
   int N, H, W, OH, OW, cin, cout, stride, act;
   int accumulate;                        // out += (gradient buffers)
   int w_transposed;                      // pw: w is [cin][cout] and read transposed (data-gradient)
-  double* stats;
+  double* stats; long long stats_rep_stride;
   const int* skip_flag; int skip_when;
 };
 
@@ -47,7 +54,7 @@ int launch_upsample(const float* in, int in_ld, float* out, int out_ld, int C, i
                     const int* skip_flag, int skip_when, hipStream_t s);
 int launch_addact(const float* z, int z_ld, ChanTab zt, const float* res, int res_ld, ChanTab rt, float* out,
                   int out_ld, int C, long long M, const int* skip_flag, int skip_when, hipStream_t s);
-int launch_bn_finalize(const double* stats, double count, const float* gamma, const float* beta, float* run_mean,
+int launch_bn_finalize(const double* stats, long long rep_stride, double count, const float* gamma, const float* beta, float* run_mean,
                        float* run_var, float* save, ChanTab t0, ChanTab t1, int C, float eps, float momentum,
                        const int* skip_flag, int skip_when, hipStream_t s);
 int launch_nhwc_to_nchw(const float* in, int in_ld, ChanTab it, float* out, int C, int HW, int N, hipStream_t s);
@@ -56,17 +63,22 @@ int launch_efpn_linear(const float* e, const float* wt, float* part, int N, int 
 
 // ---- backward of the conv stack (kernels_bwd.hip) ----------------------------------------
 int launch_bn_bwd_reduce(const float* g, int g_ld, const float* z, int z_ld, ChanTab t, const float* save, int C,
-                         long long M, double* red_out, hipStream_t s);
-int launch_bn_bwd_gz(float* g, int g_ld, const float* z, int z_ld, ChanTab t, const float* save, const float* gamma,
-                     const double* red, double count, float* g_gamma, float* g_beta, int C, long long M,
-                     hipStream_t s);
-int launch_pw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw, long long M, int N,
-                         int K, hipStream_t s);
+                         long long M, double* red_out, long long rep_stride, hipStream_t s);
+// sums the replicas -> consts[c] = {sum_gy/n, sum_gy_zhat/n, gamma*invstd}; dgamma/dbeta += totals
+int launch_bn_bwd_consts(const double* red, long long rep_stride, double count, const float* gamma, const float* save,
+                         float* consts, float* g_gamma, float* g_beta, int C, hipStream_t s);
+int launch_bn_bwd_gz(float* g, int g_ld, const float* z, int z_ld, ChanTab t, const float* save, const float* consts,
+                     int C, long long M, hipStream_t s);
+// weight-gradient kernels add into wpart (replicated scratch, zero on entry and on exit) when the
+// tensor fits, else straight into gw; launch_wpart_reduce folds the replicas into gw.
+int launch_pw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw, float* wpart,
+                         long long M, int N, int K, hipStream_t s);
+int launch_wpart_reduce(float* gw, float* wpart, int n, hipStream_t s);
 int launch_dw_bwd_data(const float* gz, int g_ld, const float* w, float* gin, int gin_ld, int C, int H, int W, int OH,
                        int OW, int N, int stride, int accumulate, hipStream_t s);
-int launch_dw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw, int C, int H,
-                         int W, int OH, int OW, int N, int stride, hipStream_t s);
-int launch_stem_bwd_weight(const StemArgs& a, const float* gz, int g_ld, float* gw, hipStream_t s);
+int launch_dw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw, float* wpart,
+                         int C, int H, int W, int OH, int OW, int N, int stride, hipStream_t s);
+int launch_stem_bwd_weight(const StemArgs& a, const float* gz, int g_ld, float* gw, float* wpart, hipStream_t s);
 int launch_spp_bwd(const float* cat, float* gcat, int ld, int h, int H, int W, int N, ChanTab it, hipStream_t s);
 int launch_upsample_bwd(const float* gdst, int dst_ld, float* gsrc, int src_ld, int C, int H, int W, int N,
                         int accumulate, hipStream_t s);

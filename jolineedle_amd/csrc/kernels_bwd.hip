@@ -34,7 +34,8 @@ __device__ __forceinline__ f32x4 tf4_(f32x4 z, f32x4 sc, f32x4 sh, f32x4 fl) {
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, int g_ld,
                                                             const float* __restrict__ z, int z_ld, ChanTab t,
                                                             const float* __restrict__ save, int C, long long M,
-                                                            int rows_per_block, double* __restrict__ red_out) {
+                                                            int rows_per_block, double* __restrict__ red_out,
+                                                            long long rep_stride) {
   extern __shared__ float red[];    // [C][2]
   for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.0f;
   __syncthreads();
@@ -66,33 +67,48 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&red_out[i], (double)red[i]);
+  double* ro = red_out + (blockIdx.x % JN_NREP) * rep_stride;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&ro[i], (double)red[i]);
 }
 
 int launch_bn_bwd_reduce(const float* g, int g_ld, const float* z, int z_ld, ChanTab t, const float* save, int C,
-                         long long M, double* red_out, hipStream_t s) {
+                         long long M, double* red_out, long long rep_stride, hipStream_t s) {
   const int rstep = 256 / (C / 4) > 0 ? 256 / (C / 4) : 1;
   const int rows_per_block = rstep * 32;
   const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(256), (size_t)2 * C * sizeof(float), s, g, g_ld, z, z_ld, t,
-                     save, C, M, rows_per_block, red_out);
+                     save, C, M, rows_per_block, red_out, rep_stride);
   return 0;
 }
 
-// ---- 2. g_a -> g_z in place; BN affine gradients ---------------------------------------------
+// ---- 2. per-channel constants, then g_a -> g_z in place --------------------------------------
+__global__ void bn_bwd_consts_kernel(const double* __restrict__ red, long long rep_stride, double count,
+                                     const float* __restrict__ gamma, const float* __restrict__ save,
+                                     float* __restrict__ consts, float* __restrict__ g_gamma,
+                                     float* __restrict__ g_beta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < JN_NREP; ++r) { s1 += red[r * rep_stride + 2 * c]; s2 += red[r * rep_stride + 2 * c + 1]; }
+  consts[3 * c] = (float)(s1 / count);
+  consts[3 * c + 1] = (float)(s2 / count);
+  consts[3 * c + 2] = gamma[c] * save[2 * c + 1];
+  g_beta[c] += (float)s1;
+  g_gamma[c] += (float)s2;
+}
+
+int launch_bn_bwd_consts(const double* red, long long rep_stride, double count, const float* gamma, const float* save,
+                         float* consts, float* g_gamma, float* g_beta, int C, hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((C + 63) / 64), dim3(64), 0, s, red, rep_stride, count, gamma, save,
+                     consts, g_gamma, g_beta, C);
+  return 0;
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_gz_kernel(float* __restrict__ g, int g_ld, const float* __restrict__ z,
                                                         int z_ld, ChanTab t, const float* __restrict__ save,
-                                                        const float* __restrict__ gamma, const double* __restrict__ red,
-                                                        double count, float* __restrict__ g_gamma,
-                                                        float* __restrict__ g_beta, int C, long long M) {
+                                                        const float* __restrict__ consts, int C, long long M) {
   const int C4 = C >> 2;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x == 0) {
-    for (int c = threadIdx.x; c < C; c += 256) {
-      g_beta[c] += (float)red[2 * c];
-      g_gamma[c] += (float)red[2 * c + 1];
-    }
-  }
   if (idx >= M * C4) return;
   const int c = (int)(idx % C4) * 4;
   const long long m = idx / C4;
@@ -103,20 +119,34 @@ __global__ __launch_bounds__(256) void bn_bwd_gz_kernel(float* __restrict__ g, i
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float mean = save[2 * (c + q)], istd = save[2 * (c + q) + 1];
-    const float c1 = (float)(red[2 * (c + q)] / count), c2 = (float)(red[2 * (c + q) + 1] / count);
+    const float c1 = consts[3 * (c + q)], c2 = consts[3 * (c + q) + 1], k = consts[3 * (c + q) + 2];
     const float zh = (zv[q] - mean) * istd;
     const float gy = gv[q] * dsilu_(fmaf(zv[q], sc[q], sh[q]));
-    out[q] = gamma[c + q] * istd * (gy - c1 - zh * c2);
+    out[q] = k * (gy - c1 - zh * c2);
   }
   *reinterpret_cast<f32x4*>(g + m * g_ld + c) = out;
 }
 
-int launch_bn_bwd_gz(float* g, int g_ld, const float* z, int z_ld, ChanTab t, const float* save, const float* gamma,
-                     const double* red, double count, float* g_gamma, float* g_beta, int C, long long M,
-                     hipStream_t s) {
+int launch_bn_bwd_gz(float* g, int g_ld, const float* z, int z_ld, ChanTab t, const float* save, const float* consts,
+                     int C, long long M, hipStream_t s) {
   const long long total = M * (C / 4);
   hipLaunchKernelGGL(bn_bwd_gz_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, g_ld, z, z_ld, t, save,
-                     gamma, red, count, g_gamma, g_beta, C, M);
+                     consts, C, M);
+  return 0;
+}
+
+// gw[i] += sum_rep wpart[rep][i]; wpart is left zeroed for the next user
+__global__ __launch_bounds__(256) void wpart_reduce_kernel(float* __restrict__ gw, float* __restrict__ wpart, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.0f;
+#pragma unroll 8
+  for (int r = 0; r < JN_NREP; ++r) { s += wpart[r * JN_WPART_MAX + i]; wpart[r * JN_WPART_MAX + i] = 0.0f; }
+  gw[i] += s;
+}
+
+int launch_wpart_reduce(float* gw, float* wpart, int n, hipStream_t s) {
+  hipLaunchKernelGGL(wpart_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, gw, wpart, n);
   return 0;
 }
 
@@ -128,8 +158,8 @@ constexpr int WG_RB = 64;
 template <int CTN, int CTK>
 __global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const float* __restrict__ gz, int g_ld,
                                                             const float* __restrict__ x, int x_ld, ChanTab it,
-                                                            float* __restrict__ gw, long long M, int N, int K,
-                                                            int rows_per_block) {
+                                                            float* __restrict__ gw, int rep, long long M, int N,
+                                                            int K, int rows_per_block) {
   constexpr int LDN = 16 * CTN + 4, LDK = 16 * CTK + 4;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Gs = sm;                      // [WG_RB][LDN]
@@ -186,28 +216,32 @@ __global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 4; ++r) atomicAdd(&Ts[(16 * a + 4 * g + r) * (16 * CTK) + 16 * b + lm], acc[a][b][r]);
   __syncthreads();
+  float* dst = rep ? gw + (blockIdx.x % JN_NREP) * JN_WPART_MAX : gw;
   for (int i = tid; i < 256 * CTN * CTK; i += 256) {
     const int n = n0 + i / (16 * CTK), k = k0 + i % (16 * CTK);
-    if (n < N && k < K) atomicAdd(&gw[(long long)n * K + k], Ts[i]);
+    if (n < N && k < K) atomicAdd(&dst[(long long)n * K + k], Ts[i]);
   }
 }
 
 template <int CTN, int CTK>
-static void launch_pw_bw_t(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw, long long M,
-                           int N, int K, hipStream_t s) {
-  const int rows_per_block = M > 65536 ? 1024 : 256;
+static void launch_pw_bw_t(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw, int rep,
+                           long long M, int N, int K, hipStream_t s) {
+  const int rows_per_block = M > 262144 ? 2048 : (M > 32768 ? 1024 : 256);
   dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block), (N + 16 * CTN - 1) / (16 * CTN),
             (K + 16 * CTK - 1) / (16 * CTK));
   const size_t smem = ((size_t)WG_RB * (16 * CTN + 4 + 16 * CTK + 4) + 256 * CTN * CTK) * sizeof(float);
-  hipLaunchKernelGGL((pw_bwd_weight_kernel<CTN, CTK>), grid, dim3(256), smem, s, gz, g_ld, x, x_ld, it, gw, M, N, K,
-                     rows_per_block);
+  hipLaunchKernelGGL((pw_bwd_weight_kernel<CTN, CTK>), grid, dim3(256), smem, s, gz, g_ld, x, x_ld, it, gw, rep, M, N,
+                     K, rows_per_block);
 }
 
-int launch_pw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw, long long M, int N,
-                         int K, hipStream_t s) {
+int launch_pw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw_final, float* wpart,
+                         long long M, int N, int K, hipStream_t s) {
+  const int rep = (wpart && N * K <= JN_WPART_MAX && M > 16384) ? 1 : 0;
+  float* gw = rep ? wpart : gw_final;
   const int tn = (N + 15) / 16, tk = (K + 15) / 16;
   const int cn = tn >= 4 ? 4 : (tn == 3 ? 3 : tn), ck = tk >= 4 ? 4 : (tk == 3 ? 3 : tk);
-#define JN_BW(A, B) if (cn == A && ck == B) { launch_pw_bw_t<A, B>(gz, g_ld, x, x_ld, it, gw, M, N, K, s); return 0; }
+#define JN_BW(A, B) if (cn == A && ck == B) { launch_pw_bw_t<A, B>(gz, g_ld, x, x_ld, it, gw, rep, M, N, K, s); \
+    if (rep) launch_wpart_reduce(gw_final, wpart, N * K, s); return 0; }
   JN_BW(1, 1) JN_BW(1, 2) JN_BW(1, 3) JN_BW(1, 4) JN_BW(2, 1) JN_BW(2, 2) JN_BW(2, 3) JN_BW(2, 4)
   JN_BW(3, 1) JN_BW(3, 2) JN_BW(3, 3) JN_BW(3, 4) JN_BW(4, 1) JN_BW(4, 2) JN_BW(4, 3) JN_BW(4, 4)
 #undef JN_BW
@@ -268,8 +302,8 @@ int launch_dw_bwd_data(const float* gz, int g_ld, const float* w, float* gin, in
 template <int S>
 __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ gz, int g_ld,
                                                             const float* __restrict__ x, int x_ld, ChanTab it,
-                                                            float* __restrict__ gw, int C, int H, int W, int OH, int OW,
-                                                            int N) {
+                                                            float* __restrict__ gw, int rep, int C, int H, int W,
+                                                            int OH, int OW, int N) {
   extern __shared__ float red[];   // [9][C]
   for (int i = threadIdx.x; i < 9 * C; i += 256) red[i] = 0.0f;
   __syncthreads();
@@ -317,21 +351,25 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
       for (int q = 0; q < 4; ++q) atomicAdd(&red[t * C + c + q], dw[t][q]);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 9 * C; i += 256) atomicAdd(&gw[i], red[i]);
+  float* dst = rep ? gw + (blockIdx.x % JN_NREP) * JN_WPART_MAX : gw;
+  for (int i = threadIdx.x; i < 9 * C; i += 256) atomicAdd(&dst[i], red[i]);
 }
 
-int launch_dw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw, int C, int H,
-                         int W, int OH, int OW, int N, int stride, hipStream_t s) {
+int launch_dw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw_final, float* wpart,
+                         int C, int H, int W, int OH, int OW, int N, int stride, hipStream_t s) {
+  const int rep = (wpart && 9 * C <= JN_WPART_MAX) ? 1 : 0;
+  float* gw = rep ? wpart : gw_final;
   const int YS = (OH + 3) / 4;
   const long long total = (long long)N * YS * OW * (C / 4);
   const unsigned blocks = (unsigned)((total + 255) / 256);
   const size_t smem = (size_t)9 * C * sizeof(float);
   if (stride == 1)
-    hipLaunchKernelGGL(dw_bwd_weight_kernel<1>, dim3(blocks), dim3(256), smem, s, gz, g_ld, x, x_ld, it, gw, C, H, W, OH,
-                       OW, N);
+    hipLaunchKernelGGL(dw_bwd_weight_kernel<1>, dim3(blocks), dim3(256), smem, s, gz, g_ld, x, x_ld, it, gw, rep, C, H, W,
+                       OH, OW, N);
   else
-    hipLaunchKernelGGL(dw_bwd_weight_kernel<2>, dim3(blocks), dim3(256), smem, s, gz, g_ld, x, x_ld, it, gw, C, H, W, OH,
-                       OW, N);
+    hipLaunchKernelGGL(dw_bwd_weight_kernel<2>, dim3(blocks), dim3(256), smem, s, gz, g_ld, x, x_ld, it, gw, rep, C, H, W,
+                       OH, OW, N);
+  if (rep) launch_wpart_reduce(gw_final, wpart, 9 * C, s);
   return 0;
 }
 
@@ -340,31 +378,15 @@ constexpr int SB_TY = 8, SB_TX = 32, SB_IH = 2 * SB_TY + 4, SB_IW = 2 * SB_TX + 
 
 __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
     const float* __restrict__ src, const long long* __restrict__ pos, int pos_stride, long long sample_stride,
-    long long chan_stride, int row_stride, int P, const float* __restrict__ gz, int g_ld, int cout, int ocg, float* __restrict__ gw) {
+    long long chan_stride, int row_stride, int P, const float* __restrict__ gz, int g_ld, int cout, int ocg,
+    int tiles_x, int tiles_y, int n_tiles, float* __restrict__ gw) {
   __shared__ __attribute__((aligned(16))) float tile[3 * SB_IH * SB_IW];
   __shared__ float Gz[SB_TY * SB_TX * 16];
   __shared__ float Ts[16 * 112];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, g = lane >> 4;
-  const int n = blockIdx.z / ocg, og = blockIdx.z % ocg;
+  const int og = blockIdx.y;
   const int OH = P / 2;
-  const int oy0 = blockIdx.y * SB_TY, ox0 = blockIdx.x * SB_TX;
-  const float* base = src + (long long)n * sample_stride;
-  if (pos) base += pos[(long long)pos_stride * n] * (long long)P * row_stride + pos[(long long)pos_stride * n + 1] * (long long)P;
-  for (int i = tid; i < 3 * SB_IH * SB_IW; i += 256) {
-    const int c = i / (SB_IH * SB_IW), r = (i / SB_IW) % SB_IH, q = i % SB_IW;
-    const int iy = 2 * oy0 - 2 + r, ix = 2 * ox0 - 2 + q;
-    float v = 0.0f;
-    if (iy >= 0 && iy < P && ix >= 0 && ix < P) v = base[c * chan_stride + (long long)iy * row_stride + ix];
-    tile[i] = v;
-  }
-  for (int i = tid; i < SB_TY * SB_TX * 4; i += 256) {
-    const int p = i >> 2, q = i & 3, ty = p / SB_TX, tx = p % SB_TX;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (oy0 + ty < OH && ox0 + tx < OH)
-      v = *reinterpret_cast<const f32x4*>(gz + (((long long)n * OH + oy0 + ty) * OH + ox0 + tx) * g_ld + og * 16 + 4 * q);
-    *reinterpret_cast<f32x4*>(&Gz[p * 16 + 4 * q]) = v;
-  }
   for (int i = tid; i < 16 * 112; i += 256) Ts[i] = 0.0f;
   int koff[7];
 #pragma unroll
@@ -373,35 +395,62 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
     const int c = k / 36, dy = (k % 36) / 6, dx = k % 6;
     koff[t] = k < 108 ? (c * SB_IH + dy) * SB_IW + dx : 0;
   }
-  __syncthreads();
   f32x4 acc[7];
 #pragma unroll
   for (int t = 0; t < 7; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int st = 0; st < SB_TY * SB_TX / 16; ++st) {
-    const int p = wave * (SB_TY * SB_TX / 4) + 4 * st + g;   // pixel of this k-step for this lane group
-    const int ty = p / SB_TX, tx = p % SB_TX;
-    const float av = Gz[p * 16 + lm];                     // A[i = oc][kk = pixel]
-    const int pbase = (2 * ty) * SB_IW + 2 * tx;
+  // persistent over (image, tile): the partial dW stays in registers, ONE set of atomics per workgroup
+  for (int tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+    const int n = tl / (tiles_x * tiles_y), tr = tl % (tiles_x * tiles_y);
+    const int oy0 = (tr / tiles_x) * SB_TY, ox0 = (tr % tiles_x) * SB_TX;
+    const float* base = src + (long long)n * sample_stride;
+    if (pos) base += pos[(long long)pos_stride * n] * (long long)P * row_stride + pos[(long long)pos_stride * n + 1] * (long long)P;
+    __syncthreads();
+    for (int i = tid; i < 3 * SB_IH * SB_IW; i += 256) {
+      const int c = i / (SB_IH * SB_IW), r = (i / SB_IW) % SB_IH, q = i % SB_IW;
+      const int iy = 2 * oy0 - 2 + r, ix = 2 * ox0 - 2 + q;
+      float v = 0.0f;
+      if (iy >= 0 && iy < P && ix >= 0 && ix < P) v = base[c * chan_stride + (long long)iy * row_stride + ix];
+      tile[i] = v;
+    }
+    for (int i = tid; i < SB_TY * SB_TX * 4; i += 256) {
+      const int p = i >> 2, q = i & 3, ty = p / SB_TX, tx = p % SB_TX;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (oy0 + ty < OH && ox0 + tx < OH)
+        v = *reinterpret_cast<const f32x4*>(gz + (((long long)n * OH + oy0 + ty) * OH + ox0 + tx) * g_ld + og * 16 + 4 * q);
+      *reinterpret_cast<f32x4*>(&Gz[p * 16 + 4 * q]) = v;
+    }
+    __syncthreads();
+    for (int st = 0; st < SB_TY * SB_TX / 16; ++st) {
+      const int p = wave * (SB_TY * SB_TX / 4) + 4 * st + g;   // pixel of this k-step for this lane group
+      const int ty = p / SB_TX, tx = p % SB_TX;
+      const float av = Gz[p * 16 + lm];                     // A[i = oc][kk = pixel]
+      const int pbase = (2 * ty) * SB_IW + 2 * tx;
 #pragma unroll
-    for (int t = 0; t < 7; ++t)
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, tile[pbase + koff[t]], acc[t], 0, 0, 0);
+      for (int t = 0; t < 7; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, tile[pbase + koff[t]], acc[t], 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int t = 0; t < 7; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) atomicAdd(&Ts[(4 * g + r) * 112 + 16 * t + lm], acc[t][r]);
   __syncthreads();
+  float* dst = gw + (blockIdx.x % JN_NREP) * JN_WPART_MAX;
   for (int i = tid; i < 16 * 108; i += 256) {
     const int oc = i / 108, k = i % 108;
-    atomicAdd(&gw[(long long)k * cout + og * 16 + oc], Ts[oc * 112 + k]);
+    atomicAdd(&dst[(long long)k * cout + og * 16 + oc], Ts[oc * 112 + k]);
   }
 }
 
-int launch_stem_bwd_weight(const StemArgs& a, const float* gz, int g_ld, float* gw, hipStream_t s) {
+int launch_stem_bwd_weight(const StemArgs& a, const float* gz, int g_ld, float* gw, float* wpart, hipStream_t s) {
   const int OH = a.P / 2, ocg = a.cout / 16;
-  dim3 grid((OH + SB_TX - 1) / SB_TX, (OH + SB_TY - 1) / SB_TY, a.N * ocg);
+  const int tiles_x = (OH + SB_TX - 1) / SB_TX, tiles_y = (OH + SB_TY - 1) / SB_TY;
+  const int n_tiles = tiles_x * tiles_y * a.N;
+  dim3 grid(n_tiles < 1024 ? n_tiles : 1024, ocg);
   hipLaunchKernelGGL(stem_bwd_weight_kernel, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.pos_stride,
-                     a.sample_stride, a.chan_stride, a.row_stride, a.P, gz, g_ld, a.cout, ocg, gw);
+                     a.sample_stride, a.chan_stride, a.row_stride, a.P, gz, g_ld, a.cout, ocg, tiles_x, tiles_y, n_tiles,
+                     wpart);
+  launch_wpart_reduce(gw, wpart, 108 * a.cout, s);
   return 0;
 }
 

@@ -89,7 +89,8 @@ constexpr int ST_KS = 27;                                     // 108 / 4 k-steps
 __global__ __launch_bounds__(256) void stem_mfma_kernel(
     const float* __restrict__ src, const long long* __restrict__ pos, int pos_stride, long long sample_stride,
     long long chan_stride, int row_stride, int P, const float* __restrict__ w, float* __restrict__ out,
-    int out_ld, int cout, int ocg, double* __restrict__ stats, const int* __restrict__ skip_flag, int skip_when) {
+    int out_ld, int cout, int ocg, double* __restrict__ stats, long long rep_stride,
+    const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
   __shared__ __attribute__((aligned(16))) float tile[3 * ST_IH * ST_IW];
   __shared__ float red[32];
@@ -142,7 +143,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(
   if (stats) {
     wave_stats_to_lds<1>(s1, s2, red, lane, 16);
     __syncthreads();
-    if (tid < 32) atomicAdd(&stats[2 * (og * 16) + tid], (double)red[tid]);
+    const int rep = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z) % JN_NREP;
+    if (tid < 32) atomicAdd(&stats[rep * rep_stride + 2 * (og * 16) + tid], (double)red[tid]);
   }
 }
 
@@ -151,8 +153,8 @@ int launch_stem(const StemArgs& a, hipStream_t s) {
   const int ocg = a.cout / 16;
   dim3 grid((OH + ST_TX - 1) / ST_TX, (OH + ST_TY - 1) / ST_TY, a.N * ocg);
   hipLaunchKernelGGL(stem_mfma_kernel, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.pos_stride,
-                     a.sample_stride, a.chan_stride, a.row_stride, a.P, a.w, a.out, a.out_ld, a.cout, ocg, a.stats, a.skip_flag,
-                     a.skip_when);
+                     a.sample_stride, a.chan_stride, a.row_stride, a.P, a.w, a.out, a.out_ld, a.cout, ocg, a.stats,
+                     a.stats_rep_stride, a.skip_flag, a.skip_when);
   return 0;
 }
 
@@ -162,7 +164,7 @@ int launch_stem(const StemArgs& a, hipStream_t s) {
 template <int S>
 __global__ __launch_bounds__(256) void dw3x3_kernel(
     const float* __restrict__ in, int in_ld, ChanTab it, const float* __restrict__ w, float* __restrict__ out,
-    int out_ld, int C, int H, int W, int OH, int OW, int N, double* __restrict__ stats,
+    int out_ld, int C, int H, int W, int OH, int OW, int N, double* __restrict__ stats, long long rep_stride,
     const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
   extern __shared__ float red[];   // [C][2] when stats
@@ -229,7 +231,8 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(
   }
   if (stats) {
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&stats[i], (double)red[i]);
+    double* st = stats + (blockIdx.x % JN_NREP) * rep_stride;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&st[i], (double)red[i]);
   }
 }
 
@@ -240,10 +243,10 @@ int launch_dw(const ConvArgs& a, hipStream_t s) {
   const size_t smem = a.stats ? (size_t)2 * a.cin * sizeof(float) : 0;
   if (a.stride == 1)
     hipLaunchKernelGGL(dw3x3_kernel<1>, dim3(blocks), dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.out, a.out_ld,
-                       a.cin, a.H, a.W, a.OH, a.OW, a.N, a.stats, a.skip_flag, a.skip_when);
+                       a.cin, a.H, a.W, a.OH, a.OW, a.N, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when);
   else
     hipLaunchKernelGGL(dw3x3_kernel<2>, dim3(blocks), dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.out, a.out_ld,
-                       a.cin, a.H, a.W, a.OH, a.OW, a.N, a.stats, a.skip_flag, a.skip_when);
+                       a.cin, a.H, a.W, a.OH, a.OW, a.N, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when);
   return 0;
 }
 
@@ -260,7 +263,7 @@ template <int CT, int PW_KC, bool WT>
 __global__ __launch_bounds__(256) void pw_mfma_kernel(
     const float* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, int out_ld, long long M, int K, int Nc, int act, int accumulate,
-    double* __restrict__ stats, const int* __restrict__ skip_flag, int skip_when) {
+    double* __restrict__ stats, long long rep_stride, const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
   constexpr int PW_LD = PW_KC + 4;        // K chunk staged in LDS (+4 floats: bank spread, 16-B rows)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -350,7 +353,8 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
   if (stats) {
     wave_stats_to_lds<CT>(s1, s2, red, lane, Nc - n0);
     __syncthreads();
-    if (tid < 32 * CT && n0 + (tid >> 1) < Nc) atomicAdd(&stats[2 * n0 + tid], (double)red[tid]);
+    if (tid < 32 * CT && n0 + (tid >> 1) < Nc)
+      atomicAdd(&stats[(blockIdx.x % JN_NREP) * rep_stride + 2 * n0 + tid], (double)red[tid]);
   }
 }
 
@@ -361,10 +365,12 @@ static void launch_pw_ct(const ConvArgs& a, long long M, hipStream_t s) {
   const size_t smem = ((size_t)(PW_BM + 16 * CT) * (KC + 4) + 32 * CT) * sizeof(float);
   if (a.w_transposed)
     hipLaunchKernelGGL((pw_mfma_kernel<CT, KC, true>), grid, dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.bias,
-                       a.out, a.out_ld, M, a.cin, a.cout, a.act, a.accumulate, a.stats, a.skip_flag, a.skip_when);
+                       a.out, a.out_ld, M, a.cin, a.cout, a.act, a.accumulate, a.stats, a.stats_rep_stride, a.skip_flag,
+                       a.skip_when);
   else
     hipLaunchKernelGGL((pw_mfma_kernel<CT, KC, false>), grid, dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.bias,
-                       a.out, a.out_ld, M, a.cin, a.cout, a.act, a.accumulate, a.stats, a.skip_flag, a.skip_when);
+                       a.out, a.out_ld, M, a.cin, a.cout, a.act, a.accumulate, a.stats, a.stats_rep_stride, a.skip_flag,
+                       a.skip_when);
 }
 
 int launch_pw(const ConvArgs& a, hipStream_t s) {
@@ -487,7 +493,8 @@ int launch_addact(const float* z, int z_ld, ChanTab zt, const float* res, int re
 // Train-mode BatchNorm2d (eps 1e-3, momentum 0.03): batch mean / biased variance
 // from the fp64 sums -> (scale, shift) of the layer's output channels (and of an alias slice
 // that holds an upsampled copy), saved (mean, invstd) for the backward pass, running stats.
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, const float* __restrict__ gamma,
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, long long rep_stride, double count,
+                                   const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ run_mean,
                                    float* __restrict__ run_var, float* __restrict__ save, ChanTab t0, ChanTab t1,
                                    int C, float eps, float momentum, const int* __restrict__ skip_flag,
@@ -495,8 +502,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double coun
   if (skip_flag && *skip_flag >= skip_when) return;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double mean = stats[2 * c] / count;
-  double var = stats[2 * c + 1] / count - mean * mean;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < JN_NREP; ++r) { s1 += stats[r * rep_stride + 2 * c]; s2 += stats[r * rep_stride + 2 * c + 1]; }
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float sc = gamma[c] * invstd;
@@ -511,10 +520,11 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double coun
   }
 }
 
-int launch_bn_finalize(const double* stats, double count, const float* gamma, const float* beta, float* run_mean,
+int launch_bn_finalize(const double* stats, long long rep_stride, double count, const float* gamma, const float* beta, float* run_mean,
                        float* run_var, float* save, ChanTab t0, ChanTab t1, int C, float eps, float momentum,
                        const int* skip_flag, int skip_when, hipStream_t s) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, stats, count, gamma, beta, run_mean, run_var,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, stats, rep_stride, count, gamma, beta, run_mean,
+                     run_var,
                      save, t0, t1, C, eps, momentum, skip_flag, skip_when);
   return 0;
 }
