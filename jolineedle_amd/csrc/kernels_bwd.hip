@@ -226,7 +226,12 @@ __global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const float* __restr
 template <int CTN, int CTK>
 static void launch_pw_bw_t(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw, int rep,
                            long long M, int N, int K, hipStream_t s) {
-  const int rows_per_block = M > 262144 ? 2048 : (M > 32768 ? 1024 : 256);
+  // aim at ~768 workgroups: enough to fill 256 CUs x 3, few enough that the final atomics stay cheap
+  const long long tiles = (long long)((N + 16 * CTN - 1) / (16 * CTN)) * ((K + 16 * CTK - 1) / (16 * CTK));
+  long long rpb = (M * tiles / 768 + 63) / 64 * 64;
+  if (rpb < 64) rpb = 64;
+  if (rpb > 4096) rpb = 4096;
+  const int rows_per_block = (int)rpb;
   dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block), (N + 16 * CTN - 1) / (16 * CTN),
             (K + 16 * CTK - 1) / (16 * CTK));
   const size_t smem = ((size_t)WG_RB * (16 * CTN + 4 + 16 * CTK + 4) + 256 * CTN * CTK) * sizeof(float);
@@ -236,7 +241,7 @@ static void launch_pw_bw_t(const float* gz, int g_ld, const float* x, int x_ld, 
 
 int launch_pw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw_final, float* wpart,
                          long long M, int N, int K, hipStream_t s) {
-  const int rep = (wpart && N * K <= JN_WPART_MAX && M > 16384) ? 1 : 0;
+  const int rep = (wpart && N * K <= JN_WPART_MAX) ? 1 : 0;
   float* gw = rep ? wpart : gw_final;
   const int tn = (N + 15) / 16, tk = (K + 15) / 16;
   const int cn = tn >= 4 ? 4 : (tn == 3 ? 3 : tn), ck = tk >= 4 ? 4 : (tk == 3 ? 3 : tk);
@@ -310,17 +315,19 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
   const int C4 = C >> 2;
   const int YS = (OH + 3) >> 2;
   const long long total = (long long)N * YS * OW * C4;
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx < total) {
-    const int c = (int)(idx % C4) * 4;
-    const int ox = (int)((idx / C4) % OW);
-    const int ys = (int)((idx / ((long long)C4 * OW)) % YS);
-    const long long n = idx / ((long long)C4 * OW * YS);
+  const long long idx0 = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long gstride = (long long)gridDim.x * 256;          // multiple of C4: the channel group stays fixed
+  {
+    const int c = (int)(idx0 % C4) * 4;
     const f32x4 sc = *reinterpret_cast<const f32x4*>(it.sc + c), sh = *reinterpret_cast<const f32x4*>(it.sh + c),
                 fl = *reinterpret_cast<const f32x4*>(it.fl + c);
     f32x4 dw[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) dw[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long long idx = idx0; idx < total; idx += gstride) {
+    const int ox = (int)((idx / C4) % OW);
+    const int ys = (int)((idx / ((long long)C4 * OW)) % YS);
+    const long long n = idx / ((long long)C4 * OW * YS);
     f32x4 gv[4];
     const int oy0 = ys * 4;
 #pragma unroll
@@ -345,6 +352,7 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
         }
       }
     }
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -361,7 +369,9 @@ int launch_dw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, Ch
   float* gw = rep ? wpart : gw_final;
   const int YS = (OH + 3) / 4;
   const long long total = (long long)N * YS * OW * (C / 4);
-  const unsigned blocks = (unsigned)((total + 255) / 256);
+  long long nb = (total + 255) / 256;
+  if (nb > 2048) nb = 2048;                       // grid-stride: each thread folds many strips before its atomics
+  const unsigned blocks = (unsigned)nb;
   const size_t smem = (size_t)9 * C * sizeof(float);
   if (stride == 1)
     hipLaunchKernelGGL(dw_bwd_weight_kernel<1>, dim3(blocks), dim3(256), smem, s, gz, g_ld, x, x_ld, it, gw, rep, C, H, W,
