@@ -21,8 +21,8 @@ void set_error(const char* fmt, ...) {
 
 int build_pafpn(Net& net, std::vector<ParamEntry>& params, const std::string& prefix, float depth, float width,
                 bool depthwise, int P);
-void add_head_params(std::vector<ParamEntry>& params, std::vector<ConvW>& convs, const std::string& prefix,
-                     float width, bool depthwise, int num_classes);
+int build_head(Net& net, std::vector<ParamEntry>& params, const std::string& prefix, float width, bool depthwise,
+               int num_classes);
 
 namespace {
 
@@ -298,8 +298,8 @@ int jn_create(const jn_config* cfg, jn_ctx** out) {
                      cfg->det_depthwise != 0, cfg->patch_size);
     if (rc) return rc;
     ctx->has_net[JN_NET_DETECTOR] = true;
-    std::vector<ConvW> head_convs;
-    add_head_params(P, head_convs, "yolox.head.", cfg->det_width, cfg->det_depthwise != 0, 1);
+    rc = build_head(ctx->nets[JN_NET_DETECTOR], P, "yolox.head.", cfg->det_width, cfg->det_depthwise != 0, 1);
+    if (rc) return rc;
   }
   if (cfg->gpt_bb_width > 0) {
     rc = build_pafpn(ctx->nets[JN_NET_GPT_BACKBONE], P, "gpt_backbone.", cfg->gpt_bb_depth, cfg->gpt_bb_width,
@@ -478,6 +478,27 @@ int jn_load_weights(jn_ctx* ctx, const jn_tensor* tensors, size_t n) {
       if (r) return r;
     }
     net.eval_tab_dirty = true;
+    for (const Op& op : net.ops) {
+      if (op.kind != OP_PRED) continue;
+      const std::string k = std::to_string(op.level), hp = "yolox.head.";
+      const int hid = net.head_hid;
+      const float* rw = tm.f32(hp + "reg_preds." + k + ".weight", (size_t)4 * hid);
+      const float* rb = tm.f32(hp + "reg_preds." + k + ".bias", 4);
+      const float* ow = tm.f32(hp + "obj_preds." + k + ".weight", hid);
+      const float* ob = tm.f32(hp + "obj_preds." + k + ".bias", 1);
+      const float* cw = tm.f32(hp + "cls_preds." + k + ".weight", hid);
+      const float* cb = tm.f32(hp + "cls_preds." + k + ".bias", 1);
+      if (!rw || !rb || !ow || !ob || !cw || !cb) return JN_ENOTFOUND;
+      std::vector<float> w6((size_t)6 * hid), b6(6);
+      std::copy(rw, rw + 4 * hid, w6.begin());
+      std::copy(ow, ow + hid, w6.begin() + 4 * hid);
+      std::copy(cw, cw + hid, w6.begin() + 5 * hid);
+      for (int i = 0; i < 4; ++i) b6[i] = rb[i];
+      b6[4] = ob[0]; b6[5] = cb[0];
+      int r;
+      if ((r = dev_upload(ctx, &net.pred_w[op.level], w6))) return r;
+      if ((r = dev_upload(ctx, &net.pred_b[op.level], b6))) return r;
+    }
     return JN_OK;
   };
   // arena order: [gpt_backbone | decision model] = what optim_gpt updates (gpt.py:552-557), then yolox.*
@@ -572,8 +593,9 @@ struct StemSrc {
 // One pass of a PAFPN over N patches in workspace slot `slot`.  train != 0: batch-statistics
 // BatchNorm (stats accumulated by every conv, finalised per layer, running stats updated).
 static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int train, const int* skip_flag,
-                   int skip_when, hipStream_t s) {
+                   int skip_when, hipStream_t s, bool with_head = false) {
   Net& net = ctx->nets[ni];
+  const int n_ops = (with_head || net.n_backbone_ops < 0) ? (int)net.ops.size() : net.n_backbone_ops;
   const int MB = ctx->cfg.max_batch;
   int rc;
   if (!train && (rc = refresh_eval_table(ctx, net, s))) return rc;
@@ -592,7 +614,8 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
                        cw.rvar_dev, save + 2 * cw.stat_off, tab(op.out), t1, cw.cout, kBnEps, kBnMomentum, skip_flag,
                        skip_when, s);
   };
-  for (const Op& op : net.ops) {
+  for (int oi = 0; oi < n_ops; ++oi) {
+    const Op& op = net.ops[oi];
     switch (op.kind) {
       case OP_STEM: {
         const ConvW& cw = net.convs[op.wslot];
@@ -604,8 +627,10 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
         break;
       }
       case OP_PW:
+      case OP_CONV3:
       case OP_DW: {
         const ConvW& cw = net.convs[op.wslot];
+        JN_CHECK(!(train && op.kind == OP_CONV3), JN_ESTATE, "train-mode dense 3x3 conv (%s) is not implemented", op.name.c_str());
         ConvArgs a{};
         a.in = ptr(op.in); a.in_ld = ld(op.in); a.itab = tab(op.in); a.w = cw.w_dev; a.bias = cw.b_dev;
         a.out = ptr(op.out); a.out_ld = ld(op.out);
@@ -614,7 +639,7 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
         a.stats = (train && cw.has_bn) ? stats + 2 * cw.stat_off : nullptr;
         a.stats_rep_stride = rep_stride;
         a.skip_flag = skip_flag; a.skip_when = skip_when;
-        if (op.kind == OP_PW) launch_pw(a, s); else launch_dw(a, s);
+        if (op.kind == OP_PW) launch_pw(a, s); else if (op.kind == OP_DW) launch_dw(a, s); else launch_conv3(a, s);
         finalize(op, cw);
         break;
       }
@@ -630,9 +655,11 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
         launch_addact(ptr(op.in), ld(op.in), tab(op.in), ptr(op.res), ld(op.res), tab(op.res), ptr(op.out), ld(op.out),
                       op.out.C, (long long)N * op.out.H * op.out.W, skip_flag, skip_when, s);
         break;
-      case OP_CONV3:
-        set_error("dense 3x3 conv (%s) is not implemented yet in this build", op.name.c_str());
-        return JN_ESTATE;
+      case OP_PRED:
+        launch_head_pred(ptr(op.in), ld(op.in), tab(op.in), ptr(op.res), ld(op.res), tab(op.res), net.pred_w[op.level],
+                         net.pred_b[op.level], ctx->det_raw, net.head_hid, op.in.H, op.in.W, op.stride, net.n_anchors,
+                         op.anchor0, N, s);
+        break;
     }
   }
   JN_HIP(hipGetLastError());
@@ -958,10 +985,32 @@ int jn_read_grad(jn_ctx* ctx, const char* name, float* host_out, size_t numel) {
   return JN_OK;
 }
 
-int jn_detect(jn_ctx* ctx, const float*, int, float*, int32_t*, float*, void*) {
-  (void)ctx;
-  set_error("jn_detect: detector head is not implemented yet in this build");
-  return JN_ESTATE;
+static int detect_impl(jn_ctx* ctx, const StemSrc& ss, int N, float* boxes_dev, int32_t* counts_dev, float* raw_dev,
+                       const int* skip_flag, int skip_when, hipStream_t s) {
+  Net& net = ctx->nets[JN_NET_DETECTOR];
+  int rc;
+  if (!ctx->det_raw)
+    if ((rc = dev_alloc(ctx, &ctx->det_raw, (size_t)ctx->cfg.max_batch * net.n_anchors * 6))) return rc;
+  if ((rc = run_net(ctx, JN_NET_DETECTOR, N, ss, 0, 0, skip_flag, skip_when, s, true))) return rc;
+  if (raw_dev)
+    JN_HIP(hipMemcpyAsync(raw_dev, ctx->det_raw, (size_t)N * net.n_anchors * 6 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (boxes_dev && counts_dev)
+    launch_postprocess(ctx->det_raw, net.n_anchors, N, ctx->cfg.det_conf_threshold, ctx->cfg.det_nms_threshold,
+                       (float)(ctx->cfg.patch_size - 1), boxes_dev, counts_dev, ctx->cfg.max_det_per_patch, s);
+  JN_HIP(hipGetLastError());
+  return JN_OK;
+}
+
+int jn_detect(jn_ctx* ctx, const float* patches_dev, int N, float* boxes_dev, int32_t* counts_dev, float* raw_dev,
+              void* stream) {
+  JN_CHECK(ctx && patches_dev, JN_EINVAL, "jn_detect: null argument");
+  JN_CHECK(ctx->has_net[JN_NET_DETECTOR], JN_ESTATE, "context was created without a detector");
+  JN_CHECK(ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
+  JN_CHECK(N >= 1 && N <= ctx->cfg.max_batch, JN_EINVAL, "N=%d exceeds max_batch=%d", N, ctx->cfg.max_batch);
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  const int P = ctx->cfg.patch_size;
+  StemSrc ss{patches_dev, nullptr, 3LL * P * P, (long long)P * P, P};
+  return detect_impl(ctx, ss, N, boxes_dev, counts_dev, raw_dev, nullptr, 0, (hipStream_t)stream);
 }
 
 // ---- environment ---------------------------------------------------------------------
@@ -1069,7 +1118,8 @@ static int rollout_impl(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev
   JN_CHECK(mode >= 0 && mode <= 2, JN_EINVAL, "unknown mode %d", mode);
   JN_CHECK(mode != JN_MODE_FORCED || forced_actions_dev, JN_EINVAL, "JN_MODE_FORCED needs forced_actions");
   JN_CHECK(out->rewards_dev && out->masks_dev, JN_EINVAL, "rewards_dev and masks_dev are required outputs");
-  JN_CHECK(!do_detection, JN_ESTATE, "do_detection: detector head is not implemented yet in this build");
+  JN_CHECK(!do_detection || (ctx->has_net[JN_NET_DETECTOR] && out->det_boxes_dev && out->det_counts_dev), JN_EINVAL,
+           "do_detection needs a detector and det_boxes_dev / det_counts_dev outputs");
   JN_HIP(hipSetDevice(ctx->cfg.device));
   hipStream_t s = (hipStream_t)stream;
   jn_ctx& x = *ctx;
@@ -1098,6 +1148,25 @@ static int rollout_impl(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev
   if (out->patches_dev)
     launch_gather(e.images, e.positions, out->patches_dev, patch_stride, B, 3, e.H, e.W, P, nullptr, 0, s);
 
+  const int Kd = c.max_det_per_patch;
+  if (do_detection) {
+    // src/reinforce.py:141-146 (start patch) — written for every image, see DESIGN.md deviations
+    JN_HIP(hipMemsetAsync(out->det_counts_dev, 0, (size_t)B * (T + 1) * sizeof(int32_t), s));
+    if (!ctx->det_tmp_boxes) {
+      int rc2;
+      if ((rc2 = dev_alloc(ctx, &ctx->det_tmp_boxes, (size_t)c.max_batch * Kd * 7))) return rc2;
+      if ((rc2 = dev_alloc(ctx, &ctx->det_tmp_counts, (size_t)c.max_batch))) return rc2;
+    }
+  }
+  auto detect_step = [&](int col, const int* flag) -> int {
+    StemSrc ds{e.images, e.positions, 3LL * e.H * e.W, (long long)e.H * e.W, e.W};
+    int r = detect_impl(ctx, ds, B, ctx->det_tmp_boxes, ctx->det_tmp_counts, nullptr, flag, B, s);
+    if (r) return r;
+    launch_det_scatter(ctx->det_tmp_boxes, ctx->det_tmp_counts, out->det_boxes_dev, out->det_counts_dev, B, T + 1, col, Kd,
+                       flag, B, s);
+    return JN_OK;
+  };
+  if (do_detection) { int r0 = detect_step(0, nullptr); if (r0) return r0; }
   if (ctx->profiling) {
     while ((int)ctx->conv_ev.size() < 2 * T) {
       hipEvent_t ev;
@@ -1147,6 +1216,7 @@ static int rollout_impl(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev
     if (out->patches_dev)
       launch_gather(e.images, e.positions, out->patches_dev + (long long)(t + 1) * 3 * P * P, patch_stride, B, 3, e.H, e.W,
                     P, flag, B, s);
+    if (do_detection && (rc = detect_step(t + 1, flag))) return rc;     // src/reinforce.py:162-167
   }
   launch_rollout_epilogue(r, ctx->n_done, B, T, stop_early ? 1 : 0, s);
   ctx->last_stop_early = stop_early != 0;

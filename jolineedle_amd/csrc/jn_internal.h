@@ -54,6 +54,7 @@ enum OpKind {
   OP_SPP,           // maxpool 5/9/13 of slice 0 into slices 1..3
   OP_UPSAMPLE,      // nearest x2 (raw values) into a slice
   OP_ADDACT,        // bottleneck shortcut: out = act(in) + act(res), materialised
+  OP_PRED,          // YOLOXHead predictors of one level + decode (in = reg_feat, res = cls_feat)
 };
 
 struct Op {
@@ -64,6 +65,7 @@ struct Op {
   int stride = 1;
   int act = ACT_SILU;
   int wslot = -1;           // index into Net::convs (packed weights)
+  int level = 0, anchor0 = 0;   // OP_PRED
   bool acc_in = false;      // backward: add into g[in] (another consumer, later in forward order, wrote it first)
   bool acc_res = false;     // backward: same for g[res]
   std::string name;         // module prefix, e.g. "backbone.dark2.0.dconv"
@@ -91,6 +93,10 @@ struct Net {
   std::vector<Op> ops;
   std::vector<ConvW> convs;
   View fpn[3];              // pan_out2, pan_out1, pan_out0
+  int n_backbone_ops = -1;  // ops before the detection head (-1: no head, all ops)
+  int n_anchors = 0, head_hid = 0;
+  float* pred_w[3] = {nullptr, nullptr, nullptr};   // [6][hid] reg(4), obj, cls predictor rows
+  float* pred_b[3] = {nullptr, nullptr, nullptr};   // [6]
   size_t per_image_floats = 0;
   std::vector<size_t> buf_off;    // per-image offset of each buffer (floats)
   std::vector<int> tab_off;       // first table channel of each buffer
@@ -178,6 +184,8 @@ struct jn_ctx {
   int32_t* found = nullptr;       // [B] visited bbox tiles
   float* ident = nullptr;         // identity table (scale 1, shift 0, flag 0) for gradient operands
   float* wpart = nullptr;         // [JN_NREP][JN_WPART_MAX] replicated weight-gradient partials (kept zero)
+  float* det_raw = nullptr;       // [B][A][6] decoded head output
+  float* det_tmp_boxes = nullptr; int32_t* det_tmp_counts = nullptr;   // one step's detections before the scatter
   float* tok_emb = nullptr;       // [B][T][C] patch embeddings of jn_gpt_forward
   jnr::EnvState env;
   // rollout workspaces

@@ -61,6 +61,16 @@ int launch_nhwc_to_nchw(const float* in, int in_ld, ChanTab it, float* out, int 
 int launch_efpn_linear(const float* e, const float* wt, float* part, int N, int K, int Co, int KS,
                        const int* skip_flag, int skip_when, hipStream_t s);
 
+// ---- detector (kernels_det.hip) --------------------------------------------------------------
+int launch_conv3(const ConvArgs& a, hipStream_t s);
+int launch_head_pred(const float* reg, int reg_ld, ChanTab rt, const float* cls, int cls_ld, ChanTab ct, const float* wp,
+                     const float* bp, float* raw, int hid, int Hl, int Wl, int stride, int A, int a0, int N,
+                     hipStream_t s);
+int launch_det_scatter(const float* boxes, const int* counts, float* out_boxes, int* out_counts, int B, int cols, int col,
+                       int K, const int* skip_flag, int skip_when, hipStream_t s);
+int launch_postprocess(const float* raw, int A, int N, float conf, float nms_thr, float clamp_max, float* boxes,
+                       int* counts, int max_out, hipStream_t s);
+
 // ---- backward of the conv stack (kernels_bwd.hip) ----------------------------------------
 int launch_bn_bwd_reduce(const float* g, int g_ld, const float* z, int z_ld, ChanTab t, const float* save, int C,
                          long long M, double* red_out, long long rep_stride, hipStream_t s);

@@ -1,0 +1,291 @@
+// Detector kernels (yolox-s style, non-depthwise): dense 3x3 conv on fp32 MFMA, the YOLOX head's
+// prediction convs fused with the box decode, and class-agnostic postprocess (threshold, sort, NMS).
+// Restated from the published YOLOX head / postprocess (reference call sites
+// src/models/yolox.py:55, 77-86, 93-113).
+#include <hip/hip_runtime.h>
+
+#include "jn_kernels.h"
+
+namespace jnr {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ float silu_d(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+__device__ __forceinline__ f32x4 tf4_d(f32x4 z, f32x4 sc, f32x4 sh, f32x4 fl) {
+  f32x4 r;
+  r.x = fl.x != 0.0f ? silu_d(fmaf(z.x, sc.x, sh.x)) : z.x;
+  r.y = fl.y != 0.0f ? silu_d(fmaf(z.y, sc.y, sh.y)) : z.y;
+  r.z = fl.z != 0.0f ? silu_d(fmaf(z.z, sc.z, sh.z)) : z.z;
+  r.w = fl.w != 0.0f ? silu_d(fmaf(z.w, sc.w, sh.w)) : z.w;
+  return r;
+}
+
+// ------------------------------------------------------------------------------------
+// dense 3x3 conv (pad 1, stride S): z[m][n] = sum_tap sum_k T(x[m (+) tap][k]) * w[tap][n][k]
+// im2col-free: nine shifted 1x1 GEMMs over ONE LDS halo tile per K chunk.
+// Workgroup = 8 x 16 output pixels x 64 channels; wave = 2 rows x 16 pixels; K chunk = 16.
+// ------------------------------------------------------------------------------------
+constexpr int C3_TH = 8, C3_TW = 16, C3_KC = 16, C3_LD = C3_KC + 4, C3_BN = 64;
+
+template <int S>
+__global__ __launch_bounds__(256) void conv3_mfma_kernel(const float* __restrict__ x, int x_ld, ChanTab it,
+                                                         const float* __restrict__ w, float* __restrict__ out,
+                                                         int out_ld, int H, int W, int OH, int OW, int K, int Nc,
+                                                         int tiles_x, int tiles_y, const int* __restrict__ skip_flag,
+                                                         int skip_when) {
+  if (skip_flag && *skip_flag >= skip_when) return;
+  constexpr int IH = C3_TH * S + 2, IW = C3_TW * S + 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;                              // [IH*IW][C3_LD]
+  float* Ws = smem + IH * IW * C3_LD;            // [9][C3_BN][C3_LD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x % (tiles_x * tiles_y);
+  const int n_img = blockIdx.x / (tiles_x * tiles_y);
+  const int oy0 = (tile / tiles_x) * C3_TH, ox0 = (tile % tiles_x) * C3_TW;
+  const int n0 = blockIdx.y * C3_BN;
+  const float* xb = x + (long long)n_img * H * W * x_ld;
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += C3_KC) {
+    if (k0) __syncthreads();
+    for (int i = tid; i < IH * IW * 4; i += 256) {
+      const int pix = i >> 2, q = i & 3;
+      const int iy = oy0 * S - 1 + pix / IW, ix = ox0 * S - 1 + pix % IW;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+        const int kk = k0 + 4 * q;
+        v = tf4_d(*reinterpret_cast<const f32x4*>(xb + ((long long)iy * W + ix) * x_ld + kk),
+                  *reinterpret_cast<const f32x4*>(it.sc + kk), *reinterpret_cast<const f32x4*>(it.sh + kk),
+                  *reinterpret_cast<const f32x4*>(it.fl + kk));
+      }
+      *reinterpret_cast<f32x4*>(Xs + pix * C3_LD + 4 * q) = v;
+    }
+    for (int i = tid; i < 9 * C3_BN * 4; i += 256) {
+      const int q = i & 3, r = (i >> 2) % C3_BN, tp = i / (4 * C3_BN);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n0 + r < Nc) v = *reinterpret_cast<const f32x4*>(w + ((long long)tp * Nc + n0 + r) * K + k0 + 4 * q);
+      *reinterpret_cast<f32x4*>(Ws + (tp * C3_BN + r) * C3_LD + 4 * q) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      const int ky = tp / 3, kx = tp % 3;
+      f32x4 xb0 = *reinterpret_cast<const f32x4*>(Xs + (((2 * wave) * S + ky) * IW + lm * S + kx) * C3_LD + 4 * g);
+      f32x4 xb1 = *reinterpret_cast<const f32x4*>(Xs + (((2 * wave + 1) * S + ky) * IW + lm * S + kx) * C3_LD + 4 * g);
+      f32x4 wa[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wa[c] = *reinterpret_cast<const f32x4*>(Ws + (tp * C3_BN + 16 * c + lm) * C3_LD + 4 * g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][j], xb0[j], acc[0][c], 0, 0, 0);
+          acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][j], xb1[j], acc[1][c], 0, 0, 0);
+        }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int oy = oy0 + 2 * wave + p, ox = ox0 + lm;
+    if (oy >= OH || ox >= OW) continue;
+    float* op = out + (((long long)n_img * OH + oy) * OW + ox) * out_ld;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int n = n0 + 16 * c + 4 * g;
+      if (n < Nc) *reinterpret_cast<f32x4*>(op + n) = acc[p][c];
+    }
+  }
+}
+
+int launch_conv3(const ConvArgs& a, hipStream_t s) {
+  const int tiles_x = (a.OW + C3_TW - 1) / C3_TW, tiles_y = (a.OH + C3_TH - 1) / C3_TH;
+  dim3 grid(tiles_x * tiles_y * a.N, (a.cout + C3_BN - 1) / C3_BN);
+  if (a.stride == 1) {
+    const size_t smem = ((size_t)(C3_TH + 2) * (C3_TW + 2) + 9 * C3_BN) * C3_LD * sizeof(float);
+    hipLaunchKernelGGL(conv3_mfma_kernel<1>, grid, dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.out, a.out_ld, a.H,
+                       a.W, a.OH, a.OW, a.cin, a.cout, tiles_x, tiles_y, a.skip_flag, a.skip_when);
+  } else {
+    const size_t smem = ((size_t)(2 * C3_TH + 2) * (2 * C3_TW + 2) + 9 * C3_BN) * C3_LD * sizeof(float);
+    static bool attr_set = false;      // 95 KB of the CU's 160 KB LDS: above the 64 KB default cap
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_mfma_kernel<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3_mfma_kernel<2>, grid, dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.out, a.out_ld, a.H,
+                       a.W, a.OH, a.OW, a.cin, a.cout, tiles_x, tiles_y, a.skip_flag, a.skip_when);
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// YOLOXHead predictors of one level + decode: raw[n][a0 + p][0..5] =
+//   ((reg_xy + grid) * stride, exp(reg_wh) * stride, sigmoid(obj), sigmoid(cls))
+// wp = [6][hid]: rows 0-3 reg_pred, 4 obj_pred (both read reg_feat), 5 cls_pred (reads cls_feat); bp[6].
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_pred_kernel(const float* __restrict__ reg, int reg_ld, ChanTab rt,
+                                                        const float* __restrict__ cls, int cls_ld, ChanTab ct,
+                                                        const float* __restrict__ wp, const float* __restrict__ bp,
+                                                        float* __restrict__ raw, int hid, int Hl, int Wl, int stride,
+                                                        int A, int a0, int N) {
+  extern __shared__ float sw[];     // [6][hid] + tables
+  for (int i = threadIdx.x; i < 6 * hid; i += 256) sw[i] = wp[i];
+  __syncthreads();
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)N * Hl * Wl) return;
+  const int p = (int)(idx % (Hl * Wl));
+  const long long n = idx / (Hl * Wl);
+  const float* rp = reg + idx * reg_ld;
+  const float* cp = cls + idx * cls_ld;
+  float o[6] = {bp[0], bp[1], bp[2], bp[3], bp[4], bp[5]};
+  for (int k = 0; k < hid; k += 4) {
+    const f32x4 rv = tf4_d(*reinterpret_cast<const f32x4*>(rp + k), *reinterpret_cast<const f32x4*>(rt.sc + k),
+                           *reinterpret_cast<const f32x4*>(rt.sh + k), *reinterpret_cast<const f32x4*>(rt.fl + k));
+    const f32x4 cv = tf4_d(*reinterpret_cast<const f32x4*>(cp + k), *reinterpret_cast<const f32x4*>(ct.sc + k),
+                           *reinterpret_cast<const f32x4*>(ct.sh + k), *reinterpret_cast<const f32x4*>(ct.fl + k));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) o[j] = fmaf(rv[q], sw[j * hid + k + q], o[j]);
+      o[5] = fmaf(cv[q], sw[5 * hid + k + q], o[5]);
+    }
+  }
+  const int gy = p / Wl, gx = p % Wl;
+  float* dst = raw + (n * A + a0 + p) * 6;
+  dst[0] = (o[0] + (float)gx) * (float)stride;
+  dst[1] = (o[1] + (float)gy) * (float)stride;
+  dst[2] = expf(o[2]) * (float)stride;
+  dst[3] = expf(o[3]) * (float)stride;
+  dst[4] = 1.0f / (1.0f + expf(-o[4]));
+  dst[5] = 1.0f / (1.0f + expf(-o[5]));
+}
+
+int launch_head_pred(const float* reg, int reg_ld, ChanTab rt, const float* cls, int cls_ld, ChanTab ct, const float* wp,
+                     const float* bp, float* raw, int hid, int Hl, int Wl, int stride, int A, int a0, int N,
+                     hipStream_t s) {
+  const long long total = (long long)N * Hl * Wl;
+  hipLaunchKernelGGL(head_pred_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), (size_t)6 * hid * sizeof(float), s,
+                     reg, reg_ld, rt, cls, cls_ld, ct, wp, bp, raw, hid, Hl, Wl, stride, A, a0, N);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------
+// postprocess (class-agnostic, one class): cxcywh -> xyxy, keep obj*cls >= conf, sort by score
+// (descending, ties by anchor index), greedy NMS (IoU > thr suppressed), clamp to [0, P-1].
+// One workgroup per patch; candidates live in LDS (cap DET_CAP, lowest anchor indices kept).
+// ------------------------------------------------------------------------------------
+constexpr int DET_CAP = 2048;
+
+__global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ raw, int A, float conf, float nms_thr,
+                                                          float clamp_max, float* __restrict__ boxes,
+                                                          int* __restrict__ counts, int max_out) {
+  __shared__ float sc[DET_CAP];
+  __shared__ int id[DET_CAP];
+  __shared__ unsigned char dead[DET_CAP];
+  __shared__ int s_n, s_keep;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float* r = raw + (long long)n * A * 6;
+  if (tid == 0) { s_n = 0; s_keep = 0; }
+  __syncthreads();
+  // ordered compaction, chunk by chunk so that lower anchor indices win the cap
+  for (int base = 0; base < A; base += 256) {
+    const int a = base + tid;
+    float score = -1.0f;
+    if (a < A) score = r[a * 6 + 4] * r[a * 6 + 5];
+    const bool ok = a < A && score >= conf;
+    const unsigned long long m = __ballot(ok);
+    __shared__ int wave_cnt[4];
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane == 0) wave_cnt[wv] = __popcll(m);
+    __syncthreads();
+    int off = s_n;
+    for (int w2 = 0; w2 < wv; ++w2) off += wave_cnt[w2];
+    off += __popcll(m & ((1ull << lane) - 1ull));
+    if (ok && off < DET_CAP) { sc[off] = score; id[off] = a; }
+    __syncthreads();
+    if (tid == 0) s_n = min(DET_CAP, s_n + wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
+    __syncthreads();
+  }
+  const int cnt = s_n;
+  // bitonic sort on (score desc, index asc)
+  int np2 = 1;
+  while (np2 < cnt) np2 <<= 1;
+  for (int i = cnt + tid; i < np2; i += 256) { sc[i] = -INFINITY; id[i] = 0x7fffffff; }
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < np2; i += 256) {
+        const int l = i ^ j;
+        if (l > i) {
+          const bool up = (i & k) == 0;
+          const bool before = sc[i] > sc[l] || (sc[i] == sc[l] && id[i] < id[l]);   // i should precede l
+          if (up ? !before : before) {
+            const float ts = sc[i]; sc[i] = sc[l]; sc[l] = ts;
+            const int ti = id[i]; id[i] = id[l]; id[l] = ti;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  for (int i = tid; i < cnt; i += 256) dead[i] = 0;
+  __syncthreads();
+  for (int i = 0; i < cnt; ++i) {
+    if (dead[i]) continue;                          // uniform: dead[] is shared and synced
+    const float* bi = r + id[i] * 6;
+    const float ax1 = bi[0] - bi[2] * 0.5f, ay1 = bi[1] - bi[3] * 0.5f, ax2 = bi[0] + bi[2] * 0.5f, ay2 = bi[1] + bi[3] * 0.5f;
+    const float aa = (ax2 - ax1) * (ay2 - ay1);
+    if (tid == 0) {
+      const int kidx = s_keep;
+      if (kidx < max_out) {
+        float* o = boxes + ((long long)n * max_out + kidx) * 7;
+        o[0] = fminf(fmaxf(ax1, 0.0f), clamp_max); o[1] = fminf(fmaxf(ay1, 0.0f), clamp_max);
+        o[2] = fminf(fmaxf(ax2, 0.0f), clamp_max); o[3] = fminf(fmaxf(ay2, 0.0f), clamp_max);
+        o[4] = bi[4]; o[5] = bi[5]; o[6] = 0.0f;
+      }
+      s_keep = kidx + 1;
+    }
+    for (int j = i + 1 + tid; j < cnt; j += 256) {
+      if (dead[j]) continue;
+      const float* bj = r + id[j] * 6;
+      const float bx1 = bj[0] - bj[2] * 0.5f, by1 = bj[1] - bj[3] * 0.5f, bx2 = bj[0] + bj[2] * 0.5f, by2 = bj[1] + bj[3] * 0.5f;
+      const float iw = fmaxf(fminf(ax2, bx2) - fmaxf(ax1, bx1), 0.0f), ih = fmaxf(fminf(ay2, by2) - fmaxf(ay1, by1), 0.0f);
+      const float inter = iw * ih;
+      const float iou = inter / (aa + (bx2 - bx1) * (by2 - by1) - inter);
+      if (iou > nms_thr) dead[j] = 1;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) counts[n] = min(s_keep, max_out);
+}
+
+int launch_postprocess(const float* raw, int A, int N, float conf, float nms_thr, float clamp_max, float* boxes,
+                       int* counts, int max_out, hipStream_t s) {
+  hipLaunchKernelGGL(postprocess_kernel, dim3(N), dim3(256), 0, s, raw, A, conf, nms_thr, clamp_max, boxes, counts,
+                     max_out);
+  return 0;
+}
+
+// boxes [B][K][7] / counts [B] of one glimpse step -> column `col` of [B][cols][K][7] / [B][cols]
+__global__ void det_scatter_kernel(const float* __restrict__ boxes, const int* __restrict__ counts,
+                                   float* __restrict__ out_boxes, int* __restrict__ out_counts, int B, int cols, int col,
+                                   int K, const int* __restrict__ skip_flag, int skip_when) {
+  if (skip_flag && *skip_flag >= skip_when) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * K * 7) return;
+  const int b = i / (K * 7), r = i % (K * 7);
+  out_boxes[((long long)b * cols + col) * K * 7 + r] = (r / 7 < counts[b]) ? boxes[i] : 0.0f;
+  if (r == 0) out_counts[b * cols + col] = counts[b];
+}
+
+int launch_det_scatter(const float* boxes, const int* counts, float* out_boxes, int* out_counts, int B, int cols, int col,
+                       int K, const int* skip_flag, int skip_when, hipStream_t s) {
+  hipLaunchKernelGGL(det_scatter_kernel, dim3((B * K * 7 + 255) / 256), dim3(256), 0, s, boxes, counts, out_boxes,
+                     out_counts, B, cols, col, K, skip_flag, skip_when);
+  return 0;
+}
+
+}  // namespace jnr

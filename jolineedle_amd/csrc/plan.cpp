@@ -17,7 +17,7 @@ namespace {
 struct Builder {
   Net& net;
   std::vector<ParamEntry>& params;
-  const std::string mod_prefix;   // state-dict prefix of this net ("gpt_backbone.")
+  std::string mod_prefix;         // state-dict prefix of the part being built ("gpt_backbone.", "yolox.head.")
 
   int new_buf(int H, int W, int C) {
     Buf b; b.H = H; b.W = W; b.C = C;
@@ -218,7 +218,7 @@ int build_pafpn(Net& net, std::vector<ParamEntry>& params, const std::string& pr
     Op& op = *it;
     int rc = JN_OK;
     switch (op.kind) {
-      case OP_STEM: break;
+      case OP_STEM: case OP_PRED: break;
       case OP_SPP: op.acc_in = true; break;                       // adds into slice 0, written by the cat consumer
       case OP_ADDACT:
         if ((rc = mark(op.in, op.acc_in, "in", op.name))) return rc;
@@ -231,34 +231,50 @@ int build_pafpn(Net& net, std::vector<ParamEntry>& params, const std::string& pr
   return JN_OK;
 }
 
-// YOLOXHead parameters ("yolox.head.*"), listed for state-dict compatibility; the op plan
-// of the head is built by the detector module.
-void add_head_params(std::vector<ParamEntry>& params, std::vector<ConvW>& convs, const std::string& prefix,
-                     float width, bool depthwise, int num_classes) {
-  Net dummy; dummy.depthwise = depthwise;
-  Builder b{dummy, params, prefix};
+// YOLOXHead (inference branch) appended to the detector's op list: per level stem 1x1, two 3x3
+// convs per branch, and one OP_PRED (the three predictor convs + decode).  State-dict names
+// follow upstream ("yolox.head.stems.0.conv.weight", "yolox.head.cls_preds.0.bias", ...).
+int build_head(Net& net, std::vector<ParamEntry>& params, const std::string& prefix, float width, bool depthwise,
+               int num_classes) {
+  JN_CHECK(num_classes == 1, JN_EINVAL, "the needle detector has one class");
+  Builder b{net, params, prefix};
+  net.n_backbone_ops = (int)net.ops.size();
   const int hid = (int)(256 * width);
-  const int in_ch[3] = {(int)(256 * width), (int)(512 * width), (int)(1024 * width)};
-  auto conv_params = [&](const std::string& name, int cin, int cout) {
-    if (depthwise) {
-      b.add_conv(name + ".dconv", cin, cin, 3, cin, true, false);
-      b.add_conv(name + ".pconv", cin, cout, 1, 1, true, false);
-    } else {
-      b.add_conv(name, cin, cout, 3, 1, true, false);
-    }
-  };
+  const int strides[3] = {8, 16, 32};
+  int a0 = 0;
   for (int k = 0; k < 3; ++k) {
     const std::string s = std::to_string(k);
-    conv_params("cls_convs." + s + ".0", hid, hid);
-    conv_params("cls_convs." + s + ".1", hid, hid);
-    conv_params("reg_convs." + s + ".0", hid, hid);
-    conv_params("reg_convs." + s + ".1", hid, hid);
-    b.add_conv("cls_preds." + s, hid, num_classes, 1, 1, false, true);
-    b.add_conv("reg_preds." + s, hid, 4, 1, 1, false, true);
-    b.add_conv("obj_preds." + s, hid, 1, 1, 1, false, true);
-    b.add_conv("stems." + s, in_ch[k], hid, 1, 1, true, false);
+    View x = b.base_conv("stems." + s, net.fpn[k], hid, 1, 1, false);
+    View c = b.conv("cls_convs." + s + ".0", x, hid, 3, 1);
+    c = b.conv("cls_convs." + s + ".1", c, hid, 3, 1);
+    View r = b.conv("reg_convs." + s + ".0", x, hid, 3, 1);
+    r = b.conv("reg_convs." + s + ".1", r, hid, 3, 1);
+    Op op; op.kind = OP_PRED; op.in = r; op.res = c; op.act = ACT_NONE; op.name = "preds." + s;
+    op.stride = strides[k]; op.level = k; op.anchor0 = a0;
+    b.add_param(prefix + "cls_preds." + s + ".weight", {num_classes, hid, 1, 1}, 0, false, true);
+    b.add_param(prefix + "cls_preds." + s + ".bias", {num_classes}, 0, false, true);
+    b.add_param(prefix + "reg_preds." + s + ".weight", {4, hid, 1, 1}, 0, false, true);
+    b.add_param(prefix + "reg_preds." + s + ".bias", {4}, 0, false, true);
+    b.add_param(prefix + "obj_preds." + s + ".weight", {1, hid, 1, 1}, 0, false, true);
+    b.add_param(prefix + "obj_preds." + s + ".bias", {1}, 0, false, true);
+    net.ops.push_back(op);
+    a0 += r.H * r.W;
   }
-  convs = dummy.convs;
+  net.n_anchors = a0;
+  net.head_hid = hid;
+  // buffer / table / stats offsets grew with the head
+  net.buf_off.resize(net.bufs.size());
+  size_t off = 0;
+  for (size_t i = 0; i < net.bufs.size(); ++i) { net.buf_off[i] = off; off += (net.bufs[i].per_image() + 63) / 64 * 64; }
+  net.per_image_floats = off;
+  net.tab_off.resize(net.bufs.size());
+  int toff = 0;
+  for (size_t i = 0; i < net.bufs.size(); ++i) { net.tab_off[i] = toff; toff += net.bufs[i].C; }
+  net.tab_channels = (toff + 3) / 4 * 4;
+  int soff = 0;
+  for (auto& cw : net.convs) { cw.stat_off = soff; soff += cw.cout; }
+  net.stat_channels = soff;
+  return JN_OK;
 }
 
 }  // namespace jnr

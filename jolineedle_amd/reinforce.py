@@ -75,6 +75,11 @@ class ReinforceTrainer:
         for k, t in buf.items():
             setattr(out, k + "_dev", t.data_ptr())
         out.patches_dev = patches.data_ptr() if patches is not None else None
+        Kd = eng.cfg.max_det_per_patch
+        if do_detection:
+            det_boxes = torch.zeros((B, T + 1, Kd, 7), **f32)
+            det_counts = torch.zeros((B, T + 1), device=dev, dtype=torch.int32)
+            out.det_boxes_dev, out.det_counts_dev = det_boxes.data_ptr(), det_counts.data_ptr()
         if forced_actions is not None:
             mode = _lib.JN_MODE_FORCED
             forced_actions = forced_actions.to(dev, torch.int64).contiguous()
@@ -95,10 +100,15 @@ class ReinforceTrainer:
             "logprobs": buf["logprobs"][:, :S], "entropies": buf["entropies"][:, :S],
             "masks": buf["masks"][:, :S + 1].bool(), "logit_masks": buf["logit_masks"][:, :S].bool(),
             "positions": buf["positions"][:, :S + 1], "bboxes": [[] for _ in range(B)],
+            "det_counts": det_counts[:, :S + 1] if do_detection else None,
             "patches": patches[:, :S + 1] if patches is not None else None,
             "actions": buf["actions"][:, :S], "logits": buf["logits"][:, :S],
             "final_emb": buf["final_emb"][:, :S + 1],
         }
+        if do_detection:                      # ragged list-of-lists of [n,7] | None (src/reinforce.py:145-146, 166-167)
+            cnt = det_counts[:, :S + 1].tolist()
+            res["bboxes"] = [[det_boxes[b, t, :cnt[b][t]].clone() if cnt[b][t] > 0 else None for t in range(S + 1)]
+                             for b in range(B)]
         return res
 
     # ---- training: one REINFORCE iteration (src/reinforce.py:302-353) ------------------------

@@ -479,3 +479,150 @@ def test_optimizer_step_matches_adamw_with_clip():
         ref_upd = (p.detach() - before[name])[sig]
         assert torch.allclose(got_upd, ref_upd, atol=5e-5), (name, (got_upd - ref_upd).abs().max())
         assert ref_upd.abs().max() > 5e-4
+
+
+# --------------------------------------------------------------------------------------
+# detector: yolox-s PAFPN + head + decode + postprocess/NMS
+# --------------------------------------------------------------------------------------
+def _gap_threshold(scores, k):
+    """A threshold in a wide gap of the sorted scores near rank k (robust to 1e-7 score noise)."""
+    v = torch.unique(scores.flatten()).flip(0)          # distinct values, descending
+    k = min(k, len(v) - 20)
+    best, arg = 0.0, k
+    for i in range(max(1, k - 15), min(len(v) - 1, k + 15)):
+        gap = float(v[i] - v[i + 1]) / float(v[i])
+        if gap > best:
+            best, arg = gap, i
+    assert best > 1e-5
+    return float((v[arg] + v[arg + 1]) / 2)
+
+
+def _same_boxes(got, ref, tol):
+    """Same rows up to reordering of near-tied scores: every got row pairs with an unused ref row whose
+    score is within 1e-3 and whose (clamped) box is within tol."""
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    used = set()
+    gs, rs = got[:, 4] * got[:, 5], ref[:, 4] * ref[:, 5]
+    for i in range(got.shape[0]):
+        cand = [j for j in range(ref.shape[0]) if j not in used and abs(float(gs[i] - rs[j])) < 1e-3]
+        assert cand, i
+        d = torch.stack([(got[i, :4] - ref[j, :4]).abs().sum() for j in cand])
+        k = int(d.argmin())
+        assert float(d[k]) < tol, (i, float(d[k]))
+        assert (got[i, 4:] - ref[cand[k], 4:]).abs().max() < 1e-3      # obj / cls probabilities (north star 1e-3)
+        used.add(cand[k])
+
+
+def _blocky_images(N, P, seed):
+    """Spatially varied content (random-resolution blocks + noise): white-noise images give almost
+    position-independent features and thousands of tied scores."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.zeros(N, 3, P, P)
+    for r in (4, 8, 16):
+        x += torch.nn.functional.interpolate(torch.rand(N, 3, P // r, P // r, generator=g), size=(P, P), mode="nearest")
+    return (x / 3 + 0.1 * torch.rand(N, 3, P, P, generator=g)).clamp(0, 1)
+
+
+def _detector_pair(P, thr, image_processor="yolox-s", max_batch=4, seed=9, calib=None):
+    product, oracle = make_pair(seed, patch_size=P, block_size=4, image_processor=image_processor,
+                                detector_conf_threshold=thr, max_batch=max_batch, max_det_per_patch=512)
+    if calib is not None:                       # BN running statistics of real activations (signal survives the depth)
+        bns = [m for m in oracle.yolox.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        for m in bns:
+            m.momentum = 1.0
+        oracle.yolox.train()
+        with torch.no_grad():
+            f = oracle.yolox.backbone(calib)
+            h = oracle.yolox.head
+            for k in range(3):
+                t = h.stems[k](f[k]); h.cls_convs[k](t); h.reg_convs[k](t)
+        oracle.yolox.eval()
+        for m in bns:
+            m.momentum = 0.03
+    with torch.no_grad():                       # spread the scores (default-init predictors are almost constant)
+        for k in range(3):
+            oracle.yolox.head.cls_preds[k].weight.mul_(40.0 if calib is None else 3.0)
+            oracle.yolox.head.obj_preds[k].weight.mul_(40.0 if calib is None else 3.0)
+            oracle.yolox.head.reg_preds[k].weight.mul_(8.0 if calib is None else 2.0)
+    product.load_state_dict(oracle.state_dict())
+    return product, oracle
+
+
+@pytest.mark.parametrize("P,ip", [(64, "yolox-s"), (448, "yolox-s"), (96, "yolox-nano")])
+def test_detector_backbone_and_raw_head(P, ip):
+    product, oracle = _detector_pair(P, 0.5, ip)
+    x = torch.rand((2, 3, P, P), generator=torch.Generator().manual_seed(P))
+    with torch.no_grad():
+        fpn = oracle.yolox.backbone(x)
+        raw = oracle.yolox.head(fpn)                       # [N, A, 6] decoded
+    got_fpn = product.backbone_features(x, net=_lib.JN_NET_DETECTOR)
+    for i in range(3):
+        assert (got_fpn[i].cpu() - fpn[i]).abs().max() < 5e-4, i
+    eng = product.engine()
+    A = raw.shape[1]
+    got_raw = torch.empty((2, A, 6), device=DEV)
+    boxes = torch.zeros((2, eng.cfg.max_det_per_patch, 7), device=DEV)
+    counts = torch.zeros(2, device=DEV, dtype=torch.int32)
+    check(eng.lib.jn_detect(eng.handle, ptr(x.to(DEV)), 2, ptr(boxes), ptr(counts), ptr(got_raw),
+                            _lib.current_stream(torch.device(DEV))), "jn_detect")
+    torch.cuda.synchronize()
+    assert A == sum((P // s) ** 2 for s in (8, 16, 32))
+    assert (got_raw.cpu()[..., :4] - raw[..., :4]).abs().max() < 1e-3 * max(1.0, P / 64)   # boxes, pixels
+    assert (got_raw.cpu()[..., 4:] - raw[..., 4:]).abs().max() < 1e-5                      # obj / cls probabilities
+
+
+@pytest.mark.parametrize("P,keep", [(64, 20), (448, 40)])
+def test_detector_postprocess_nms_vs_oracle(P, keep):
+    """NeedleYOLOX.forward inference branch: threshold + NMS + clamp; ragged outputs incl. None."""
+    from oracle import yolox_ref
+    x = _blocky_images(3, P, P + 7)
+    _, oracle0 = _detector_pair(P, 0.5, calib=x)
+    with torch.no_grad():
+        raw = oracle0.yolox.head(oracle0.yolox.backbone(x))
+    thr = _gap_threshold(raw[..., 4] * raw[..., 5], 3 * keep)                  # ~keep survivors per patch
+    product, oracle = _detector_pair(P, thr, calib=x)
+    thr2 = float((raw[2, :, 4] * raw[2, :, 5]).max()) * 1.01
+    with torch.no_grad():
+        ref_out, ref_fpn, _ = oracle.yolox(x)
+    out, fpn_outs, losses = product.yolox(x)
+    assert losses == {} and len(out) == 3 and len(fpn_outs) == 3
+    for b in range(3):
+        if ref_out[b] is None:
+            assert out[b] is None
+            continue
+        got, ref = out[b].cpu(), ref_out[b]
+        assert ref.shape[0] <= product.engine().cfg.max_det_per_patch
+        _same_boxes(got, ref, 1e-3 * P)       # L1 over 4 coords: 2.5e-4 of the patch size per coordinate
+        assert got[:, :4].min() >= 0 and got[:, :4].max() <= P - 1
+    # a threshold above every score -> the reference's None
+    product2, _ = _detector_pair(P, min(max(thr2, 0.5), 0.9999), calib=x)
+    out2, _, _ = product2.yolox(x[2:3])
+    assert out2 == [None]
+
+
+def test_rollout_with_detection_vs_oracle():
+    from oracle import env_ref, rollout_ref
+    P, Tn, B = 64, 3, 2
+    images, bboxes, start = synth_batch(B, 3, 3, P, seed=8)
+    images = _blocky_images(B, 3 * P, 8)
+    calib = images[:, :, :P, :P].contiguous()
+    _, oracle0 = _detector_pair(P, 0.5, max_batch=B, calib=calib)
+    with torch.no_grad():
+        raw = oracle0.yolox.head(oracle0.yolox.backbone(images[:, :, :P, :P]))
+    thr = _gap_threshold(raw[..., 4] * raw[..., 5], 30)
+    product, oracle = _detector_pair(P, thr, max_batch=B, calib=calib)
+    forced = torch.tensor([[1, 3, 0], [3, 1, 2]])
+    with torch.no_grad():
+        ref = rollout_ref.rollout(oracle, env_ref.EnvRef(images, bboxes, P, Tn, 1, True), do_detection=True,
+                                  forced_actions=forced, start_positions=start)
+    env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True)
+    ro = ja.ReinforceTrainer(_cfg(T=Tn), product).rollout(env, do_detection=True, forced_actions=forced,
+                                                           start_positions=start)
+    assert torch.equal(ro["positions"].cpu(), ref["positions"])
+    for b in range(B):
+        assert len(ro["bboxes"][b]) == len(ref["bboxes"][b]) == Tn + 1
+        for t in range(Tn + 1):
+            r, g = ref["bboxes"][b][t], ro["bboxes"][b][t]
+            assert (r is None) == (g is None), (b, t)
+            if r is not None:
+                _same_boxes(g.cpu(), r, 1e-3 * P)
