@@ -34,6 +34,9 @@ sys.path.insert(0, str(ROOT))
 # BN+SiLU fused, concat/upsample/focus free: 17.44 M elements per patch, fp32 storage.
 NANO_448_ELEMS_PER_PATCH = 17.44e6
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+# HBM traffic of ONE forward conv-stack pass at B=64, 448 px from the PMC counters (separate --pmc FETCH_SIZE and
+# --pmc WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM): profiles/r01_c_pmc_conv_stack_traffic.txt
+PMC_TRAFFIC_BYTES_B64_448 = 5.581e9
 
 
 def synth_inputs(B, G, P, seed, device):
@@ -109,13 +112,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    if os.environ.get("JN_BENCH_SAME_DEVICE"):                    # rehearsal: all ranks share GPU 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("JN_BENCH_BACKEND", "nccl")      # "gloo" only for single-GPU rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import jolineedle_amd as ja
     from tests.helpers import model_config
@@ -197,7 +206,8 @@ def main():
                                                    + ("/bn_finalize, train-mode BN" if train else "") +
                                                    "), one pass over the batch per glimpse step",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": (PMC_TRAFFIC_BYTES_B64_448 if (B, P) == (64, 448) else None),
                          "ms_per_launch": round(conv_ms_per_launch, 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes)},
         }
