@@ -170,7 +170,6 @@ __global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const float* __restr
   const int n0 = blockIdx.y * 16 * CTN, k0 = blockIdx.z * 16 * CTK;
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-  for (int i = tid; i < 256 * CTN * CTK; i += 256) Ts[i] = 0.0f;
   f32x4 acc[CTN][CTK];
 #pragma unroll
   for (int a = 0; a < CTN; ++a)
@@ -208,13 +207,22 @@ __global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const float* __restr
         for (int b = 0; b < CTK; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
     }
   }
-  __syncthreads();
+  // cross-wave sum of the four partial tiles: one wave at a time, plain LDS read-modify-write
+  // (LDS float atomics cost ~3x the whole kernel here: ds_add_f32 with 4-way bank conflicts)
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
 #pragma unroll
-  for (int a = 0; a < CTN; ++a)
+      for (int a = 0; a < CTN; ++a)
 #pragma unroll
-    for (int b = 0; b < CTK; ++b)
+        for (int b = 0; b < CTK; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&Ts[(16 * a + 4 * g + r) * (16 * CTK) + 16 * b + lm], acc[a][b][r]);
+          for (int r = 0; r < 4; ++r) {
+            float* tp = &Ts[(16 * a + 4 * g + r) * (16 * CTK) + 16 * b + lm];
+            *tp = (w == 0 ? 0.0f : *tp) + acc[a][b][r];
+          }
+    }
+  }
   __syncthreads();
   float* dst = rep ? gw + (blockIdx.x % JN_NREP) * JN_WPART_MAX : gw;
   for (int i = tid; i < 256 * CTN * CTK; i += 256) {
@@ -353,10 +361,17 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
       }
     }
     }
+    // lanes l, l + C4, l + 2*C4, ... of a wave hold the same channel group: butterfly-sum them first so that
+    // only C4 lanes per wave touch the (slow) LDS float atomics
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) atomicAdd(&red[t * C + c + q], dw[t][q]);
+      for (int q = 0; q < 4; ++q) {
+        float v = dw[t][q];
+        for (int off = C4; off < 64; off <<= 1) v += __shfl_xor(v, off);
+        if (lane < C4) atomicAdd(&red[t * C + c + q], v);
+      }
   }
   __syncthreads();
   float* dst = rep ? gw + (blockIdx.x % JN_NREP) * JN_WPART_MAX : gw;

@@ -176,6 +176,8 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(
   const int YS = (OH + 3) >> 2;
   const long long total = (long long)N * YS * OW * C4;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  const int cstat = (int)(idx % C4) * 4;
   if (idx < total) {
     const int c4 = (int)(idx % C4);
     const int ox = (int)((idx / C4) % OW);
@@ -211,7 +213,6 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(
       }
     }
     float* ob = out + (long long)n * OH * OW * out_ld + c;
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int oy = oy0 + j;
@@ -221,15 +222,18 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(
         s2 += acc[j] * acc[j];
       }
     }
-    if (stats) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        atomicAdd(&red[2 * (c + q)], s1[q]);
-        atomicAdd(&red[2 * (c + q) + 1], s2[q]);
-      }
-    }
   }
   if (stats) {
+    const int lane = threadIdx.x & 63;         // lanes l, l + C4, ... share the channel group: butterfly first
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float a = s1[q], b = s2[q];
+      for (int off = C4; off < 64; off <<= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+      if (lane < C4) {
+        atomicAdd(&red[2 * (cstat + q)], a);
+        atomicAdd(&red[2 * (cstat + q) + 1], b);
+      }
+    }
     __syncthreads();
     double* st = stats + (blockIdx.x % JN_NREP) * rep_stride;
     for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&st[i], (double)red[i]);
