@@ -44,12 +44,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   const int rstep = 256 / C4;
   const long long r0 = (long long)blockIdx.x * rows_per_block;
   const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-  if ((int)(threadIdx.x / C4) < rstep) {
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  const bool active = (int)(threadIdx.x / C4) < rstep;
+  if (active) {
     const f32x4 sc = *reinterpret_cast<const f32x4*>(t.sc + c), sh = *reinterpret_cast<const f32x4*>(t.sh + c);
     f32x4 mean, istd;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { mean[q] = save[2 * (c + q)]; istd[q] = save[2 * (c + q) + 1]; }
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     for (long long m = r0 + threadIdx.x / C4; m < r1; m += rstep) {
       const f32x4 gv = *reinterpret_cast<const f32x4*>(g + m * g_ld + c);
       const f32x4 zv = *reinterpret_cast<const f32x4*>(z + m * z_ld + c);
@@ -60,6 +61,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         s2[q] += gy * (zv[q] - mean[q]) * istd[q];
       }
     }
+  }
+  if ((C4 & (C4 - 1)) == 0) {
+    // power-of-two channel groups: lanes l, l + C4, ... hold the same channels -> butterfly, then C4 lanes add
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float a = s1[q], b = s2[q];
+      for (int off = C4; off < 64; off <<= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+      if (lane < C4) {
+        atomicAdd(&red[2 * (c + q)], a);
+        atomicAdd(&red[2 * (c + q) + 1], b);
+      }
+    }
+  } else if (active) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       atomicAdd(&red[2 * (c + q)], s1[q]);

@@ -263,87 +263,119 @@ constexpr int PW_BM = 128;     // pixels per workgroup (4 waves x 2 tiles of 16)
 
 // WT: `w` is stored [K][Nc] (the forward weight of the layer whose data-gradient is computed) and is
 // read transposed; accumulate: out += result (gradient buffers with several contributors).
-template <int CT, int PW_KC, bool WT>
+// WM = waves along the pixel dimension: 4 -> 128 pixels x 16*CT channels per workgroup, every wave all
+// channel tiles; 2 -> 64 pixels, the two wave pairs split the channel tiles (more workgroups for the
+// 14x14 / 28x28 layers).  K chunks are software-pipelined: chunk i+1 is fetched into registers while
+// the MFMAs of chunk i run.
+template <int CT, int PW_KC, bool WT, int WM>
 __global__ __launch_bounds__(256) void pw_mfma_kernel(
     const float* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, int out_ld, long long M, int K, int Nc, int act, int accumulate,
     double* __restrict__ stats, long long rep_stride, const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
   constexpr int PW_LD = PW_KC + 4;        // K chunk staged in LDS (+4 floats: bank spread, 16-B rows)
+  constexpr int BM = 32 * WM;             // pixels per workgroup
+  constexpr int CTW = CT * WM / 4;        // channel tiles per wave
+  constexpr int NX = BM * (PW_KC / 4) / 256, NW = (16 * CT * (PW_KC / 4) + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Xs = smem;                       // [PW_BM][PW_LD]
-  float* Ws = smem + PW_BM * PW_LD;       // [16*CT][PW_LD]
+  float* Xs = smem;                       // [BM][PW_LD]
+  float* Ws = smem + BM * PW_LD;          // [16*CT][PW_LD]
   float* red = Ws + 16 * CT * PW_LD;      // [16*CT][2]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
   const int lm = lane & 15, g = lane >> 4;
-  const long long m0 = (long long)blockIdx.x * PW_BM;
+  const long long m0 = (long long)blockIdx.x * BM;
   const int n0 = blockIdx.y * (16 * CT);
   if (stats && tid < 32 * CT) red[tid] = 0.0f;
 
-  f32x4 acc[2][CT];
+  f32x4 acc[2][CTW];
 #pragma unroll
   for (int p = 0; p < 2; ++p)
 #pragma unroll
-    for (int c = 0; c < CT; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < CTW; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int k0 = 0; k0 < K; k0 += PW_KC) {
-    const int kc = (K - k0 < PW_KC) ? (K - k0) : PW_KC;   // multiple of 16
-    const int q4 = kc >> 2;
-    if (k0) __syncthreads();
-    for (int i = tid; i < PW_BM * q4; i += 256) {
-      const int r = i / q4, q = i - r * q4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m0 + r < M) {
-        const int kk = k0 + 4 * q;
-        v = tf4(*reinterpret_cast<const f32x4*>(x + (m0 + r) * x_ld + kk), *reinterpret_cast<const f32x4*>(it.sc + kk),
-                *reinterpret_cast<const f32x4*>(it.sh + kk), *reinterpret_cast<const f32x4*>(it.fl + kk));
-      }
-      *reinterpret_cast<f32x4*>(Xs + r * PW_LD + 4 * q) = v;
+  f32x4 xr[NX], wr[NW];
+  auto fetch = [&](int k0) {
+    const int kc = (K - k0 < PW_KC) ? (K - k0) : PW_KC, q4 = kc >> 2;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int i = tid + 256 * j, r = i / q4, q = i - r * q4;
+      xr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < BM * q4 && m0 + r < M) xr[j] = *reinterpret_cast<const f32x4*>(x + (m0 + r) * x_ld + k0 + 4 * q);
     }
-    for (int i = tid; i < 16 * CT * q4; i += 256) {
-      const int r = i / q4, q = i - r * q4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (n0 + r < Nc) {
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int i = tid + 256 * j, r = i / q4, q = i - r * q4;
+      wr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < 16 * CT * q4 && n0 + r < Nc) {
         if (WT) {
           const float* wp = w + (long long)(k0 + 4 * q) * Nc + n0 + r;
-          v = f32x4{wp[0], wp[Nc], wp[2 * Nc], wp[3 * Nc]};
+          wr[j] = f32x4{wp[0], wp[Nc], wp[2 * Nc], wp[3 * Nc]};
         } else {
-          v = *reinterpret_cast<const f32x4*>(w + (long long)(n0 + r) * K + k0 + 4 * q);
+          wr[j] = *reinterpret_cast<const f32x4*>(w + (long long)(n0 + r) * K + k0 + 4 * q);
         }
       }
-      *reinterpret_cast<f32x4*>(Ws + r * PW_LD + 4 * q) = v;
     }
+  };
+  auto stage = [&](int k0) {
+    const int kc = (K - k0 < PW_KC) ? (K - k0) : PW_KC, q4 = kc >> 2;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int i = tid + 256 * j, r = i / q4, q = i - r * q4;
+      if (i < BM * q4) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m0 + r < M) {
+          const int kk = k0 + 4 * q;
+          v = tf4(xr[j], *reinterpret_cast<const f32x4*>(it.sc + kk), *reinterpret_cast<const f32x4*>(it.sh + kk),
+                  *reinterpret_cast<const f32x4*>(it.fl + kk));
+        }
+        *reinterpret_cast<f32x4*>(Xs + r * PW_LD + 4 * q) = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int i = tid + 256 * j, r = i / q4, q = i - r * q4;
+      if (i < 16 * CT * q4) *reinterpret_cast<f32x4*>(Ws + r * PW_LD + 4 * q) = wr[j];
+    }
+  };
+
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += PW_KC) {
+    const int kc = (K - k0 < PW_KC) ? (K - k0) : PW_KC;   // multiple of 16
+    if (k0) __syncthreads();
+    stage(k0);
     __syncthreads();
-    const float* xrow0 = Xs + (wave * 32 + lm) * PW_LD + 4 * g;
+    if (k0 + PW_KC < K) fetch(k0 + PW_KC);
+    const float* xrow0 = Xs + (wm * 32 + lm) * PW_LD + 4 * g;
     const float* xrow1 = xrow0 + 16 * PW_LD;
-    const float* wrow = Ws + lm * PW_LD + 4 * g;
+    const float* wrow = Ws + (wn * CTW * 16 + lm) * PW_LD + 4 * g;
     for (int kk = 0; kk < kc; kk += 16) {
       const f32x4 xb0 = *reinterpret_cast<const f32x4*>(xrow0 + kk);
       const f32x4 xb1 = *reinterpret_cast<const f32x4*>(xrow1 + kk);
-      f32x4 wa[CT];
+      f32x4 wa[CTW];
 #pragma unroll
-      for (int c = 0; c < CT; ++c) wa[c] = *reinterpret_cast<const f32x4*>(wrow + c * 16 * PW_LD + kk);
+      for (int c = 0; c < CTW; ++c) wa[c] = *reinterpret_cast<const f32x4*>(wrow + c * 16 * PW_LD + kk);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
+        for (int c = 0; c < CTW; ++c) {
           acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][j], xb0[j], acc[0][c], 0, 0, 0);
           acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][j], xb1[j], acc[1][c], 0, 0, 0);
         }
       }
     }
   }
-  f32x4 s1[CT], s2[CT];
+  f32x4 s1[CTW], s2[CTW];
 #pragma unroll
-  for (int c = 0; c < CT; ++c) { s1[c] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[c] = s1[c]; }
+  for (int c = 0; c < CTW; ++c) { s1[c] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[c] = s1[c]; }
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
-    const long long m = m0 + wave * 32 + p * 16 + lm;
+    const long long m = m0 + wm * 32 + p * 16 + lm;
     if (m >= M) continue;
 #pragma unroll
-    for (int c = 0; c < CT; ++c) {
-      const int n = n0 + c * 16 + 4 * g;
+    for (int c = 0; c < CTW; ++c) {
+      const int n = n0 + (wn * CTW + c) * 16 + 4 * g;
       if (n >= Nc) continue;
       f32x4 v = acc[p][c];
       if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
@@ -355,26 +387,36 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
     }
   }
   if (stats) {
-    wave_stats_to_lds<CT>(s1, s2, red, lane, Nc - n0);
+    wave_stats_to_lds<CTW>(s1, s2, red + 2 * (wn * CTW * 16), lane, Nc - n0 - wn * CTW * 16);
     __syncthreads();
     if (tid < 32 * CT && n0 + (tid >> 1) < Nc)
       atomicAdd(&stats[(blockIdx.x % JN_NREP) * rep_stride + 2 * n0 + tid], (double)red[tid]);
   }
 }
 
+template <int CT, bool WT, int WM>
+static void launch_pw_cfg(const ConvArgs& a, long long M, hipStream_t s) {
+  constexpr int KC = (CT > 4) ? 32 : 64;
+  constexpr int BM = 32 * WM;
+  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.cout + 16 * CT - 1) / (16 * CT)));
+  const size_t smem = ((size_t)(BM + 16 * CT) * (KC + 4) + 32 * CT) * sizeof(float);
+  hipLaunchKernelGGL((pw_mfma_kernel<CT, KC, WT, WM>), grid, dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.bias,
+                     a.out, a.out_ld, M, a.cin, a.cout, a.act, a.accumulate, a.stats, a.stats_rep_stride, a.skip_flag,
+                     a.skip_when);
+}
+
 template <int CT>
 static void launch_pw_ct(const ConvArgs& a, long long M, hipStream_t s) {
-  constexpr int KC = (CT > 4) ? 32 : 64;
-  dim3 grid((unsigned)((M + PW_BM - 1) / PW_BM), (unsigned)((a.cout + 16 * CT - 1) / (16 * CT)));
-  const size_t smem = ((size_t)(PW_BM + 16 * CT) * (KC + 4) + 32 * CT) * sizeof(float);
-  if (a.w_transposed)
-    hipLaunchKernelGGL((pw_mfma_kernel<CT, KC, true>), grid, dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.bias,
-                       a.out, a.out_ld, M, a.cin, a.cout, a.act, a.accumulate, a.stats, a.stats_rep_stride, a.skip_flag,
-                       a.skip_when);
-  else
-    hipLaunchKernelGGL((pw_mfma_kernel<CT, KC, false>), grid, dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.bias,
-                       a.out, a.out_ld, M, a.cin, a.cout, a.act, a.accumulate, a.stats, a.stats_rep_stride, a.skip_flag,
-                       a.skip_when);
+  // few pixels (14x14 / 28x28 maps): 64-pixel workgroups double the workgroup count
+  constexpr bool can_split = (CT % 2 == 0);
+  const bool small_m = M <= 65536;
+  if (a.w_transposed) {
+    if (can_split && small_m) launch_pw_cfg<CT, true, can_split ? 2 : 4>(a, M, s);
+    else launch_pw_cfg<CT, true, 4>(a, M, s);
+  } else {
+    if (can_split && small_m) launch_pw_cfg<CT, false, can_split ? 2 : 4>(a, M, s);
+    else launch_pw_cfg<CT, false, 4>(a, M, s);
+  }
 }
 
 int launch_pw(const ConvArgs& a, hipStream_t s) {
