@@ -185,6 +185,16 @@ typedef struct jn_train_opts {
 int jn_reinforce_step(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev,
                       const int64_t* start_positions_dev, uint64_t seed, int stop_early,
                       const jn_train_opts* opts, const jn_rollout_out* out, float* metrics_dev, void* stream);
+/* One supervised (teacher-forced) step minus the optimiser: SupervisedTrainer.run body
+ * (src/supervised.py:863-902) with the detector term off.  patches [B,T,3,P,P], current_actions /
+ * next_actions [B,T] int64, positions [B,T,2] int64, masks [B,T] u8 (1 = token, 0 = padding); B*T <=
+ * max_batch.  GPT.forward runs on the full sequence in train mode (BatchNorm statistics over the B*T
+ * patches), loss = CrossEntropy(weight[STOP] = stop_weight, reduction none) averaged over non-padding
+ * tokens (:138-177); gradients ACCUMULATE in the arena.  logits_out_dev [B,T,n_actions] optional;
+ * metrics_dev[4] = action_loss, action_accuracy, episode_length. */
+int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* current_actions_dev,
+                       const int64_t* next_actions_dev, const int64_t* positions_dev, const uint8_t* masks_dev,
+                       int B, int T, float stop_weight, float* logits_out_dev, float* metrics_dev, void* stream);
 /* clip_grad_value_(clip_value) + AdamW (torch defaults) over the optim_gpt parameters
  * (src/reinforce.py:344-346, src/models/gpt.py:552-557); grad_scale multiplies the gradients first
  * (1/world_size after a SUM all-reduce). */

@@ -13,6 +13,7 @@ from .gpt import GPT  # noqa: F401
 from .env import NeedleGeneralEnv  # noqa: F401
 from .yolox import NeedleYOLOX  # noqa: F401
 from .reinforce import ReinforceTrainer  # noqa: F401
+from .supervised import SupervisedTrainer  # noqa: F401
 
-__all__ = ["GPT", "NeedleYOLOX", "NeedleGeneralEnv", "ReinforceTrainer", "Action", "ACTION_DELTAS",
+__all__ = ["GPT", "NeedleYOLOX", "NeedleGeneralEnv", "ReinforceTrainer", "SupervisedTrainer", "Action", "ACTION_DELTAS",
            "ActionInfo", "get_actions_info", "CfgNode", "get_args", "args_to_config", "load_library"]

@@ -79,6 +79,8 @@ SIGNATURES = {
     "jn_embed_patches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "jn_reinforce_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,
                                     C.POINTER(JnTrainOpts), C.POINTER(JnRolloutOut), C.c_void_p, C.c_void_p]),
+    "jn_supervised_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "jn_optimizer_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "jn_arena_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "jn_set_grad_arena": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -1311,7 +1311,8 @@ int jn_reinforce_step(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, 
   ba.use_pos_emb = c.use_pos_emb; ba.no_patch_emb = c.no_patch_emb; ba.concat_emb = c.concat_emb;
   ba.dec_pos_enc = c.decoder_pos_encoding; ba.pe2_ch = (int)std::ceil(C / 4.0) * 2;
   ba.n_done = ctx->n_done; ba.final_emb = out->final_emb_dev; ba.dlogits = ctx->dlogits; ba.actions = out->actions_dev;
-  ba.positions = out->positions_dev; ba.tok_emb = ctx->tok_emb_train; ba.d_tok_emb = ctx->d_tok_emb;
+  ba.positions = out->positions_dev; ba.pos_tokens = T + 1; ba.pos1d_by_token = 0; ba.tok_actions = nullptr;
+  ba.tok_emb = ctx->tok_emb_train; ba.d_tok_emb = ctx->d_tok_emb;
   ba.wte = g.wte; ba.wpe = g.wpe; ba.proj_wt = g.proj_wt; ba.pos1d = g.pos1d; ba.pe2 = g.pos2d_col; ba.head_wt = g.head_wt;
   ba.lnf_w = g.lnf_w; ba.lnf_b = g.lnf_b; ba.layers = ctx->layers_dev; ba.g_layers = ctx->g_layers_dev;
   ba.g_wte = grad_of(ctx, g.wte); ba.g_wpe = g.wpe ? grad_of(ctx, g.wpe) : nullptr;
@@ -1350,6 +1351,113 @@ int jn_reinforce_step(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, 
     if ((rc = run_net_backward(ctx, ctx->enc_net, B, ss, slot, s))) return rc;
   }
   (void)P;
+  JN_HIP(hipGetLastError());
+  return JN_OK;
+}
+
+// One supervised (teacher-forced) training step minus the optimiser: src/supervised.py:863-902 with the
+// detector term off.  GPT.forward on the full sequence (B*T patches through the encoder in ONE train-mode
+// pass, 1-D positions 0..T-1), CrossEntropy(weight[STOP] = stop_weight) over non-padding tokens, backward.
+int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* current_actions_dev,
+                       const int64_t* next_actions_dev, const int64_t* positions_dev, const uint8_t* masks_dev, int B,
+                       int T, float stop_weight, float* logits_out_dev, float* metrics_dev, void* stream) {
+  JN_CHECK(ctx && patches_dev && current_actions_dev && next_actions_dev && masks_dev && metrics_dev, JN_EINVAL,
+           "jn_supervised_step: null argument");
+  JN_CHECK(ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
+  const jn_config& c = ctx->cfg;
+  JN_CHECK(!c.no_patch_emb, JN_ESTATE, "training without a patch encoder is not supported");
+  JN_CHECK(T >= 1 && T <= c.block_size && c.block_size <= 62, JN_EINVAL, "sequence length %d out of range", T);
+  JN_CHECK(B >= 1 && B * T <= c.max_batch, JN_EINVAL, "B*T = %d patches exceed max_batch = %d", B * T, c.max_batch);
+  JN_CHECK(!c.use_pos_emb || positions_dev, JN_EINVAL, "positions are required when use_pos_emb is set");
+  JN_HIP(hipSetDevice(c.device));
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if ((rc = ensure_train_state(ctx))) return rc;
+  if ((rc = build_grad_layer_table(ctx))) return rc;
+  const int C = c.n_embd, nA = c.n_actions, P = c.patch_size, N = B * T, L = T + 1;
+  const int HW = ctx->efpn_h * ctx->efpn_w, K = HW * C;
+  if (!ctx->efpn_train) {
+    const size_t MBt = (size_t)c.max_batch * c.block_size;
+    if ((rc = dev_alloc(ctx, &ctx->efpn_train, MBt * HW * C))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->tok_emb_train, MBt * C))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_tok_emb, MBt * C))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->dlogits, MBt * nA))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->de_ws, (size_t)c.max_batch * HW * C))) return rc;
+  }
+  if (!ctx->sup_final_emb) {
+    if ((rc = dev_alloc(ctx, &ctx->sup_final_emb, (size_t)c.max_batch * (c.block_size + 1) * C))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->sup_logits, (size_t)c.max_batch * c.block_size * nA))) return rc;
+  }
+  // ---- forward: encoder over all B*T patches at once (BN statistics over B*T) ----
+  Net& net = ctx->nets[ctx->enc_net];
+  StemSrc ss{patches_dev, nullptr, 3LL * P * P, (long long)P * P, P};
+  if ((rc = run_net(ctx, ctx->enc_net, N, ss, 0, 1, nullptr, 0, s))) return rc;
+  if ((rc = run_embed_fpn(ctx, N, 0, ctx->efpn_train, nullptr, 0, s))) return rc;
+  hipLaunchKernelGGL(emb_finish_kernel, dim3((N * C + 255) / 256), dim3(256), 0, s, ctx->emb_part, ctx->gpt.efpn_lin_b,
+                     ctx->tok_emb_train, (long long)C, N, ctx->KS, C);
+  JN_HIP(hipMemsetAsync(ctx->cache_len, 0, (size_t)B * sizeof(int32_t), s));
+  GptStepArgs a{};
+  fill_gpt_weights(ctx, a);
+  a.B = B; a.T = L; a.emb_stride = L; a.out.final_emb = ctx->sup_final_emb; a.logits_stride = T * nA;
+  for (int tok = 0; tok < L; ++tok) {
+    a.step = tok;
+    a.logits_rows = tok >= 1 ? ctx->sup_logits + (size_t)(tok - 1) * nA : nullptr;
+    if (tok == 0) {
+      a.src_mode = GPT_SRC_CLASS;
+    } else {
+      a.src_mode = GPT_SRC_TEACH;
+      a.t_actions = current_actions_dev; a.t_positions = positions_dev; a.t_stride = T; a.t_index = tok - 1;
+      a.pos_index = tok - 1;
+      a.tok_emb = ctx->tok_emb_train; a.tok_emb_stride = T; a.tok_emb_index = tok - 1;
+    }
+    launch_gpt_step(a, s);
+  }
+  if (logits_out_dev)
+    JN_HIP(hipMemcpyAsync(logits_out_dev, ctx->sup_logits, (size_t)N * nA * sizeof(float), hipMemcpyDeviceToDevice, s));
+  // ---- loss + backward ----
+  launch_ce_loss(ctx->sup_logits, next_actions_dev, masks_dev, stop_weight, ctx->dlogits, metrics_dev, N, nA, T, s);
+  const int nL = c.n_layer, nh = c.n_head;
+  const long long per_agent = (long long)(nL + 1) * L * C + (long long)nL * (11LL * L * C + (long long)nh * L * L) +
+                              12LL * L * C + (long long)nh * L * L + 4LL * C + 64;
+  if (!ctx->gpt_bwd_scratch || ctx->gpt_bwd_scratch_floats < (size_t)per_agent * c.max_batch) {
+    if ((rc = dev_alloc(ctx, &ctx->gpt_bwd_scratch, (size_t)per_agent * c.max_batch))) return rc;
+    ctx->gpt_bwd_scratch_floats = (size_t)per_agent * c.max_batch;
+  }
+  const GptW& g = ctx->gpt;
+  GptBwdArgs ba{};
+  ba.C = C; ba.n_head = nh; ba.n_layer = nL; ba.nA = nA; ba.B = B; ba.T = T; ba.stop_early = 0;
+  ba.use_pos_emb = c.use_pos_emb; ba.no_patch_emb = c.no_patch_emb; ba.concat_emb = c.concat_emb;
+  ba.dec_pos_enc = c.decoder_pos_encoding; ba.pe2_ch = (int)std::ceil(C / 4.0) * 2;
+  ba.n_done = ctx->n_done; ba.final_emb = ctx->sup_final_emb; ba.dlogits = ctx->dlogits; ba.actions = current_actions_dev;
+  ba.tok_actions = current_actions_dev; ba.positions = positions_dev; ba.pos_tokens = T; ba.pos1d_by_token = 1;
+  ba.tok_emb = ctx->tok_emb_train; ba.d_tok_emb = ctx->d_tok_emb;
+  ba.wte = g.wte; ba.wpe = g.wpe; ba.proj_wt = g.proj_wt; ba.pos1d = g.pos1d; ba.pe2 = g.pos2d_col; ba.head_wt = g.head_wt;
+  ba.lnf_w = g.lnf_w; ba.lnf_b = g.lnf_b; ba.layers = ctx->layers_dev; ba.g_layers = ctx->g_layers_dev;
+  ba.g_wte = grad_of(ctx, g.wte); ba.g_wpe = g.wpe ? grad_of(ctx, g.wpe) : nullptr;
+  ba.g_embed_class = grad_of(ctx, g.embed_class);
+  ba.g_proj_wt = g.proj_wt ? grad_of(ctx, g.proj_wt) : nullptr; ba.g_proj_b = g.proj_b ? grad_of(ctx, g.proj_b) : nullptr;
+  ba.g_head_wt = grad_of(ctx, g.head_wt); ba.g_lnf_w = grad_of(ctx, g.lnf_w); ba.g_lnf_b = grad_of(ctx, g.lnf_b);
+  ba.scratch = ctx->gpt_bwd_scratch; ba.scratch_per_agent = per_agent;
+  launch_gpt_backward(ba, s);
+  const int MB = c.max_batch;
+  const View& f2 = net.fpn[2];
+  const ChanTab ident{ctx->ident, ctx->ident + 2048, ctx->ident + 4096};
+  launch_efpn_linear_bwd(ctx->efpn_train, g.efpn_lin_wt, ctx->d_tok_emb, (long long)C, ctx->de_ws,
+                         grad_of(ctx, g.efpn_lin_wt), grad_of(ctx, g.efpn_lin_b), N, K, C, s);
+  float* g_f2 = net.gact + net.buf_off[f2.buf] * (size_t)MB + f2.coff;
+  ConvArgs ca{};
+  ca.in = ctx->de_ws; ca.in_ld = C; ca.itab = ident; ca.w = g.efpn_w; ca.bias = nullptr;
+  ca.out = g_f2; ca.out_ld = net.bufs[f2.buf].C;
+  ca.N = N; ca.H = f2.H; ca.W = f2.W; ca.OH = f2.H; ca.OW = f2.W; ca.cin = C; ca.cout = f2.C; ca.stride = 1; ca.act = ACT_NONE;
+  ca.accumulate = 0; ca.w_transposed = 1;
+  launch_pw(ca, s);
+  launch_pw_bwd_weight(ctx->de_ws, C, view_ptr(net, 0, MB, f2), net.bufs[f2.buf].C, view_tab(net, 0, f2),
+                       grad_of(ctx, g.efpn_w), ctx->wpart, (long long)N * HW, C, f2.C, s);
+  for (int i = 0; i < 2; ++i) {
+    const View& f = net.fpn[i];
+    JN_HIP(hipMemsetAsync(net.gact + net.buf_off[f.buf] * (size_t)MB + f.coff, 0, (size_t)N * f.H * f.W * f.C * sizeof(float), s));
+  }
+  if ((rc = run_net_backward(ctx, ctx->enc_net, N, ss, 0, s))) return rc;
   JN_HIP(hipGetLastError());
   return JN_OK;
 }

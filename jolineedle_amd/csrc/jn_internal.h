@@ -168,6 +168,7 @@ struct jn_ctx {
   float* d_tok_emb = nullptr;     // [B][T][C] their gradients
   float* dlogits = nullptr;       // [B][T][nA]
   float* de_ws = nullptr;         // [B][h*w*C] gradient of embed_fpn.0 activations (one step)
+  float* sup_final_emb = nullptr; float* sup_logits = nullptr;   // supervised step: [B][T+1][C], [B][T][nA]
   float* gpt_bwd_scratch = nullptr; size_t gpt_bwd_scratch_floats = 0;
   std::vector<jnr::ParamSeg> segs;
   std::map<std::string, int> seg_index;

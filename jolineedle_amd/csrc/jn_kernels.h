@@ -178,8 +178,11 @@ struct GptBwdArgs {
   const int32_t* n_done;
   const float* final_emb;           // [B][T+1][C]
   const float* dlogits;             // [B][T][nA]
-  const int64_t* actions;           // [B][T]
-  const int64_t* positions;         // [B][T+1][2]
+  const int64_t* actions;           // [B][T] actions taken (rollout)
+  const int64_t* tok_actions;       // [B][T] action token of every patch token (teacher-forced mode) or null
+  const int64_t* positions;         // [B][pos_tokens][2]
+  int pos_tokens;                   // T + 1 (rollout history) or T
+  int pos1d_by_token;               // 1: token t has 1-D position t (full-sequence forward)
   const float* tok_emb;             // [B][T][C] patch embeddings
   float* d_tok_emb;                 // [B][T][C] out
   const float *wte, *wpe, *proj_wt, *pos1d, *pe2, *head_wt, *lnf_w, *lnf_b;
@@ -189,6 +192,8 @@ struct GptBwdArgs {
   float* scratch; long long scratch_per_agent;
 };
 int launch_gpt_backward(const GptBwdArgs& a, hipStream_t s);
+int launch_ce_loss(const float* logits, const int64_t* target, const uint8_t* masks, float stop_weight, float* dlogits,
+                   float* metrics, int n, int nA, int T, hipStream_t s);
 int launch_efpn_linear_bwd(const float* e, const float* wt, const float* dpe, long long dpe_stride, float* de,
                            float* gwt, float* gb, int N, int K, int Co, hipStream_t s);
 int launch_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,

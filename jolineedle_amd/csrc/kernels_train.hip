@@ -84,6 +84,58 @@ int launch_reinforce_loss(const LossArgs& a, hipStream_t s) {
   return 0;
 }
 
+// ---- supervised loss (src/supervised.py:138-177): CrossEntropyLoss(weight, reduction="none") averaged over
+// the non-padding tokens; dlogits = w[y] * (softmax - onehot) / n_valid --------------------------------
+__global__ __launch_bounds__(TB) void ce_loss_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
+                                                     const unsigned char* __restrict__ masks, float stop_weight,
+                                                     float* __restrict__ dlogits, float* __restrict__ metrics, int n,
+                                                     int nA, int T) {
+  __shared__ float red[TB];
+  __shared__ float tot[3];
+  const int tid = threadIdx.x;
+  float cnt = 0.0f;
+  for (int i = tid; i < n; i += TB) cnt += masks[i] ? 1.0f : 0.0f;
+  red[tid] = cnt; __syncthreads();
+  for (int o = TB / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  const float nvalid = red[0];
+  __syncthreads();
+  float ls = 0.0f, acc = 0.0f;
+  for (int i = tid; i < n; i += TB) {
+    float* dl = dlogits + (long long)i * nA;
+    if (!masks[i]) { for (int j = 0; j < nA; ++j) dl[j] = 0.0f; continue; }
+    const float* lg = logits + (long long)i * nA;
+    float mx = -INFINITY; int best = 0;
+    for (int j = 0; j < nA; ++j) if (lg[j] > mx) { mx = lg[j]; best = j; }
+    float se = 0.0f;
+    for (int j = 0; j < nA; ++j) se += expf(lg[j] - mx);
+    const float lse = mx + logf(se);
+    int y = (int)target[i];
+    y = min(max(y, 0), nA - 1);
+    const float wy = (y == 8) ? stop_weight : 1.0f;
+    for (int j = 0; j < nA; ++j) dl[j] = wy * (expf(lg[j] - lse) - (j == y ? 1.0f : 0.0f)) / nvalid;
+    ls += -wy * (lg[y] - lse);
+    acc += (best == y) ? 1.0f : 0.0f;
+  }
+  red[tid] = ls; __syncthreads();
+  for (int o = TB / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  if (tid == 0) tot[0] = red[0];
+  __syncthreads();
+  red[tid] = acc; __syncthreads();
+  for (int o = TB / 2; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  if (tid == 0) {
+    metrics[0] = tot[0] / nvalid;            // action_loss (= loss without the detector term)
+    metrics[1] = red[0] / nvalid;            // action_accuracy
+    metrics[2] = nvalid / (n / T);           // episode_length
+  }
+}
+
+int launch_ce_loss(const float* logits, const int64_t* target, const uint8_t* masks, float stop_weight, float* dlogits,
+                   float* metrics, int n, int nA, int T, hipStream_t s) {
+  hipLaunchKernelGGL(ce_loss_kernel, dim3(1), dim3(TB), 0, s, logits, (const long long*)target, masks, stop_weight, dlogits,
+                     metrics, n, nA, T);
+  return 0;
+}
+
 // ---- helpers on per-agent global scratch (all threads of the block, barrier at the end) --------
 __device__ __forceinline__ void lin_fwd(float* out, const float* in, const float* __restrict__ wt,
                                         const float* __restrict__ b, int L, int K, int N) {
@@ -392,13 +444,17 @@ __global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
   for (int c = tid; c < C; c += TB) atomicAdd(&a.g_embed_class[c], dX[c]);          // class token id 0
   for (int i = 1; i < L; ++i) {
     const int t = i - 1;
-    const int act = (i == 1) ? 0 : (int)a.actions[(long long)b * a.T + (i - 2)];
-    const int row = (int)a.positions[((long long)b * (a.T + 1) + t) * 2];
-    const int col = (int)a.positions[((long long)b * (a.T + 1) + t) * 2 + 1];
+    // rollout: token i carries the action taken BEFORE its patch (BOS = 0); teacher-forced full sequence:
+    // current_actions[b][t] (src/supervised.py:863-868)
+    const int act = a.tok_actions ? (int)a.tok_actions[(long long)b * a.T + t]
+                                  : ((i == 1) ? 0 : (int)a.actions[(long long)b * a.T + (i - 2)]);
+    const int row = (int)a.positions[((long long)b * a.pos_tokens + t) * 2];
+    const int col = (int)a.positions[((long long)b * a.pos_tokens + t) * 2 + 1];
     int p = 0;
     for (int c = tid; c < C; c += TB) PARTS[c] = a.wte[act * C + c];
     ++p;
-    for (int c = tid; c < C; c += TB) PARTS[p * C + c] = a.dec_pos_enc ? a.pos1d[c] : a.wpe[c];
+    const int p1 = a.pos1d_by_token ? t : 0;            // recurrent tokens: 1-D position 0 (gpt.py:431-449)
+    for (int c = tid; c < C; c += TB) PARTS[p * C + c] = a.dec_pos_enc ? a.pos1d[p1 * C + c] : a.wpe[p1 * C + c];
     const int p_pos = p; ++p;
     int p_patch = -1, p_pos2 = -1;
     if (!a.no_patch_emb) {
@@ -429,7 +485,7 @@ __global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
     __syncthreads();
     for (int c = tid; c < C; c += TB) atomicAdd(&a.g_wte[act * C + c], dparts[c]);
     if (!a.dec_pos_enc && a.g_wpe)
-      for (int c = tid; c < C; c += TB) atomicAdd(&a.g_wpe[c], dparts[p_pos * C + c]);
+      for (int c = tid; c < C; c += TB) atomicAdd(&a.g_wpe[p1 * C + c], dparts[p_pos * C + c]);
     if (p_patch >= 0)
       for (int c = tid; c < C; c += TB) a.d_tok_emb[((long long)b * a.T + t) * C + c] = dparts[p_patch * C + c];
     (void)p_pos2;

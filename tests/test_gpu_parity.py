@@ -626,3 +626,46 @@ def test_rollout_with_detection_vs_oracle():
             assert (r is None) == (g is None), (b, t)
             if r is not None:
                 _same_boxes(g.cpu(), r, 1e-3 * P)
+
+
+# --------------------------------------------------------------------------------------
+# supervised teacher-forced step (BASELINE configs 1-2)
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,T,P,stop_w", [(2, 4, 64, 0.1), (4, 8, 64, 1.0)])
+def test_supervised_step_vs_oracle(B, T, P, stop_w):
+    product, oracle = make_pair(13, patch_size=P, block_size=T, with_detector=False, image_processor=None,
+                                max_batch=B * T)
+    patches, cur, positions = synth_tokens(B, T, P, 9, 5, seed=21)
+    g = torch.Generator().manual_seed(4)
+    nxt = torch.randint(0, 9, (B, T), generator=g)
+    nxt[0, 1] = 8                                             # a STOP target exercises the class weight
+    masks = torch.ones((B, T), dtype=torch.long)
+    masks[1, T - 2:] = 0                                      # padded tail
+    oracle.train()
+    oracle.zero_grad()
+    logits, _ = oracle(patches, cur, torch.zeros(B, dtype=torch.long), positions)
+    w = torch.ones(9); w[8] = stop_w
+    ce = torch.nn.functional.cross_entropy(logits.reshape(B * T, 9), nxt.flatten(), weight=w, reduction="none")
+    keep = masks.flatten() == 1
+    loss = ce[keep].mean()
+    loss.backward()
+    acc = (logits.reshape(B * T, 9).argmax(1)[keep] == nxt.flatten()[keep]).float().mean()
+    cfg = ja.CfgNode(stop_enabled=True, stop_weight=stop_w, learning_rate=1e-3, gradient_accumulation=1)
+    tr = ja.SupervisedTrainer(cfg, product)
+    m = tr.train_step(patches, cur, nxt, positions, masks, optimizer_step=False)
+    assert (m["logits"].cpu() - logits.detach()).abs().max() < 1e-3        # train-mode BN over B*T patches
+    assert abs(float(m["loss"]) - float(loss)) < 2e-4
+    assert abs(float(m["action_accuracy"]) - float(acc)) < 1e-6
+    assert abs(float(m["episode_length"]) - float(masks.sum(1).float().mean())) < 1e-6
+    grads = product.engine_grads()
+    n = 0
+    for name, p in oracle.named_parameters():
+        if p.grad is None or not p.requires_grad:
+            continue
+        scale = p.grad.abs().max().item()
+        if scale < 1e-12:
+            continue
+        err = (grads[name] - p.grad).abs().max().item() / scale
+        assert err < 5e-3, (name, err)
+        n += 1
+    assert n > 150
