@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--grid", type=int, default=10, help="image side in patches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["train", "rollout"], default="train")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="activation storage / MFMA type; bf16 is the inference (rollout) mode only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,7 +133,9 @@ def main():
 
     B, T, P, G = args.batch, args.seq_len, args.patch_size, args.grid
     torch.manual_seed(12345)
-    model = ja.GPT(model_config(patch_size=P, block_size=T, with_detector=False, image_processor=None),
+    assert not (args.dtype == "bf16" and args.mode == "train"), "bf16 is the inference mode: use --mode rollout"
+    model = ja.GPT(model_config(patch_size=P, block_size=T, with_detector=False, image_processor=None,
+                                act_dtype=args.dtype),
                    max_batch=B, device=f"cuda:{local_rank}")
     model.sync_weights()
     cfg = ja.CfgNode(max_seq_len=T, entropy_weight=0.01, stop_enabled=True, reward_norm=True, seed=12345 + rank,
@@ -185,14 +189,15 @@ def main():
     if rank == 0:
         glimpse_steps = args.steps * T
         conv_ms_per_launch = conv_ms / glimpse_steps          # one PAFPN pass over B patches
-        algo_bytes = NANO_448_ELEMS_PER_PATCH * (P / 448.0) ** 2 * 4.0 * B
+        esz = 2.0 if args.dtype == "bf16" else 4.0
+        algo_bytes = NANO_448_ELEMS_PER_PATCH * (P / 448.0) ** 2 * esz * B
         achieved = algo_bytes / (conv_ms_per_launch * 1e-3) / 1e9
         out = {
             "metric": "glimpse-patches/sec (448px, seq-len 20) REINFORCE step",
             "value": round(total_patches / elapsed, 1), "unit": "glimpse-patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"configs[2]/[3]: REINFORCE rollout, gpt-nano + yolox-nano encoder, {P}px, "
                                    f"seq-len {T}, --enable-stop, {B} agents/GPU x {world} GPU, "
                                    f"{G * P}x{G * P} synthetic images, forced non-STOP actions (S=T)",
@@ -207,7 +212,7 @@ def main():
                                                    "), one pass over the batch per glimpse step",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": (PMC_TRAFFIC_BYTES_B64_448 if (B, P) == (64, 448) else None),
+                         "traffic": (PMC_TRAFFIC_BYTES_B64_448 if (B, P, args.dtype) == (64, 448, "f32") else None),
                          "ms_per_launch": round(conv_ms_per_launch, 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes)},
         }

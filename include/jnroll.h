@@ -74,6 +74,8 @@ typedef struct jn_config {
   float det_nms_threshold;      /* yolox postprocess default 0.45                       */
   int32_t max_batch;            /* capacity B of env / rollout workspaces               */
   int32_t max_det_per_patch;    /* cap of kept boxes per patch (ragged output rows)     */
+  int32_t act_dtype;            /* activation storage: 0 = fp32 (the reference's dtype, exact-fp32 MFMA),
+                                 * 1 = bf16 (bf16 storage + bf16 MFMA, fp32 accumulate / statistics / weights) */
 } jn_config;
 
 /* One state-dict entry (names of SURVEY.md §5, e.g. "gpt_backbone.backbone.stem.conv.bn.weight"). */

@@ -31,7 +31,8 @@ class JnConfig(C.Structure):
                 ("gpt_bb_depth", C.c_float), ("gpt_bb_width", C.c_float), ("gpt_bb_depthwise", C.c_int32),
                 ("with_detector", C.c_int32), ("det_depth", C.c_float), ("det_width", C.c_float),
                 ("det_depthwise", C.c_int32), ("det_conf_threshold", C.c_float),
-                ("det_nms_threshold", C.c_float), ("max_batch", C.c_int32), ("max_det_per_patch", C.c_int32)]
+                ("det_nms_threshold", C.c_float), ("max_batch", C.c_int32), ("max_det_per_patch", C.c_int32),
+                ("act_dtype", C.c_int32)]
 
 
 class JnTensor(C.Structure):

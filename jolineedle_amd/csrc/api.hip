@@ -236,11 +236,11 @@ int n_parts(const jn_config& c) { return 2 + (c.no_patch_emb ? 0 : 1) + (c.use_p
 }  // namespace
 
 // ---- workspace slots ----------------------------------------------------------------
-inline float* slot_act(const Net& net, int slot, int max_batch) {
-  return net.act + (size_t)slot * net.per_image_floats * max_batch;
-}
-inline float* view_ptr(const Net& net, int slot, int max_batch, const View& v) {
-  return slot_act(net, slot, max_batch) + net.buf_off[v.buf] * (size_t)max_batch + v.coff;
+// Activation buffers are stored as net.act_dtype (JN_F32: 4-byte, JN_BF16: 2-byte elements).
+inline size_t act_esz(const Net& net) { return net.act_dtype == JN_BF16 ? 2 : 4; }
+inline void* view_ptr(const Net& net, int slot, int max_batch, const View& v) {
+  const size_t elem = (size_t)slot * net.per_image_floats * max_batch + net.buf_off[v.buf] * (size_t)max_batch + v.coff;
+  return reinterpret_cast<char*>(net.act) + elem * act_esz(net);
 }
 inline ChanTab view_tab(const Net& net, int slot, const View& v) {
   float* t = net.tab + (size_t)slot * 3 * net.tab_channels + net.tab_off[v.buf] + v.coff;
@@ -273,6 +273,8 @@ int jn_create(const jn_config* cfg, jn_ctx** out) {
            "no patch encoder: set gpt_bb_width or with_detector (or no_patch_emb)");
   std::unique_ptr<jn_ctx> ctx(new jn_ctx());
   ctx->cfg = *cfg;
+  JN_CHECK(cfg->act_dtype == JN_F32 || cfg->act_dtype == JN_BF16, JN_EINVAL, "act_dtype must be 0 (fp32) or 1 (bf16)");
+  ctx->nets[0].act_dtype = ctx->nets[1].act_dtype = cfg->act_dtype;
   if (ctx->cfg.det_nms_threshold <= 0) ctx->cfg.det_nms_threshold = 0.45f;
   if (ctx->cfg.max_det_per_patch <= 0) ctx->cfg.max_det_per_patch = 64;
   const int C = cfg->n_embd, nA = cfg->n_actions;
@@ -384,10 +386,11 @@ __global__ void fill_kernel(float* p, float v, long long n) {
 static int ensure_slots(jn_ctx* ctx, Net& net, int n_slots) {
   if (net.n_slots >= n_slots) return JN_OK;
   const int MB = ctx->cfg.max_batch;
-  float *act = nullptr, *tab = nullptr, *save = nullptr;
+  float *tab = nullptr, *save = nullptr;
   double* stats = nullptr;
+  char* act = nullptr;
   int rc;
-  if ((rc = dev_alloc(ctx, &act, (size_t)n_slots * net.per_image_floats * MB))) return rc;
+  if ((rc = dev_alloc(ctx, &act, (size_t)n_slots * net.per_image_floats * MB * act_esz(net)))) return rc;
   if ((rc = dev_alloc(ctx, &tab, (size_t)n_slots * 3 * net.tab_channels))) return rc;
   if ((rc = dev_alloc(ctx, &save, (size_t)n_slots * 2 * net.stat_channels))) return rc;
   if ((rc = dev_alloc(ctx, &stats, (size_t)n_slots * JN_NREP * 2 * net.stat_channels))) return rc;
@@ -620,8 +623,8 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
       case OP_STEM: {
         const ConvW& cw = net.convs[op.wslot];
         StemArgs a{ss.src, ss.positions, ss.pos_stride, ss.sample_stride, ss.chan_stride, ss.row_stride, net.P, N, cw.cout,
-                   cw.w_dev, ptr(op.out), ld(op.out), train ? stats + 2 * cw.stat_off : nullptr, rep_stride, skip_flag,
-                   skip_when};
+                   cw.w_dev, ptr(op.out), ld(op.out), net.act_dtype, train ? stats + 2 * cw.stat_off : nullptr, rep_stride,
+                   skip_flag, skip_when};
         launch_stem(a, s);
         finalize(op, cw);
         break;
@@ -632,8 +635,9 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
         const ConvW& cw = net.convs[op.wslot];
         JN_CHECK(!(train && op.kind == OP_CONV3), JN_ESTATE, "train-mode dense 3x3 conv (%s) is not implemented", op.name.c_str());
         ConvArgs a{};
-        a.in = ptr(op.in); a.in_ld = ld(op.in); a.itab = tab(op.in); a.w = cw.w_dev; a.bias = cw.b_dev;
-        a.out = ptr(op.out); a.out_ld = ld(op.out);
+        a.in = ptr(op.in); a.in_ld = ld(op.in); a.in_dtype = net.act_dtype; a.itab = tab(op.in); a.w = cw.w_dev;
+        a.bias = cw.b_dev; a.out = ptr(op.out); a.out_ld = ld(op.out); a.out_dtype = net.act_dtype;
+        a.bf16_mfma = net.act_dtype == JN_BF16;
         a.N = N; a.H = op.in.H; a.W = op.in.W; a.OH = op.out.H; a.OW = op.out.W;
         a.cin = op.in.C; a.cout = op.out.C; a.stride = op.stride; a.act = op.act;
         a.stats = (train && cw.has_bn) ? stats + 2 * cw.stat_off : nullptr;
@@ -644,19 +648,19 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
         break;
       }
       case OP_SPP:
-        launch_spp(view_ptr(net, slot, MB, net_full_view(net, op.out.buf)), ld(op.out), op.in.C, op.in.H, op.in.W, N,
+        launch_spp(view_ptr(net, slot, MB, net_full_view(net, op.out.buf)), net.act_dtype, ld(op.out), op.in.C, op.in.H, op.in.W, N,
                    tab(op.in), skip_flag, skip_when, s);
         break;
       case OP_UPSAMPLE:
-        launch_upsample(ptr(op.in), ld(op.in), ptr(op.out), ld(op.out), op.in.C, op.in.H, op.in.W, N, skip_flag,
+        launch_upsample(ptr(op.in), ld(op.in), ptr(op.out), ld(op.out), net.act_dtype, op.in.C, op.in.H, op.in.W, N, skip_flag,
                         skip_when, s);
         break;
       case OP_ADDACT:
         launch_addact(ptr(op.in), ld(op.in), tab(op.in), ptr(op.res), ld(op.res), tab(op.res), ptr(op.out), ld(op.out),
-                      op.out.C, (long long)N * op.out.H * op.out.W, skip_flag, skip_when, s);
+                      net.act_dtype, op.out.C, (long long)N * op.out.H * op.out.W, skip_flag, skip_when, s);
         break;
       case OP_PRED:
-        launch_head_pred(ptr(op.in), ld(op.in), tab(op.in), ptr(op.res), ld(op.res), tab(op.res), net.pred_w[op.level],
+        launch_head_pred(ptr(op.in), ld(op.in), tab(op.in), ptr(op.res), ld(op.res), tab(op.res), net.act_dtype, net.pred_w[op.level],
                          net.pred_b[op.level], ctx->det_raw, net.head_hid, op.in.H, op.in.W, op.stride, net.n_anchors,
                          op.anchor0, N, s);
         break;
@@ -717,31 +721,31 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
       const long long M = (long long)N * op.out.H * op.out.W;
       double* red = net.bred + 2 * cw.stat_off;
       float* consts = net.bconsts + 3 * cw.stat_off;
-      launch_bn_bwd_reduce(gptr(op.out), ld(op.out), ptr(op.out), ld(op.out), tab(op.out), save + 2 * cw.stat_off, cw.cout,
+      launch_bn_bwd_reduce(gptr(op.out), ld(op.out), ptr(op.out), net.act_dtype, ld(op.out), tab(op.out), save + 2 * cw.stat_off, cw.cout,
                            M, red, rep_stride, s);
       launch_bn_bwd_consts(red, rep_stride, (double)M, cw.gamma_dev, save + 2 * cw.stat_off, consts,
                            grad_of(ctx, cw.gamma_dev), grad_of(ctx, cw.beta_dev), cw.cout, s);
-      launch_bn_bwd_gz(gptr(op.out), ld(op.out), ptr(op.out), ld(op.out), tab(op.out), save + 2 * cw.stat_off, consts,
+      launch_bn_bwd_gz(gptr(op.out), ld(op.out), ptr(op.out), net.act_dtype, ld(op.out), tab(op.out), save + 2 * cw.stat_off, consts,
                        cw.cout, M, s);
       float* gw = grad_of(ctx, cw.w_dev);
       if (op.kind == OP_PW) {
         ConvArgs a{};
-        a.in = gptr(op.out); a.in_ld = ld(op.out); a.itab = ident; a.w = cw.w_dev; a.bias = nullptr;
-        a.out = gptr(op.in); a.out_ld = ld(op.in);
+        a.in = gptr(op.out); a.in_ld = ld(op.out); a.in_dtype = JN_F32; a.itab = ident; a.w = cw.w_dev; a.bias = nullptr;
+        a.out = gptr(op.in); a.out_ld = ld(op.in); a.out_dtype = JN_F32; a.bf16_mfma = net.act_dtype == JN_BF16;
         a.N = N; a.H = op.out.H; a.W = op.out.W; a.OH = op.out.H; a.OW = op.out.W;
         a.cin = cw.cout; a.cout = cw.cin; a.stride = 1; a.act = ACT_NONE;
         a.accumulate = op.acc_in ? 1 : 0; a.w_transposed = 1;
         launch_pw(a, s);
-        launch_pw_bwd_weight(gptr(op.out), ld(op.out), ptr(op.in), ld(op.in), tab(op.in), gw, ctx->wpart, M, cw.cout,
+        launch_pw_bwd_weight(gptr(op.out), ld(op.out), ptr(op.in), net.act_dtype, ld(op.in), tab(op.in), gw, ctx->wpart, M, cw.cout,
                              cw.cin, s);
       } else if (op.kind == OP_DW) {
         launch_dw_bwd_data(gptr(op.out), ld(op.out), cw.w_dev, gptr(op.in), ld(op.in), cw.cout, op.in.H, op.in.W, op.out.H,
                            op.out.W, N, op.stride, op.acc_in ? 1 : 0, s);
-        launch_dw_bwd_weight(gptr(op.out), ld(op.out), ptr(op.in), ld(op.in), tab(op.in), gw, ctx->wpart, cw.cout, op.in.H,
+        launch_dw_bwd_weight(gptr(op.out), ld(op.out), ptr(op.in), net.act_dtype, ld(op.in), tab(op.in), gw, ctx->wpart, cw.cout, op.in.H,
                              op.in.W, op.out.H, op.out.W, N, op.stride, s);
       } else if (op.kind == OP_STEM) {
         StemArgs a{ss.src, ss.positions, ss.pos_stride, ss.sample_stride, ss.chan_stride, ss.row_stride, net.P, N, cw.cout,
-                   cw.w_dev, nullptr, 0, nullptr, 0, nullptr, 0};
+                   cw.w_dev, nullptr, 0, JN_F32, nullptr, 0, nullptr, 0};
         launch_stem_bwd_weight(a, gptr(op.out), ld(op.out), gw, ctx->wpart, s);
       } else {
         set_error("backward of dense 3x3 conv (%s) is not implemented", op.name.c_str());
@@ -758,7 +762,7 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
       }
       case OP_SPP: {
         const View full = net_full_view(net, op.out.buf);
-        launch_spp_bwd(ptr(full), gptr(full), ld(op.out), op.in.C, op.in.H, op.in.W, N, tab(op.in), s);
+        launch_spp_bwd(ptr(full), net.act_dtype, gptr(full), ld(op.out), op.in.C, op.in.H, op.in.W, N, tab(op.in), s);
         break;
       }
       case OP_UPSAMPLE:
@@ -782,7 +786,8 @@ static int run_embed_fpn(jn_ctx* ctx, int N, int slot, float* e_buf, const int* 
   const int C = ctx->cfg.n_embd, MB = ctx->cfg.max_batch;
   const View& f = net.fpn[2];
   ConvArgs a{};
-  a.in = view_ptr(net, slot, MB, f); a.in_ld = net.bufs[f.buf].C; a.itab = view_tab(net, slot, f);
+  a.in = view_ptr(net, slot, MB, f); a.in_ld = net.bufs[f.buf].C; a.in_dtype = net.act_dtype; a.itab = view_tab(net, slot, f);
+  a.out_dtype = JN_F32; a.bf16_mfma = net.act_dtype == JN_BF16;
   a.w = ctx->gpt.efpn_w; a.bias = nullptr; a.out = e_buf; a.out_ld = C;
   a.N = N; a.H = f.H; a.W = f.W; a.OH = f.H; a.OW = f.W; a.cin = f.C; a.cout = C; a.stride = 1; a.act = ACT_RELU;
   a.skip_flag = skip_flag; a.skip_when = skip_when;
@@ -809,7 +814,7 @@ int jn_backbone_forward(jn_ctx* ctx, int net, const float* patches_dev, int N, i
   for (int i = 0; i < 3; ++i) {
     if (!outs[i]) continue;
     const View& f = n.fpn[i];
-    launch_nhwc_to_nchw(view_ptr(n, 0, ctx->cfg.max_batch, f), n.bufs[f.buf].C, view_tab(n, 0, f), outs[i], f.C,
+    launch_nhwc_to_nchw(view_ptr(n, 0, ctx->cfg.max_batch, f), n.act_dtype, n.bufs[f.buf].C, view_tab(n, 0, f), outs[i], f.C,
                         f.H * f.W, N, s);
   }
   JN_HIP(hipGetLastError());
@@ -1280,6 +1285,8 @@ int jn_reinforce_step(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, 
            JN_EINVAL, "training needs logits/actions/returns/logit_masks/positions/final_emb/rewards/masks outputs");
   JN_CHECK(!ctx->cfg.no_patch_emb, JN_ESTATE, "training without a patch encoder is not supported");
   JN_CHECK(ctx->cfg.block_size <= 62, JN_EINVAL, "training supports block_size <= 62");
+  // batch-statistics BatchNorm on bf16-rounded pre-activations is ill-conditioned
+  JN_CHECK(ctx->cfg.act_dtype == JN_F32, JN_ESTATE, "training needs act_dtype = fp32 (bf16 is the inference mode)");
   hipStream_t s = (hipStream_t)stream;
   int rc = rollout_impl(ctx, mode, forced_actions_dev, start_positions_dev, seed, 0, stop_early, out, 1, stream);
   if (rc) return rc;
@@ -1334,12 +1341,12 @@ int jn_reinforce_step(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, 
                            grad_of(ctx, g.efpn_lin_wt), grad_of(ctx, g.efpn_lin_b), B, K, C, s);
     float* g_f2 = net.gact + net.buf_off[f2.buf] * (size_t)MB + f2.coff;
     ConvArgs a{};
-    a.in = ctx->de_ws; a.in_ld = C; a.itab = ident; a.w = g.efpn_w; a.bias = nullptr;
-    a.out = g_f2; a.out_ld = net.bufs[f2.buf].C;
+    a.in = ctx->de_ws; a.in_ld = C; a.in_dtype = JN_F32; a.itab = ident; a.w = g.efpn_w; a.bias = nullptr;
+    a.out = g_f2; a.out_ld = net.bufs[f2.buf].C; a.out_dtype = JN_F32; a.bf16_mfma = net.act_dtype == JN_BF16;
     a.N = B; a.H = f2.H; a.W = f2.W; a.OH = f2.H; a.OW = f2.W; a.cin = C; a.cout = f2.C; a.stride = 1; a.act = ACT_NONE;
     a.accumulate = 0; a.w_transposed = 1;
     launch_pw(a, s);
-    launch_pw_bwd_weight(ctx->de_ws, C, view_ptr(net, slot, MB, f2), net.bufs[f2.buf].C, view_tab(net, slot, f2),
+    launch_pw_bwd_weight(ctx->de_ws, C, view_ptr(net, slot, MB, f2), net.act_dtype, net.bufs[f2.buf].C, view_tab(net, slot, f2),
                          grad_of(ctx, g.efpn_w), ctx->wpart, (long long)B * HW, C, f2.C, s);
     for (int i = 0; i < 2; ++i) {
       const View& f = net.fpn[i];
@@ -1366,6 +1373,7 @@ int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* cur
   JN_CHECK(ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
   const jn_config& c = ctx->cfg;
   JN_CHECK(!c.no_patch_emb, JN_ESTATE, "training without a patch encoder is not supported");
+  JN_CHECK(c.act_dtype == JN_F32, JN_ESTATE, "training needs act_dtype = fp32 (bf16 is the inference mode)");
   JN_CHECK(T >= 1 && T <= c.block_size && c.block_size <= 62, JN_EINVAL, "sequence length %d out of range", T);
   JN_CHECK(B >= 1 && B * T <= c.max_batch, JN_EINVAL, "B*T = %d patches exceed max_batch = %d", B * T, c.max_batch);
   JN_CHECK(!c.use_pos_emb || positions_dev, JN_EINVAL, "positions are required when use_pos_emb is set");
@@ -1446,12 +1454,12 @@ int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* cur
                          grad_of(ctx, g.efpn_lin_wt), grad_of(ctx, g.efpn_lin_b), N, K, C, s);
   float* g_f2 = net.gact + net.buf_off[f2.buf] * (size_t)MB + f2.coff;
   ConvArgs ca{};
-  ca.in = ctx->de_ws; ca.in_ld = C; ca.itab = ident; ca.w = g.efpn_w; ca.bias = nullptr;
-  ca.out = g_f2; ca.out_ld = net.bufs[f2.buf].C;
+  ca.in = ctx->de_ws; ca.in_ld = C; ca.in_dtype = JN_F32; ca.itab = ident; ca.w = g.efpn_w; ca.bias = nullptr;
+  ca.out = g_f2; ca.out_ld = net.bufs[f2.buf].C; ca.out_dtype = JN_F32; ca.bf16_mfma = net.act_dtype == JN_BF16;
   ca.N = N; ca.H = f2.H; ca.W = f2.W; ca.OH = f2.H; ca.OW = f2.W; ca.cin = C; ca.cout = f2.C; ca.stride = 1; ca.act = ACT_NONE;
   ca.accumulate = 0; ca.w_transposed = 1;
   launch_pw(ca, s);
-  launch_pw_bwd_weight(ctx->de_ws, C, view_ptr(net, 0, MB, f2), net.bufs[f2.buf].C, view_tab(net, 0, f2),
+  launch_pw_bwd_weight(ctx->de_ws, C, view_ptr(net, 0, MB, f2), net.act_dtype, net.bufs[f2.buf].C, view_tab(net, 0, f2),
                        grad_of(ctx, g.efpn_w), ctx->wpart, (long long)N * HW, C, f2.C, s);
   for (int i = 0; i < 2; ++i) {
     const View& f = net.fpn[i];

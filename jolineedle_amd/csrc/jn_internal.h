@@ -104,7 +104,8 @@ struct Net {
   int stat_channels = 0;          // sum of BN channels
   // workspace slots: slot 0 = eval / single-step; slots 1..n = one per glimpse step when training
   int n_slots = 0;
-  float* act = nullptr;           // [n_slots][per_image_floats * max_batch]
+  int act_dtype = 0;              // JN_F32 / JN_BF16 storage of the activation buffers
+  char* act = nullptr;            // [n_slots][per_image_floats * max_batch] elements of act_dtype
   float* tab = nullptr;           // [n_slots][3][tab_channels]
   float* save = nullptr;          // [n_slots][2 * stat_channels]  (mean, invstd)
   double* stats = nullptr;        // [n_slots][2 * stat_channels]  (sum, sumsq)

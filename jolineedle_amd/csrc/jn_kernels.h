@@ -9,6 +9,7 @@
 namespace jnr {
 
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
+enum { JN_F32 = 0, JN_BF16 = 1 };   // storage type of an activation buffer (jn_types.h)
 
 // Atomic accumulators (BN statistics, weight-gradient partials) are replicated JN_NREP times and a
 // workgroup adds into replica (block id % JN_NREP): same-address contention drops 32x; the consumer
@@ -28,16 +29,17 @@ struct StemArgs {
   const float* src; const int64_t* positions; int pos_stride;   // positions[pos_stride * n + {0,1}] = (y, x)
   long long sample_stride, chan_stride; int row_stride;
   int P, N, cout;
-  const float* w; float* out; int out_ld;
+  const float* w; void* out; int out_ld; int out_dtype;
   double* stats;                    // [JN_NREP][rep_stride]: [cout][2] sum / sumsq accumulators (train) or null
   long long stats_rep_stride;
   const int* skip_flag; int skip_when;
 };
 
 struct ConvArgs {
-  const float* in; int in_ld; ChanTab itab;
+  const void* in; int in_ld; int in_dtype; ChanTab itab;
   const float* w; const float* bias;     // bias only for BN-free layers
-  float* out; int out_ld;
+  void* out; int out_ld; int out_dtype;
+  int bf16_mfma;                         // 1x1 / dense 3x3: bf16 operands on v_mfma_f32_16x16x32_bf16
   int N, H, W, OH, OW, cin, cout, stride, act;
   int accumulate;                        // out += (gradient buffers)
   int w_transposed;                      // pw: w is [cin][cout] and read transposed (data-gradient)
@@ -48,48 +50,50 @@ struct ConvArgs {
 int launch_stem(const StemArgs& a, hipStream_t s);
 int launch_dw(const ConvArgs& a, hipStream_t s);
 int launch_pw(const ConvArgs& a, hipStream_t s);
-int launch_spp(float* cat, int ld, int h, int H, int W, int N, ChanTab it, const int* skip_flag, int skip_when,
-               hipStream_t s);
-int launch_upsample(const float* in, int in_ld, float* out, int out_ld, int C, int H, int W, int N,
+int launch_spp(void* cat, int dtype, int ld, int h, int H, int W, int N, ChanTab it, const int* skip_flag,
+               int skip_when, hipStream_t s);
+int launch_upsample(const void* in, int in_ld, void* out, int out_ld, int dtype, int C, int H, int W, int N,
                     const int* skip_flag, int skip_when, hipStream_t s);
-int launch_addact(const float* z, int z_ld, ChanTab zt, const float* res, int res_ld, ChanTab rt, float* out,
-                  int out_ld, int C, long long M, const int* skip_flag, int skip_when, hipStream_t s);
+int launch_addact(const void* z, int z_ld, ChanTab zt, const void* res, int res_ld, ChanTab rt, void* out, int out_ld,
+                  int dtype, int C, long long M, const int* skip_flag, int skip_when, hipStream_t s);
 int launch_bn_finalize(const double* stats, long long rep_stride, double count, const float* gamma, const float* beta, float* run_mean,
                        float* run_var, float* save, ChanTab t0, ChanTab t1, int C, float eps, float momentum,
                        const int* skip_flag, int skip_when, hipStream_t s);
-int launch_nhwc_to_nchw(const float* in, int in_ld, ChanTab it, float* out, int C, int HW, int N, hipStream_t s);
+int launch_nhwc_to_nchw(const void* in, int dtype, int in_ld, ChanTab it, float* out, int C, int HW, int N,
+                        hipStream_t s);
 int launch_efpn_linear(const float* e, const float* wt, float* part, int N, int K, int Co, int KS,
                        const int* skip_flag, int skip_when, hipStream_t s);
 
 // ---- detector (kernels_det.hip) --------------------------------------------------------------
 int launch_conv3(const ConvArgs& a, hipStream_t s);
-int launch_head_pred(const float* reg, int reg_ld, ChanTab rt, const float* cls, int cls_ld, ChanTab ct, const float* wp,
-                     const float* bp, float* raw, int hid, int Hl, int Wl, int stride, int A, int a0, int N,
-                     hipStream_t s);
+int launch_head_pred(const void* reg, int reg_ld, ChanTab rt, const void* cls, int cls_ld, ChanTab ct, int dtype,
+                     const float* wp, const float* bp, float* raw, int hid, int Hl, int Wl, int stride, int A, int a0,
+                     int N, hipStream_t s);
 int launch_det_scatter(const float* boxes, const int* counts, float* out_boxes, int* out_counts, int B, int cols, int col,
                        int K, const int* skip_flag, int skip_when, hipStream_t s);
 int launch_postprocess(const float* raw, int A, int N, float conf, float nms_thr, float clamp_max, float* boxes,
                        int* counts, int max_out, hipStream_t s);
 
 // ---- backward of the conv stack (kernels_bwd.hip) ----------------------------------------
-int launch_bn_bwd_reduce(const float* g, int g_ld, const float* z, int z_ld, ChanTab t, const float* save, int C,
-                         long long M, double* red_out, long long rep_stride, hipStream_t s);
+int launch_bn_bwd_reduce(const float* g, int g_ld, const void* z, int z_dtype, int z_ld, ChanTab t, const float* save,
+                         int C, long long M, double* red_out, long long rep_stride, hipStream_t s);
 // sums the replicas -> consts[c] = {sum_gy/n, sum_gy_zhat/n, gamma*invstd}; dgamma/dbeta += totals
 int launch_bn_bwd_consts(const double* red, long long rep_stride, double count, const float* gamma, const float* save,
                          float* consts, float* g_gamma, float* g_beta, int C, hipStream_t s);
-int launch_bn_bwd_gz(float* g, int g_ld, const float* z, int z_ld, ChanTab t, const float* save, const float* consts,
-                     int C, long long M, hipStream_t s);
+int launch_bn_bwd_gz(float* g, int g_ld, const void* z, int z_dtype, int z_ld, ChanTab t, const float* save,
+                     const float* consts, int C, long long M, hipStream_t s);
 // weight-gradient kernels add into wpart (replicated scratch, zero on entry and on exit) when the
 // tensor fits, else straight into gw; launch_wpart_reduce folds the replicas into gw.
-int launch_pw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw, float* wpart,
-                         long long M, int N, int K, hipStream_t s);
+int launch_pw_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, int x_ld, ChanTab it, float* gw,
+                         float* wpart, long long M, int N, int K, hipStream_t s);
 int launch_wpart_reduce(float* gw, float* wpart, int n, hipStream_t s);
 int launch_dw_bwd_data(const float* gz, int g_ld, const float* w, float* gin, int gin_ld, int C, int H, int W, int OH,
                        int OW, int N, int stride, int accumulate, hipStream_t s);
-int launch_dw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw, float* wpart,
-                         int C, int H, int W, int OH, int OW, int N, int stride, hipStream_t s);
+int launch_dw_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, int x_ld, ChanTab it, float* gw,
+                         float* wpart, int C, int H, int W, int OH, int OW, int N, int stride, hipStream_t s);
 int launch_stem_bwd_weight(const StemArgs& a, const float* gz, int g_ld, float* gw, float* wpart, hipStream_t s);
-int launch_spp_bwd(const float* cat, float* gcat, int ld, int h, int H, int W, int N, ChanTab it, hipStream_t s);
+int launch_spp_bwd(const void* cat, int dtype, float* gcat, int ld, int h, int H, int W, int N, ChanTab it,
+                   hipStream_t s);
 int launch_upsample_bwd(const float* gdst, int dst_ld, float* gsrc, int src_ld, int C, int H, int W, int N,
                         int accumulate, hipStream_t s);
 int launch_grad_copy(const float* src, int src_ld, float* dst, int dst_ld, int C, long long M, int accumulate,

@@ -10,10 +10,9 @@
 #include <hip/hip_runtime.h>
 
 #include "jn_kernels.h"
+#include "jn_types.h"
 
 namespace jnr {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 __device__ __forceinline__ float sigmoidf_(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 __device__ __forceinline__ float silu_(float v) { return v * sigmoidf_(v); }
@@ -31,8 +30,9 @@ __device__ __forceinline__ f32x4 tf4_(f32x4 z, f32x4 sc, f32x4 sh, f32x4 fl) {
 }
 
 // ---- 1. per-channel reductions ------------------------------------------------------------
+template <typename ZT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, int g_ld,
-                                                            const float* __restrict__ z, int z_ld, ChanTab t,
+                                                            const ZT* __restrict__ z, int z_ld, ChanTab t,
                                                             const float* __restrict__ save, int C, long long M,
                                                             int rows_per_block, double* __restrict__ red_out,
                                                             long long rep_stride) {
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     for (int q = 0; q < 4; ++q) { mean[q] = save[2 * (c + q)]; istd[q] = save[2 * (c + q) + 1]; }
     for (long long m = r0 + threadIdx.x / C4; m < r1; m += rstep) {
       const f32x4 gv = *reinterpret_cast<const f32x4*>(g + m * g_ld + c);
-      const f32x4 zv = *reinterpret_cast<const f32x4*>(z + m * z_ld + c);
+      const f32x4 zv = ld4(z + m * z_ld + c);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float gy = gv[q] * dsilu_(fmaf(zv[q], sc[q], sh[q]));
@@ -86,13 +86,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&ro[i], (double)red[i]);
 }
 
-int launch_bn_bwd_reduce(const float* g, int g_ld, const float* z, int z_ld, ChanTab t, const float* save, int C,
-                         long long M, double* red_out, long long rep_stride, hipStream_t s) {
+int launch_bn_bwd_reduce(const float* g, int g_ld, const void* z, int z_dtype, int z_ld, ChanTab t, const float* save,
+                         int C, long long M, double* red_out, long long rep_stride, hipStream_t s) {
   const int rstep = 256 / (C / 4) > 0 ? 256 / (C / 4) : 1;
   const int rows_per_block = rstep * 32;
   const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(256), (size_t)2 * C * sizeof(float), s, g, g_ld, z, z_ld, t,
-                     save, C, M, rows_per_block, red_out, rep_stride);
+  if (z_dtype == JN_BF16)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), (size_t)2 * C * sizeof(float), s, g, g_ld,
+                       (const bf16_t*)z, z_ld, t, save, C, M, rows_per_block, red_out, rep_stride);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), (size_t)2 * C * sizeof(float), s, g, g_ld,
+                       (const float*)z, z_ld, t, save, C, M, rows_per_block, red_out, rep_stride);
   return 0;
 }
 
@@ -119,7 +123,8 @@ int launch_bn_bwd_consts(const double* red, long long rep_stride, double count, 
   return 0;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_gz_kernel(float* __restrict__ g, int g_ld, const float* __restrict__ z,
+template <typename ZT>
+__global__ __launch_bounds__(256) void bn_bwd_gz_kernel(float* __restrict__ g, int g_ld, const ZT* __restrict__ z,
                                                         int z_ld, ChanTab t, const float* __restrict__ save,
                                                         const float* __restrict__ consts, int C, long long M) {
   const int C4 = C >> 2;
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256) void bn_bwd_gz_kernel(float* __restrict__ g, i
   const long long m = idx / C4;
   const f32x4 sc = *reinterpret_cast<const f32x4*>(t.sc + c), sh = *reinterpret_cast<const f32x4*>(t.sh + c);
   const f32x4 gv = *reinterpret_cast<const f32x4*>(g + m * g_ld + c);
-  const f32x4 zv = *reinterpret_cast<const f32x4*>(z + m * z_ld + c);
+  const f32x4 zv = ld4(z + m * z_ld + c);
   f32x4 out;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -142,11 +147,14 @@ __global__ __launch_bounds__(256) void bn_bwd_gz_kernel(float* __restrict__ g, i
   *reinterpret_cast<f32x4*>(g + m * g_ld + c) = out;
 }
 
-int launch_bn_bwd_gz(float* g, int g_ld, const float* z, int z_ld, ChanTab t, const float* save, const float* consts,
-                     int C, long long M, hipStream_t s) {
+int launch_bn_bwd_gz(float* g, int g_ld, const void* z, int z_dtype, int z_ld, ChanTab t, const float* save,
+                     const float* consts, int C, long long M, hipStream_t s) {
   const long long total = M * (C / 4);
-  hipLaunchKernelGGL(bn_bwd_gz_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, g_ld, z, z_ld, t, save,
-                     consts, C, M);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (z_dtype == JN_BF16)
+    hipLaunchKernelGGL(bn_bwd_gz_kernel<bf16_t>, grid, dim3(256), 0, s, g, g_ld, (const bf16_t*)z, z_ld, t, save, consts, C, M);
+  else
+    hipLaunchKernelGGL(bn_bwd_gz_kernel<float>, grid, dim3(256), 0, s, g, g_ld, (const float*)z, z_ld, t, save, consts, C, M);
   return 0;
 }
 
@@ -170,9 +178,9 @@ int launch_wpart_reduce(float* gw, float* wpart, int n, hipStream_t s) {
 // iteration in LDS, each wave contracts 16 of them per iteration on v_mfma_f32_16x16x4_f32.
 constexpr int WG_RB = 64;
 
-template <int CTN, int CTK>
+template <int CTN, int CTK, typename XT>
 __global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const float* __restrict__ gz, int g_ld,
-                                                            const float* __restrict__ x, int x_ld, ChanTab it,
+                                                            const XT* __restrict__ x, int x_ld, ChanTab it,
                                                             float* __restrict__ gw, int rep, long long M, int N,
                                                             int K, int rows_per_block) {
   constexpr int LDN = 16 * CTN + 4, LDK = 16 * CTK + 4;
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const float* __restr
 }
 
 template <int CTN, int CTK>
-static void launch_pw_bw_t(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw, int rep,
+static void launch_pw_bw_t(const float* gz, int g_ld, const void* x, int x_dtype, int x_ld, ChanTab it, float* gw, int rep,
                            long long M, int N, int K, hipStream_t s) {
   // aim at ~768 workgroups: enough to fill 256 CUs x 3, few enough that the final atomics stay cheap
   const long long tiles = (long long)((N + 16 * CTN - 1) / (16 * CTN)) * ((K + 16 * CTK - 1) / (16 * CTK));
@@ -258,17 +266,21 @@ static void launch_pw_bw_t(const float* gz, int g_ld, const float* x, int x_ld, 
   dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block), (N + 16 * CTN - 1) / (16 * CTN),
             (K + 16 * CTK - 1) / (16 * CTK));
   const size_t smem = ((size_t)WG_RB * (16 * CTN + 4 + 16 * CTK + 4) + 256 * CTN * CTK) * sizeof(float);
-  hipLaunchKernelGGL((pw_bwd_weight_kernel<CTN, CTK>), grid, dim3(256), smem, s, gz, g_ld, x, x_ld, it, gw, rep, M, N,
-                     K, rows_per_block);
+  if (x_dtype == JN_BF16)
+    hipLaunchKernelGGL((pw_bwd_weight_kernel<CTN, CTK, bf16_t>), grid, dim3(256), smem, s, gz, g_ld, (const bf16_t*)x, x_ld,
+                       it, gw, rep, M, N, K, rows_per_block);
+  else
+    hipLaunchKernelGGL((pw_bwd_weight_kernel<CTN, CTK, float>), grid, dim3(256), smem, s, gz, g_ld, (const float*)x, x_ld,
+                       it, gw, rep, M, N, K, rows_per_block);
 }
 
-int launch_pw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw_final, float* wpart,
-                         long long M, int N, int K, hipStream_t s) {
+int launch_pw_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, int x_ld, ChanTab it, float* gw_final,
+                         float* wpart, long long M, int N, int K, hipStream_t s) {
   const int rep = (wpart && N * K <= JN_WPART_MAX) ? 1 : 0;
   float* gw = rep ? wpart : gw_final;
   const int tn = (N + 15) / 16, tk = (K + 15) / 16;
   const int cn = tn >= 4 ? 4 : (tn == 3 ? 3 : tn), ck = tk >= 4 ? 4 : (tk == 3 ? 3 : tk);
-#define JN_BW(A, B) if (cn == A && ck == B) { launch_pw_bw_t<A, B>(gz, g_ld, x, x_ld, it, gw, rep, M, N, K, s); \
+#define JN_BW(A, B) if (cn == A && ck == B) { launch_pw_bw_t<A, B>(gz, g_ld, x, x_dtype, x_ld, it, gw, rep, M, N, K, s); \
     if (rep) launch_wpart_reduce(gw_final, wpart, N * K, s); return 0; }
   JN_BW(1, 1) JN_BW(1, 2) JN_BW(1, 3) JN_BW(1, 4) JN_BW(2, 1) JN_BW(2, 2) JN_BW(2, 3) JN_BW(2, 4)
   JN_BW(3, 1) JN_BW(3, 2) JN_BW(3, 3) JN_BW(3, 4) JN_BW(4, 1) JN_BW(4, 2) JN_BW(4, 3) JN_BW(4, 4)
@@ -327,9 +339,9 @@ int launch_dw_bwd_data(const float* gz, int g_ld, const float* w, float* gin, in
 }
 
 // ---- 4b. depthwise weight gradient: dW[tap][c] += sum gz[oy][ox][c] * T(x)[oy*S-1+ky][ox*S-1+kx][c]
-template <int S>
+template <int S, typename XT>
 __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ gz, int g_ld,
-                                                            const float* __restrict__ x, int x_ld, ChanTab it,
+                                                            const XT* __restrict__ x, int x_ld, ChanTab it,
                                                             float* __restrict__ gw, int rep, int C, int H, int W,
                                                             int OH, int OW, int N) {
   extern __shared__ float red[];   // [9][C]
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
       gv[j] = (oy0 + j < OH) ? *reinterpret_cast<const f32x4*>(gz + ((n * OH + oy0 + j) * OW + ox) * g_ld + c)
                              : f32x4{0.f, 0.f, 0.f, 0.f};
     constexpr int R = 3 * S + 3;
-    const float* xb = x + n * H * W * (long long)x_ld + c;
+    const XT* xb = x + n * H * W * (long long)x_ld + c;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int iy = oy0 * S - 1 + r;
@@ -367,7 +379,7 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
       for (int kx = 0; kx < 3; ++kx) {
         const int ix = ox * S - 1 + kx;
         if (ix < 0 || ix >= W) continue;
-        const f32x4 v = tf4_(*reinterpret_cast<const f32x4*>(xb + ((long long)iy * W + ix) * x_ld), sc, sh, fl);
+        const f32x4 v = tf4_(ld4(xb + ((long long)iy * W + ix) * x_ld), sc, sh, fl);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int ky = r - j * S;
@@ -393,8 +405,8 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
   for (int i = threadIdx.x; i < 9 * C; i += 256) atomicAdd(&dst[i], red[i]);
 }
 
-int launch_dw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, ChanTab it, float* gw_final, float* wpart,
-                         int C, int H, int W, int OH, int OW, int N, int stride, hipStream_t s) {
+int launch_dw_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, int x_ld, ChanTab it, float* gw_final,
+                         float* wpart, int C, int H, int W, int OH, int OW, int N, int stride, hipStream_t s) {
   const int rep = (wpart && 9 * C <= JN_WPART_MAX) ? 1 : 0;
   float* gw = rep ? wpart : gw_final;
   const int YS = (OH + 3) / 4;
@@ -403,12 +415,12 @@ int launch_dw_bwd_weight(const float* gz, int g_ld, const float* x, int x_ld, Ch
   if (nb > 2048) nb = 2048;                       // grid-stride: each thread folds many strips before its atomics
   const unsigned blocks = (unsigned)nb;
   const size_t smem = (size_t)9 * C * sizeof(float);
-  if (stride == 1)
-    hipLaunchKernelGGL(dw_bwd_weight_kernel<1>, dim3(blocks), dim3(256), smem, s, gz, g_ld, x, x_ld, it, gw, rep, C, H, W,
-                       OH, OW, N);
-  else
-    hipLaunchKernelGGL(dw_bwd_weight_kernel<2>, dim3(blocks), dim3(256), smem, s, gz, g_ld, x, x_ld, it, gw, rep, C, H, W,
-                       OH, OW, N);
+#define JN_DWW(S_, T_)                                                                                            \
+  hipLaunchKernelGGL((dw_bwd_weight_kernel<S_, T_>), dim3(blocks), dim3(256), smem, s, gz, g_ld, (const T_*)x, x_ld, it, \
+                     gw, rep, C, H, W, OH, OW, N)
+  if (x_dtype == JN_BF16) { if (stride == 1) JN_DWW(1, bf16_t); else JN_DWW(2, bf16_t); }
+  else { if (stride == 1) JN_DWW(1, float); else JN_DWW(2, float); }
+#undef JN_DWW
   if (rep) launch_wpart_reduce(gw_final, wpart, 9 * C, s);
   return 0;
 }
@@ -495,19 +507,20 @@ int launch_stem_bwd_weight(const StemArgs& a, const float* gz, int g_ld, float* 
 }
 
 // ---- SPP backward: g0 += route(g1, argmax5) + route(g2, argmax9) + route(g3, argmax13) ----------
-__global__ __launch_bounds__(256) void spp_bwd_kernel(const float* __restrict__ cat, float* __restrict__ gcat, int ld,
+template <typename AT>
+__global__ __launch_bounds__(256) void spp_bwd_kernel(const AT* __restrict__ cat, float* __restrict__ gcat, int ld,
                                                       int h, int H, int W, int cb, ChanTab it) {
   extern __shared__ float sp[];
   const int HW = H * W;
   float* A = sp;                 // activation of slice 0
   float* G = sp + HW * cb;       // gradient accumulator for slice 0
   const int n = blockIdx.y, c0 = blockIdx.x * cb;
-  const float* base = cat + (long long)n * HW * ld + c0;
+  const AT* base = cat + (long long)n * HW * ld + c0;
   float* gbase = gcat + (long long)n * HW * ld + c0;
   const int tid = threadIdx.x;
   for (int e = tid; e < HW * cb; e += 256) {
     const int c = e % cb;
-    const float z = base[(long long)(e / cb) * ld + c];
+    const float z = ld1(base + (long long)(e / cb) * ld + c);
     A[e] = it.fl[c0 + c] != 0.0f ? silu_(fmaf(z, it.sc[c0 + c], it.sh[c0 + c])) : z;
     G[e] = 0.0f;
   }
@@ -530,12 +543,17 @@ __global__ __launch_bounds__(256) void spp_bwd_kernel(const float* __restrict__ 
   for (int e = tid; e < HW * cb; e += 256) gbase[(long long)(e / cb) * ld + (e % cb)] += G[e];
 }
 
-int launch_spp_bwd(const float* cat, float* gcat, int ld, int h, int H, int W, int N, ChanTab it, hipStream_t s) {
+int launch_spp_bwd(const void* cat, int dtype, float* gcat, int ld, int h, int H, int W, int N, ChanTab it,
+                   hipStream_t s) {
   int cb = 32;
   while (cb > 4 && (size_t)H * W * cb * 2 * sizeof(float) > 48 * 1024) cb >>= 1;
   dim3 grid(h / cb, N);
-  hipLaunchKernelGGL(spp_bwd_kernel, grid, dim3(256), (size_t)H * W * cb * 2 * sizeof(float), s, cat, gcat, ld, h, H, W,
-                     cb, it);
+  if (dtype == JN_BF16)
+    hipLaunchKernelGGL(spp_bwd_kernel<bf16_t>, grid, dim3(256), (size_t)H * W * cb * 2 * sizeof(float), s, (const bf16_t*)cat,
+                       gcat, ld, h, H, W, cb, it);
+  else
+    hipLaunchKernelGGL(spp_bwd_kernel<float>, grid, dim3(256), (size_t)H * W * cb * 2 * sizeof(float), s, (const float*)cat,
+                       gcat, ld, h, H, W, cb, it);
   return 0;
 }
 

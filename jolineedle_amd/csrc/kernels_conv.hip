@@ -23,11 +23,12 @@
 //   bn_finalize_kernel  batch statistics -> (scale, shift) table, running-stat update.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "jn_kernels.h"
+#include "jn_types.h"
 
 namespace jnr {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 __device__ __forceinline__ float silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
@@ -86,9 +87,10 @@ constexpr int ST_TY = 16, ST_TX = 32;
 constexpr int ST_IH = 2 * ST_TY + 4, ST_IW = 2 * ST_TX + 4;   // 36 x 68
 constexpr int ST_KS = 27;                                     // 108 / 4 k-steps
 
+template <typename OT>
 __global__ __launch_bounds__(256) void stem_mfma_kernel(
     const float* __restrict__ src, const long long* __restrict__ pos, int pos_stride, long long sample_stride,
-    long long chan_stride, int row_stride, int P, const float* __restrict__ w, float* __restrict__ out,
+    long long chan_stride, int row_stride, int P, const float* __restrict__ w, OT* __restrict__ out,
     int out_ld, int cout, int ocg, double* __restrict__ stats, long long rep_stride,
     const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], tile[pbase + koff[s]], acc, 0, 0, 0);
       const int ox = ox0 + 16 * h + lm;
       if (oy < OH && ox < OH) {
-        *reinterpret_cast<f32x4*>(out + (((long long)n * OH + oy) * OH + ox) * out_ld + og * 16 + 4 * g) = acc;
+        st4(out + (((long long)n * OH + oy) * OH + ox) * out_ld + og * 16 + 4 * g, acc);
         s1[0] += acc;
         s2[0] += acc * acc;
       }
@@ -152,18 +154,23 @@ int launch_stem(const StemArgs& a, hipStream_t s) {
   const int OH = a.P / 2;
   const int ocg = a.cout / 16;
   dim3 grid((OH + ST_TX - 1) / ST_TX, (OH + ST_TY - 1) / ST_TY, a.N * ocg);
-  hipLaunchKernelGGL(stem_mfma_kernel, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.pos_stride,
-                     a.sample_stride, a.chan_stride, a.row_stride, a.P, a.w, a.out, a.out_ld, a.cout, ocg, a.stats,
-                     a.stats_rep_stride, a.skip_flag, a.skip_when);
+  if (a.out_dtype == JN_BF16)
+    hipLaunchKernelGGL(stem_mfma_kernel<bf16_t>, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.pos_stride,
+                       a.sample_stride, a.chan_stride, a.row_stride, a.P, a.w, (bf16_t*)a.out, a.out_ld, a.cout, ocg,
+                       a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when);
+  else
+    hipLaunchKernelGGL(stem_mfma_kernel<float>, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.pos_stride,
+                       a.sample_stride, a.chan_stride, a.row_stride, a.P, a.w, (float*)a.out, a.out_ld, a.cout, ocg,
+                       a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when);
   return 0;
 }
 
 // ------------------------------------------------------------------------------------
 // depthwise 3x3 (pad 1), stride S; thread = 4 channels x 4 output rows of one column.
 // ------------------------------------------------------------------------------------
-template <int S>
+template <int S, typename AT>
 __global__ __launch_bounds__(256) void dw3x3_kernel(
-    const float* __restrict__ in, int in_ld, ChanTab it, const float* __restrict__ w, float* __restrict__ out,
+    const AT* __restrict__ in, int in_ld, ChanTab it, const float* __restrict__ w, AT* __restrict__ out,
     int out_ld, int C, int H, int W, int OH, int OW, int N, double* __restrict__ stats, long long rep_stride,
     const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(
     for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int oy0 = ys * 4;
     constexpr int R = 3 * S + 3;
-    const float* inb = in + (long long)n * H * W * in_ld + c;
+    const AT* inb = in + (long long)n * H * W * in_ld + c;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int iy = oy0 * S - 1 + r;
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(
       for (int kx = 0; kx < 3; ++kx) {
         const int ix = ox * S - 1 + kx;
         if (ix < 0 || ix >= W) continue;
-        const f32x4 v = tf4(*reinterpret_cast<const f32x4*>(inb + ((long long)iy * W + ix) * in_ld), sc, sh, fl);
+        const f32x4 v = tf4(ld4(inb + ((long long)iy * W + ix) * in_ld), sc, sh, fl);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int ky = r - j * S;
@@ -212,12 +219,12 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(
         }
       }
     }
-    float* ob = out + (long long)n * OH * OW * out_ld + c;
+    AT* ob = out + (long long)n * OH * OW * out_ld + c;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int oy = oy0 + j;
       if (oy < OH) {
-        *reinterpret_cast<f32x4*>(ob + ((long long)oy * OW + ox) * out_ld) = acc[j];
+        st4(ob + ((long long)oy * OW + ox) * out_ld, acc[j]);
         s1 += acc[j];
         s2 += acc[j] * acc[j];
       }
@@ -245,12 +252,13 @@ int launch_dw(const ConvArgs& a, hipStream_t s) {
   const long long total = (long long)a.N * YS * a.OW * (a.cin / 4);
   const unsigned blocks = (unsigned)((total + 255) / 256);
   const size_t smem = a.stats ? (size_t)2 * a.cin * sizeof(float) : 0;
-  if (a.stride == 1)
-    hipLaunchKernelGGL(dw3x3_kernel<1>, dim3(blocks), dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.out, a.out_ld,
-                       a.cin, a.H, a.W, a.OH, a.OW, a.N, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when);
-  else
-    hipLaunchKernelGGL(dw3x3_kernel<2>, dim3(blocks), dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.out, a.out_ld,
-                       a.cin, a.H, a.W, a.OH, a.OW, a.N, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when);
+#define JN_DW(S_, T_)                                                                                              \
+  hipLaunchKernelGGL((dw3x3_kernel<S_, T_>), dim3(blocks), dim3(256), smem, s, (const T_*)a.in, a.in_ld, a.itab, a.w, \
+                     (T_*)a.out, a.out_ld, a.cin, a.H, a.W, a.OH, a.OW, a.N, a.stats, a.stats_rep_stride, a.skip_flag, \
+                     a.skip_when)
+  if (a.in_dtype == JN_BF16) { if (a.stride == 1) JN_DW(1, bf16_t); else JN_DW(2, bf16_t); }
+  else { if (a.stride == 1) JN_DW(1, float); else JN_DW(2, float); }
+#undef JN_DW
   return 0;
 }
 
@@ -267,20 +275,25 @@ constexpr int PW_BM = 128;     // pixels per workgroup (4 waves x 2 tiles of 16)
 // channel tiles; 2 -> 64 pixels, the two wave pairs split the channel tiles (more workgroups for the
 // 14x14 / 28x28 layers).  K chunks are software-pipelined: chunk i+1 is fetched into registers while
 // the MFMAs of chunk i run.
-template <int CT, int PW_KC, bool WT, int WM>
+// BF = false: fp32 LDS tiles, v_mfma_f32_16x16x4_f32 (exact fp32, k-permuted ds_read_b128 fragments).
+// BF = true : bf16 LDS tiles, v_mfma_f32_16x16x32_bf16 (8 consecutive k per lane = one ds_read_b128),
+//             fp32 accumulation; weights are converted from the fp32 master copy while staging.
+template <int CT, int PW_KC, bool WT, int WM, typename IT, typename OT, bool BF>
 __global__ __launch_bounds__(256) void pw_mfma_kernel(
-    const float* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, const float* __restrict__ bias,
-    float* __restrict__ out, int out_ld, long long M, int K, int Nc, int act, int accumulate,
+    const IT* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, const float* __restrict__ bias,
+    OT* __restrict__ out, int out_ld, long long M, int K, int Nc, int act, int accumulate,
     double* __restrict__ stats, long long rep_stride, const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
-  constexpr int PW_LD = PW_KC + 4;        // K chunk staged in LDS (+4 floats: bank spread, 16-B rows)
+  using LT = typename std::conditional<BF, bf16_t, float>::type;   // LDS element type
+  constexpr int PW_LD = PW_KC + (BF ? 8 : 4);   // row stride in elements: 16-B aligned rows, banks spread
   constexpr int BM = 32 * WM;             // pixels per workgroup
   constexpr int CTW = CT * WM / 4;        // channel tiles per wave
   constexpr int NX = BM * (PW_KC / 4) / 256, NW = (16 * CT * (PW_KC / 4) + 255) / 256;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Xs = smem;                       // [BM][PW_LD]
-  float* Ws = smem + BM * PW_LD;          // [16*CT][PW_LD]
-  float* red = Ws + 16 * CT * PW_LD;      // [16*CT][2]
+  constexpr int KSTEP = BF ? 32 : 16;     // k consumed per fragment read
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  LT* Xs = reinterpret_cast<LT*>(smem_raw);     // [BM][PW_LD]
+  LT* Ws = Xs + BM * PW_LD;                      // [16*CT][PW_LD]
+  float* red = reinterpret_cast<float*>(Ws + 16 * CT * PW_LD);   // [16*CT][2]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM;
@@ -296,19 +309,21 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
     for (int c = 0; c < CTW; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   f32x4 xr[NX], wr[NW];
+  // chunk width rounded up to the fragment step (K = 16 layers on the bf16 path are zero-padded to 32)
+  auto chunk_q4 = [&](int k0) { const int kc = (K - k0 < PW_KC) ? (K - k0) : PW_KC; return ((kc + KSTEP - 1) / KSTEP * KSTEP) >> 2; };
   auto fetch = [&](int k0) {
-    const int kc = (K - k0 < PW_KC) ? (K - k0) : PW_KC, q4 = kc >> 2;
+    const int q4 = chunk_q4(k0);
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
       const int i = tid + 256 * j, r = i / q4, q = i - r * q4;
       xr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (i < BM * q4 && m0 + r < M) xr[j] = *reinterpret_cast<const f32x4*>(x + (m0 + r) * x_ld + k0 + 4 * q);
+      if (i < BM * q4 && m0 + r < M && k0 + 4 * q < K) xr[j] = ld4(x + (m0 + r) * x_ld + k0 + 4 * q);
     }
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int i = tid + 256 * j, r = i / q4, q = i - r * q4;
       wr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (i < 16 * CT * q4 && n0 + r < Nc) {
+      if (i < 16 * CT * q4 && n0 + r < Nc && k0 + 4 * q < K) {
         if (WT) {
           const float* wp = w + (long long)(k0 + 4 * q) * Nc + n0 + r;
           wr[j] = f32x4{wp[0], wp[Nc], wp[2 * Nc], wp[3 * Nc]};
@@ -319,49 +334,64 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
     }
   };
   auto stage = [&](int k0) {
-    const int kc = (K - k0 < PW_KC) ? (K - k0) : PW_KC, q4 = kc >> 2;
+    const int q4 = chunk_q4(k0);
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
       const int i = tid + 256 * j, r = i / q4, q = i - r * q4;
       if (i < BM * q4) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m0 + r < M) {
-          const int kk = k0 + 4 * q;
+        const int kk = k0 + 4 * q;
+        if (m0 + r < M && kk < K)
           v = tf4(xr[j], *reinterpret_cast<const f32x4*>(it.sc + kk), *reinterpret_cast<const f32x4*>(it.sh + kk),
                   *reinterpret_cast<const f32x4*>(it.fl + kk));
-        }
-        *reinterpret_cast<f32x4*>(Xs + r * PW_LD + 4 * q) = v;
+        st4(Xs + r * PW_LD + 4 * q, v);
       }
     }
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
       const int i = tid + 256 * j, r = i / q4, q = i - r * q4;
-      if (i < 16 * CT * q4) *reinterpret_cast<f32x4*>(Ws + r * PW_LD + 4 * q) = wr[j];
+      if (i < 16 * CT * q4) st4(Ws + r * PW_LD + 4 * q, wr[j]);
     }
   };
 
   fetch(0);
   for (int k0 = 0; k0 < K; k0 += PW_KC) {
-    const int kc = (K - k0 < PW_KC) ? (K - k0) : PW_KC;   // multiple of 16
+    const int kc = chunk_q4(k0) << 2;     // multiple of KSTEP
     if (k0) __syncthreads();
     stage(k0);
     __syncthreads();
     if (k0 + PW_KC < K) fetch(k0 + PW_KC);
-    const float* xrow0 = Xs + (wm * 32 + lm) * PW_LD + 4 * g;
-    const float* xrow1 = xrow0 + 16 * PW_LD;
-    const float* wrow = Ws + (wn * CTW * 16 + lm) * PW_LD + 4 * g;
-    for (int kk = 0; kk < kc; kk += 16) {
-      const f32x4 xb0 = *reinterpret_cast<const f32x4*>(xrow0 + kk);
-      const f32x4 xb1 = *reinterpret_cast<const f32x4*>(xrow1 + kk);
-      f32x4 wa[CTW];
-#pragma unroll
-      for (int c = 0; c < CTW; ++c) wa[c] = *reinterpret_cast<const f32x4*>(wrow + c * 16 * PW_LD + kk);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
+    if constexpr (BF) {
+      const LT* xrow0 = Xs + (wm * 32 + lm) * PW_LD + 8 * g;
+      const LT* xrow1 = xrow0 + 16 * PW_LD;
+      const LT* wrow = Ws + (wn * CTW * 16 + lm) * PW_LD + 8 * g;
+      for (int kk = 0; kk < kc; kk += 32) {
+        const bf16x8 xb0 = *reinterpret_cast<const bf16x8*>(xrow0 + kk);
+        const bf16x8 xb1 = *reinterpret_cast<const bf16x8*>(xrow1 + kk);
 #pragma unroll
         for (int c = 0; c < CTW; ++c) {
-          acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][j], xb0[j], acc[0][c], 0, 0, 0);
-          acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][j], xb1[j], acc[1][c], 0, 0, 0);
+          const bf16x8 wa = *reinterpret_cast<const bf16x8*>(wrow + c * 16 * PW_LD + kk);
+          acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb0, acc[0][c], 0, 0, 0);
+          acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb1, acc[1][c], 0, 0, 0);
+        }
+      }
+    } else {
+      const LT* xrow0 = Xs + (wm * 32 + lm) * PW_LD + 4 * g;
+      const LT* xrow1 = xrow0 + 16 * PW_LD;
+      const LT* wrow = Ws + (wn * CTW * 16 + lm) * PW_LD + 4 * g;
+      for (int kk = 0; kk < kc; kk += 16) {
+        const f32x4 xb0 = *reinterpret_cast<const f32x4*>(xrow0 + kk);
+        const f32x4 xb1 = *reinterpret_cast<const f32x4*>(xrow1 + kk);
+        f32x4 wa[CTW];
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) wa[c] = *reinterpret_cast<const f32x4*>(wrow + c * 16 * PW_LD + kk);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int c = 0; c < CTW; ++c) {
+            acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][j], xb0[j], acc[0][c], 0, 0, 0);
+            acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][j], xb1[j], acc[1][c], 0, 0, 0);
+          }
         }
       }
     }
@@ -380,8 +410,8 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
       f32x4 v = acc[p][c];
       if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
       if (act != ACT_NONE) v = f32x4{act_apply(v.x, act), act_apply(v.y, act), act_apply(v.z, act), act_apply(v.w, act)};
-      if (accumulate) v += *reinterpret_cast<const f32x4*>(out + m * out_ld + n);
-      *reinterpret_cast<f32x4*>(out + m * out_ld + n) = v;
+      if (accumulate) v += ld4(out + m * out_ld + n);
+      st4(out + m * out_ld + n, v);
       s1[c] += v;
       s2[c] += v * v;
     }
@@ -394,39 +424,53 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
   }
 }
 
-template <int CT, bool WT, int WM>
+template <int CT, bool WT, int WM, typename IT, typename OT, bool BF>
 static void launch_pw_cfg(const ConvArgs& a, long long M, hipStream_t s) {
-  constexpr int KC = (CT > 4) ? 32 : 64;
+  constexpr int KC = BF ? 64 : ((CT > 4) ? 32 : 64);
   constexpr int BM = 32 * WM;
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.cout + 16 * CT - 1) / (16 * CT)));
-  const size_t smem = ((size_t)(BM + 16 * CT) * (KC + 4) + 32 * CT) * sizeof(float);
-  hipLaunchKernelGGL((pw_mfma_kernel<CT, KC, WT, WM>), grid, dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.bias,
-                     a.out, a.out_ld, M, a.cin, a.cout, a.act, a.accumulate, a.stats, a.stats_rep_stride, a.skip_flag,
-                     a.skip_when);
+  const size_t smem = (size_t)(BM + 16 * CT) * (KC + (BF ? 8 : 4)) * (BF ? 2 : 4) + 32 * CT * sizeof(float);
+  hipLaunchKernelGGL((pw_mfma_kernel<CT, KC, WT, WM, IT, OT, BF>), grid, dim3(256), smem, s, (const IT*)a.in, a.in_ld,
+                     a.itab, a.w, a.bias, (OT*)a.out, a.out_ld, M, a.cin, a.cout, a.act, a.accumulate, a.stats,
+                     a.stats_rep_stride, a.skip_flag, a.skip_when);
 }
 
-template <int CT>
+template <int CT, typename IT, typename OT, bool BF>
 static void launch_pw_ct(const ConvArgs& a, long long M, hipStream_t s) {
   // few pixels (14x14 / 28x28 maps): 64-pixel workgroups double the workgroup count
   constexpr bool can_split = (CT % 2 == 0);
   const bool small_m = M <= 65536;
   if (a.w_transposed) {
-    if (can_split && small_m) launch_pw_cfg<CT, true, can_split ? 2 : 4>(a, M, s);
-    else launch_pw_cfg<CT, true, 4>(a, M, s);
+    if (can_split && small_m) launch_pw_cfg<CT, true, can_split ? 2 : 4, IT, OT, BF>(a, M, s);
+    else launch_pw_cfg<CT, true, 4, IT, OT, BF>(a, M, s);
   } else {
-    if (can_split && small_m) launch_pw_cfg<CT, false, can_split ? 2 : 4>(a, M, s);
-    else launch_pw_cfg<CT, false, 4>(a, M, s);
+    if (can_split && small_m) launch_pw_cfg<CT, false, can_split ? 2 : 4, IT, OT, BF>(a, M, s);
+    else launch_pw_cfg<CT, false, 4, IT, OT, BF>(a, M, s);
   }
 }
 
-int launch_pw(const ConvArgs& a, hipStream_t s) {
+template <typename IT, typename OT, bool BF>
+static void launch_pw_types(const ConvArgs& a, hipStream_t s) {
   const long long M = (long long)a.N * a.H * a.W;
   const int nt = (a.cout + 15) / 16;
-  if (nt == 1) launch_pw_ct<1>(a, M, s);
-  else if (nt == 2) launch_pw_ct<2>(a, M, s);
-  else if (nt == 3) launch_pw_ct<3>(a, M, s);
-  else if (nt == 4 || (nt % 8 != 0 && nt % 4 == 0)) launch_pw_ct<4>(a, M, s);
-  else launch_pw_ct<8>(a, M, s);
+  if (nt == 1) launch_pw_ct<1, IT, OT, BF>(a, M, s);
+  else if (nt == 2) launch_pw_ct<2, IT, OT, BF>(a, M, s);
+  else if (nt == 3) launch_pw_ct<3, IT, OT, BF>(a, M, s);
+  else if (nt == 4 || (nt % 8 != 0 && nt % 4 == 0)) launch_pw_ct<4, IT, OT, BF>(a, M, s);
+  else launch_pw_ct<8, IT, OT, BF>(a, M, s);
+}
+
+// Type combinations in use: fp32 mode (f32, f32, fp32 MFMA); bf16 mode: activations (bf16 -> bf16),
+// embed_fpn.0 (bf16 -> f32) and gradients (f32 -> f32), all on the bf16 MFMA.
+int launch_pw(const ConvArgs& a, hipStream_t s) {
+  if (!a.bf16_mfma) {
+    if (a.in_dtype == JN_F32 && a.out_dtype == JN_F32) { launch_pw_types<float, float, false>(a, s); return 0; }
+    return -1;
+  }
+  if (a.in_dtype == JN_BF16 && a.out_dtype == JN_BF16) launch_pw_types<bf16_t, bf16_t, true>(a, s);
+  else if (a.in_dtype == JN_BF16 && a.out_dtype == JN_F32) launch_pw_types<bf16_t, float, true>(a, s);
+  else if (a.in_dtype == JN_F32 && a.out_dtype == JN_F32) launch_pw_types<float, float, true>(a, s);
+  else return -1;
   return 0;
 }
 
@@ -434,7 +478,8 @@ int launch_pw(const ConvArgs& a, hipStream_t s) {
 // SPP: slices 1..3 of `cat` = maxpool 5 / 9 / 13 (stride 1, -inf padding) of the ACTIVATION of
 // slice 0 (raw z + table).  mp9 = mp5(mp5), mp13 = mp5(mp9); each mp5 is separable.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void spp_kernel(float* __restrict__ cat, int ld, int h, int H, int W, int cb,
+template <typename AT>
+__global__ __launch_bounds__(256) void spp_kernel(AT* __restrict__ cat, int ld, int h, int H, int W, int cb,
                                                   ChanTab it, const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
   extern __shared__ float sp[];
@@ -442,11 +487,11 @@ __global__ __launch_bounds__(256) void spp_kernel(float* __restrict__ cat, int l
   float* A = sp;
   float* Bf = sp + HW * cb;
   const int n = blockIdx.y, c0 = blockIdx.x * cb;
-  float* base = cat + (long long)n * HW * ld + c0;
+  AT* base = cat + (long long)n * HW * ld + c0;
   const int tid = threadIdx.x;
   for (int e = tid; e < HW * cb; e += 256) {
     const int c = e % cb;
-    const float z = base[(long long)(e / cb) * ld + c];
+    const float z = ld1(base + (long long)(e / cb) * ld + c);
     A[e] = it.fl[c0 + c] != 0.0f ? silu(fmaf(z, it.sc[c0 + c], it.sh[c0 + c])) : z;
   }
   __syncthreads();
@@ -469,25 +514,29 @@ __global__ __launch_bounds__(256) void spp_kernel(float* __restrict__ cat, int l
         if (y2 >= 0 && y2 < H) m = fmaxf(m, Bf[(y2 * W + xx) * cb + c]);
       }
       A[e] = m;
-      base[(long long)p * ld + stage * h + c] = m;
+      st1(base + (long long)p * ld + stage * h + c, m);
     }
     __syncthreads();
   }
 }
 
-int launch_spp(float* cat, int ld, int h, int H, int W, int N, ChanTab it, const int* skip_flag, int skip_when,
-               hipStream_t s) {
+int launch_spp(void* cat, int dtype, int ld, int h, int H, int W, int N, ChanTab it, const int* skip_flag,
+               int skip_when, hipStream_t s) {
   int cb = 32;                                   // channels per block: keep 2 * HW * cb floats under 48 KB
   while (cb > 4 && (size_t)H * W * cb * 2 * sizeof(float) > 48 * 1024) cb >>= 1;
   dim3 grid(h / cb, N);
   const size_t smem = (size_t)H * W * cb * 2 * sizeof(float);
-  hipLaunchKernelGGL(spp_kernel, grid, dim3(256), smem, s, cat, ld, h, H, W, cb, it, skip_flag, skip_when);
+  if (dtype == JN_BF16)
+    hipLaunchKernelGGL(spp_kernel<bf16_t>, grid, dim3(256), smem, s, (bf16_t*)cat, ld, h, H, W, cb, it, skip_flag, skip_when);
+  else
+    hipLaunchKernelGGL(spp_kernel<float>, grid, dim3(256), smem, s, (float*)cat, ld, h, H, W, cb, it, skip_flag, skip_when);
   return 0;
 }
 
 // nearest x2 upsample of raw values: out[n][y][x][c] = in[n][y/2][x/2][c]
-__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ in, int in_ld,
-                                                       float* __restrict__ out, int out_ld, int C, int H, int W,
+template <typename AT>
+__global__ __launch_bounds__(256) void upsample_kernel(const AT* __restrict__ in, int in_ld,
+                                                       AT* __restrict__ out, int out_ld, int C, int H, int W,
                                                        long long total, const int* __restrict__ skip_flag,
                                                        int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
@@ -498,22 +547,28 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
   const int ox = (int)((idx / C4) % OW);
   const int oy = (int)((idx / ((long long)C4 * OW)) % OH);
   const long long n = idx / ((long long)C4 * OW * OH);
-  const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((n * H + (oy >> 1)) * W + (ox >> 1)) * in_ld + 4 * c4);
-  *reinterpret_cast<f32x4*>(out + ((n * OH + oy) * OW + ox) * out_ld + 4 * c4) = v;
+  const f32x4 v = ld4(in + ((n * H + (oy >> 1)) * W + (ox >> 1)) * in_ld + 4 * c4);
+  st4(out + ((n * OH + oy) * OW + ox) * out_ld + 4 * c4, v);
 }
 
-int launch_upsample(const float* in, int in_ld, float* out, int out_ld, int C, int H, int W, int N,
+int launch_upsample(const void* in, int in_ld, void* out, int out_ld, int dtype, int C, int H, int W, int N,
                     const int* skip_flag, int skip_when, hipStream_t s) {
   const long long total = (long long)N * 4 * H * W * (C / 4);
-  hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, in_ld, out, out_ld, C, H,
-                     W, total, skip_flag, skip_when);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == JN_BF16)
+    hipLaunchKernelGGL(upsample_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)in, in_ld, (bf16_t*)out, out_ld, C, H,
+                       W, total, skip_flag, skip_when);
+  else
+    hipLaunchKernelGGL(upsample_kernel<float>, grid, dim3(256), 0, s, (const float*)in, in_ld, (float*)out, out_ld, C, H,
+                       W, total, skip_flag, skip_when);
   return 0;
 }
 
 // Bottleneck shortcut: out = T_res(res) + T_z(z), materialised (table flag 0 on the output).
-__global__ __launch_bounds__(256) void addact_kernel(const float* __restrict__ z, int z_ld, ChanTab zt,
-                                                     const float* __restrict__ res, int res_ld, ChanTab rt,
-                                                     float* __restrict__ out, int out_ld, int C, long long M,
+template <typename AT>
+__global__ __launch_bounds__(256) void addact_kernel(const AT* __restrict__ z, int z_ld, ChanTab zt,
+                                                     const AT* __restrict__ res, int res_ld, ChanTab rt,
+                                                     AT* __restrict__ out, int out_ld, int C, long long M,
                                                      const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
   const int C4 = C >> 2;
@@ -521,18 +576,23 @@ __global__ __launch_bounds__(256) void addact_kernel(const float* __restrict__ z
   if (idx >= M * C4) return;
   const int c = (int)(idx % C4) * 4;
   const long long m = idx / C4;
-  const f32x4 a = tf4(*reinterpret_cast<const f32x4*>(z + m * z_ld + c), *reinterpret_cast<const f32x4*>(zt.sc + c),
+  const f32x4 a = tf4(ld4(z + m * z_ld + c), *reinterpret_cast<const f32x4*>(zt.sc + c),
                       *reinterpret_cast<const f32x4*>(zt.sh + c), *reinterpret_cast<const f32x4*>(zt.fl + c));
-  const f32x4 r = tf4(*reinterpret_cast<const f32x4*>(res + m * res_ld + c), *reinterpret_cast<const f32x4*>(rt.sc + c),
+  const f32x4 r = tf4(ld4(res + m * res_ld + c), *reinterpret_cast<const f32x4*>(rt.sc + c),
                       *reinterpret_cast<const f32x4*>(rt.sh + c), *reinterpret_cast<const f32x4*>(rt.fl + c));
-  *reinterpret_cast<f32x4*>(out + m * out_ld + c) = a + r;
+  st4(out + m * out_ld + c, a + r);
 }
 
-int launch_addact(const float* z, int z_ld, ChanTab zt, const float* res, int res_ld, ChanTab rt, float* out,
-                  int out_ld, int C, long long M, const int* skip_flag, int skip_when, hipStream_t s) {
+int launch_addact(const void* z, int z_ld, ChanTab zt, const void* res, int res_ld, ChanTab rt, void* out, int out_ld,
+                  int dtype, int C, long long M, const int* skip_flag, int skip_when, hipStream_t s) {
   const long long total = M * (C / 4);
-  hipLaunchKernelGGL(addact_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, z_ld, zt, res, res_ld, rt,
-                     out, out_ld, C, M, skip_flag, skip_when);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == JN_BF16)
+    hipLaunchKernelGGL(addact_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)z, z_ld, zt, (const bf16_t*)res, res_ld,
+                       rt, (bf16_t*)out, out_ld, C, M, skip_flag, skip_when);
+  else
+    hipLaunchKernelGGL(addact_kernel<float>, grid, dim3(256), 0, s, (const float*)z, z_ld, zt, (const float*)res, res_ld,
+                       rt, (float*)out, out_ld, C, M, skip_flag, skip_when);
   return 0;
 }
 
@@ -576,21 +636,26 @@ int launch_bn_finalize(const double* stats, long long rep_stride, double count, 
 }
 
 // NHWC slice (raw z + table) -> contiguous NCHW activations (boundary export for the parity API)
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, int in_ld, ChanTab it,
+template <typename AT>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const AT* __restrict__ in, int in_ld, ChanTab it,
                                                            float* __restrict__ out, int C, int HW, long long total) {
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int p = (int)(idx % HW);
   const int c = (int)((idx / HW) % C);
   const long long n = idx / ((long long)HW * C);
-  const float z = in[(n * HW + p) * in_ld + c];
+  const float z = ld1(in + (n * HW + p) * in_ld + c);
   out[idx] = it.fl[c] != 0.0f ? silu(fmaf(z, it.sc[c], it.sh[c])) : z;
 }
 
-int launch_nhwc_to_nchw(const float* in, int in_ld, ChanTab it, float* out, int C, int HW, int N, hipStream_t s) {
+int launch_nhwc_to_nchw(const void* in, int dtype, int in_ld, ChanTab it, float* out, int C, int HW, int N,
+                        hipStream_t s) {
   const long long total = (long long)N * C * HW;
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, in_ld, it, out, C,
-                     HW, total);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == JN_BF16)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)in, in_ld, it, out, C, HW, total);
+  else
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, s, (const float*)in, in_ld, it, out, C, HW, total);
   return 0;
 }
 

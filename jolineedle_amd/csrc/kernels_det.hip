@@ -5,10 +5,9 @@
 #include <hip/hip_runtime.h>
 
 #include "jn_kernels.h"
+#include "jn_types.h"
 
 namespace jnr {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 __device__ __forceinline__ float silu_d(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 __device__ __forceinline__ f32x4 tf4_d(f32x4 z, f32x4 sc, f32x4 sh, f32x4 fl) {
@@ -27,9 +26,9 @@ __device__ __forceinline__ f32x4 tf4_d(f32x4 z, f32x4 sc, f32x4 sh, f32x4 fl) {
 // ------------------------------------------------------------------------------------
 constexpr int C3_TH = 8, C3_TW = 16, C3_KC = 16, C3_LD = C3_KC + 4, C3_BN = 64;
 
-template <int S>
-__global__ __launch_bounds__(256) void conv3_mfma_kernel(const float* __restrict__ x, int x_ld, ChanTab it,
-                                                         const float* __restrict__ w, float* __restrict__ out,
+template <int S, typename AT>
+__global__ __launch_bounds__(256) void conv3_mfma_kernel(const AT* __restrict__ x, int x_ld, ChanTab it,
+                                                         const float* __restrict__ w, AT* __restrict__ out,
                                                          int out_ld, int H, int W, int OH, int OW, int K, int Nc,
                                                          int tiles_x, int tiles_y, const int* __restrict__ skip_flag,
                                                          int skip_when) {
@@ -44,7 +43,7 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const float* __restrict
   const int n_img = blockIdx.x / (tiles_x * tiles_y);
   const int oy0 = (tile / tiles_x) * C3_TH, ox0 = (tile % tiles_x) * C3_TW;
   const int n0 = blockIdx.y * C3_BN;
-  const float* xb = x + (long long)n_img * H * W * x_ld;
+  const AT* xb = x + (long long)n_img * H * W * x_ld;
   f32x4 acc[2][4];
 #pragma unroll
   for (int p = 0; p < 2; ++p)
@@ -58,7 +57,7 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const float* __restrict
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
         const int kk = k0 + 4 * q;
-        v = tf4_d(*reinterpret_cast<const f32x4*>(xb + ((long long)iy * W + ix) * x_ld + kk),
+        v = tf4_d(ld4(xb + ((long long)iy * W + ix) * x_ld + kk),
                   *reinterpret_cast<const f32x4*>(it.sc + kk), *reinterpret_cast<const f32x4*>(it.sh + kk),
                   *reinterpret_cast<const f32x4*>(it.fl + kk));
       }
@@ -92,33 +91,35 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const float* __restrict
   for (int p = 0; p < 2; ++p) {
     const int oy = oy0 + 2 * wave + p, ox = ox0 + lm;
     if (oy >= OH || ox >= OW) continue;
-    float* op = out + (((long long)n_img * OH + oy) * OW + ox) * out_ld;
+    AT* op = out + (((long long)n_img * OH + oy) * OW + ox) * out_ld;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int n = n0 + 16 * c + 4 * g;
-      if (n < Nc) *reinterpret_cast<f32x4*>(op + n) = acc[p][c];
+      if (n < Nc) st4(op + n, acc[p][c]);
     }
   }
 }
 
-int launch_conv3(const ConvArgs& a, hipStream_t s) {
+template <int S, typename AT>
+static void launch_conv3_t(const ConvArgs& a, hipStream_t s) {
   const int tiles_x = (a.OW + C3_TW - 1) / C3_TW, tiles_y = (a.OH + C3_TH - 1) / C3_TH;
   dim3 grid(tiles_x * tiles_y * a.N, (a.cout + C3_BN - 1) / C3_BN);
-  if (a.stride == 1) {
-    const size_t smem = ((size_t)(C3_TH + 2) * (C3_TW + 2) + 9 * C3_BN) * C3_LD * sizeof(float);
-    hipLaunchKernelGGL(conv3_mfma_kernel<1>, grid, dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.out, a.out_ld, a.H,
-                       a.W, a.OH, a.OW, a.cin, a.cout, tiles_x, tiles_y, a.skip_flag, a.skip_when);
-  } else {
-    const size_t smem = ((size_t)(2 * C3_TH + 2) * (2 * C3_TW + 2) + 9 * C3_BN) * C3_LD * sizeof(float);
-    static bool attr_set = false;      // 95 KB of the CU's 160 KB LDS: above the 64 KB default cap
+  const size_t smem = ((size_t)(S * C3_TH + 2) * (S * C3_TW + 2) + 9 * C3_BN) * C3_LD * sizeof(float);
+  if (smem > 64 * 1024) {             // stride 2: 95 KB of the CU's 160 KB LDS, above the 64 KB default cap
+    static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_mfma_kernel<2>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_mfma_kernel<S, AT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       attr_set = true;
     }
-    hipLaunchKernelGGL(conv3_mfma_kernel<2>, grid, dim3(256), smem, s, a.in, a.in_ld, a.itab, a.w, a.out, a.out_ld, a.H,
-                       a.W, a.OH, a.OW, a.cin, a.cout, tiles_x, tiles_y, a.skip_flag, a.skip_when);
   }
+  hipLaunchKernelGGL((conv3_mfma_kernel<S, AT>), grid, dim3(256), smem, s, (const AT*)a.in, a.in_ld, a.itab, a.w, (AT*)a.out,
+                     a.out_ld, a.H, a.W, a.OH, a.OW, a.cin, a.cout, tiles_x, tiles_y, a.skip_flag, a.skip_when);
+}
+
+int launch_conv3(const ConvArgs& a, hipStream_t s) {
+  if (a.in_dtype == JN_BF16) { if (a.stride == 1) launch_conv3_t<1, bf16_t>(a, s); else launch_conv3_t<2, bf16_t>(a, s); }
+  else { if (a.stride == 1) launch_conv3_t<1, float>(a, s); else launch_conv3_t<2, float>(a, s); }
   return 0;
 }
 
@@ -127,8 +128,9 @@ int launch_conv3(const ConvArgs& a, hipStream_t s) {
 //   ((reg_xy + grid) * stride, exp(reg_wh) * stride, sigmoid(obj), sigmoid(cls))
 // wp = [6][hid]: rows 0-3 reg_pred, 4 obj_pred (both read reg_feat), 5 cls_pred (reads cls_feat); bp[6].
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void head_pred_kernel(const float* __restrict__ reg, int reg_ld, ChanTab rt,
-                                                        const float* __restrict__ cls, int cls_ld, ChanTab ct,
+template <typename AT>
+__global__ __launch_bounds__(256) void head_pred_kernel(const AT* __restrict__ reg, int reg_ld, ChanTab rt,
+                                                        const AT* __restrict__ cls, int cls_ld, ChanTab ct,
                                                         const float* __restrict__ wp, const float* __restrict__ bp,
                                                         float* __restrict__ raw, int hid, int Hl, int Wl, int stride,
                                                         int A, int a0, int N) {
@@ -139,13 +141,13 @@ __global__ __launch_bounds__(256) void head_pred_kernel(const float* __restrict_
   if (idx >= (long long)N * Hl * Wl) return;
   const int p = (int)(idx % (Hl * Wl));
   const long long n = idx / (Hl * Wl);
-  const float* rp = reg + idx * reg_ld;
-  const float* cp = cls + idx * cls_ld;
+  const AT* rp = reg + idx * reg_ld;
+  const AT* cp = cls + idx * cls_ld;
   float o[6] = {bp[0], bp[1], bp[2], bp[3], bp[4], bp[5]};
   for (int k = 0; k < hid; k += 4) {
-    const f32x4 rv = tf4_d(*reinterpret_cast<const f32x4*>(rp + k), *reinterpret_cast<const f32x4*>(rt.sc + k),
+    const f32x4 rv = tf4_d(ld4(rp + k), *reinterpret_cast<const f32x4*>(rt.sc + k),
                            *reinterpret_cast<const f32x4*>(rt.sh + k), *reinterpret_cast<const f32x4*>(rt.fl + k));
-    const f32x4 cv = tf4_d(*reinterpret_cast<const f32x4*>(cp + k), *reinterpret_cast<const f32x4*>(ct.sc + k),
+    const f32x4 cv = tf4_d(ld4(cp + k), *reinterpret_cast<const f32x4*>(ct.sc + k),
                            *reinterpret_cast<const f32x4*>(ct.sh + k), *reinterpret_cast<const f32x4*>(ct.fl + k));
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -164,12 +166,17 @@ __global__ __launch_bounds__(256) void head_pred_kernel(const float* __restrict_
   dst[5] = 1.0f / (1.0f + expf(-o[5]));
 }
 
-int launch_head_pred(const float* reg, int reg_ld, ChanTab rt, const float* cls, int cls_ld, ChanTab ct, const float* wp,
-                     const float* bp, float* raw, int hid, int Hl, int Wl, int stride, int A, int a0, int N,
-                     hipStream_t s) {
+int launch_head_pred(const void* reg, int reg_ld, ChanTab rt, const void* cls, int cls_ld, ChanTab ct, int dtype,
+                     const float* wp, const float* bp, float* raw, int hid, int Hl, int Wl, int stride, int A, int a0,
+                     int N, hipStream_t s) {
   const long long total = (long long)N * Hl * Wl;
-  hipLaunchKernelGGL(head_pred_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), (size_t)6 * hid * sizeof(float), s,
-                     reg, reg_ld, rt, cls, cls_ld, ct, wp, bp, raw, hid, Hl, Wl, stride, A, a0, N);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == JN_BF16)
+    hipLaunchKernelGGL(head_pred_kernel<bf16_t>, grid, dim3(256), (size_t)6 * hid * sizeof(float), s, (const bf16_t*)reg,
+                       reg_ld, rt, (const bf16_t*)cls, cls_ld, ct, wp, bp, raw, hid, Hl, Wl, stride, A, a0, N);
+  else
+    hipLaunchKernelGGL(head_pred_kernel<float>, grid, dim3(256), (size_t)6 * hid * sizeof(float), s, (const float*)reg,
+                       reg_ld, rt, (const float*)cls, cls_ld, ct, wp, bp, raw, hid, Hl, Wl, stride, A, a0, N);
   return 0;
 }
 

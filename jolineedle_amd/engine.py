@@ -99,6 +99,7 @@ def make_jn_config(config, device_index, max_batch, n_actions):
     c.det_nms_threshold = 0.45
     c.max_batch = max_batch
     c.max_det_per_patch = int(getattr(config, "max_det_per_patch", 64))
+    c.act_dtype = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}[str(getattr(config, "act_dtype", "f32"))]
     return c
 
 

@@ -59,6 +59,7 @@ def make_pair(seed=0, bn_seed=5, max_batch=8, **kw):
     from oracle.gpt_ref import build_gpt_ref
     okw = dict(kw)
     okw.pop("max_det_per_patch", None)
+    okw.pop("act_dtype", None)
     oracle = build_gpt_ref(seed, **okw)
     if bn_seed is not None:
         randomize_bn(oracle, bn_seed)

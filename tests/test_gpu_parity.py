@@ -669,3 +669,51 @@ def test_supervised_step_vs_oracle(B, T, P, stop_w):
         assert err < 5e-3, (name, err)
         n += 1
     assert n > 150
+
+
+# --------------------------------------------------------------------------------------
+# bf16 inference mode (bf16 activation storage + bf16 MFMA, eval-mode BN): north-star bar 1e-3 on logits
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("P,N", [(64, 3), (448, 2)])
+def test_bf16_mode_backbone_maps(P, N):
+    product, oracle = make_pair(3, patch_size=P, block_size=6, with_detector=False, image_processor=None,
+                                act_dtype="bf16")
+    x = torch.rand((N, 3, P, P), generator=torch.Generator().manual_seed(P))
+    with torch.no_grad():
+        ref = oracle.gpt_backbone(x)
+    got = product.backbone_features(x)
+    for i in range(3):
+        err = (got[i].cpu() - ref[i]).abs().max().item()
+        assert err < 5e-3 * ref[i].abs().max().item() + 1e-4, (i, err)      # bf16: ~0.4 % per rounding
+
+
+def test_bf16_mode_logits_and_rollout_golden(golden):
+    g, g4 = golden("g3_gpt_forward.npz"), golden("g4_rollout.npz")
+    product, _ = make_pair(int(g["seed"]), int(g["bn_seed"]), patch_size=64, block_size=6,
+                           image_processor="yolox-nano", gpt_backbone="yolox-nano", act_dtype="bf16")
+    patches, actions, positions = synth_tokens(3, 6, 64, 9, 5, seed=int(g["tok_seed"]))
+    lg, emb = product(patches, actions, torch.zeros(3, dtype=torch.long), positions)
+    assert np.abs(lg.cpu().numpy() - g["full_logits"]).max() < 1e-3
+    assert np.abs(emb.cpu().numpy() - g["full_emb"]).max() < 1e-3
+    P, Tn = int(g4["P"]), int(g4["T"])
+    images, bboxes, _ = synth_batch(4, 4, 5, P, seed=int(g4["batch_seed"]))
+    env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True)
+    ro = ja.ReinforceTrainer(_cfg(T=Tn), product).rollout(env, sample_actions=False, start_positions=T_(g4["start"]))
+    for k in ("masks", "logit_masks", "positions"):
+        assert np.array_equal(ro[k].cpu().numpy(), g4[k]), k
+    assert np.array_equal(ro["rewards"].cpu().numpy(), g4["rewards"])
+    for k in ("returns", "logprobs", "entropies"):
+        assert np.allclose(ro[k].cpu().numpy(), g4[k], atol=1e-3), k
+    pos = ro["positions"].cpu()
+    for b in range(4):                                     # the gather stays bit exact in every mode
+        y, x = pos[b, 1].tolist()
+        assert torch.equal(ro["patches"][b, 1].cpu(), images[b, :, y * P:(y + 1) * P, x * P:(x + 1) * P])
+
+
+def test_bf16_mode_refuses_training():
+    product, _ = make_pair(5, patch_size=64, block_size=3, with_detector=False, image_processor=None, act_dtype="bf16")
+    images, bboxes, start = synth_batch(2, 3, 3, 64, seed=1)
+    env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, 64, 3, 1, True)
+    tr = ja.ReinforceTrainer(_cfg(T=3, learning_rate=1e-3, gradient_accumulation=1), product)
+    with pytest.raises(_lib.JnError, match="fp32"):
+        tr.train_iteration(env, start_positions=start)
