@@ -617,6 +617,14 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
                        cw.rvar_dev, save + 2 * cw.stat_off, tab(op.out), t1, cw.cout, kBnEps, kBnMomentum, skip_flag,
                        skip_when, s);
   };
+  // JN_LAYER_PROFILE=1: HIP events around every op of the pass, table on stderr (a measuring aid, off by default)
+  static const bool layer_profile = std::getenv("JN_LAYER_PROFILE") != nullptr;
+  std::vector<hipEvent_t> lev;
+  if (layer_profile) {
+    lev.resize(n_ops + 1);
+    for (auto& e : lev) hipEventCreate(&e);
+    hipEventRecord(lev[0], s);
+  }
   for (int oi = 0; oi < n_ops; ++oi) {
     const Op& op = net.ops[oi];
     switch (op.kind) {
@@ -665,6 +673,30 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
                          op.anchor0, N, s);
         break;
     }
+    if (layer_profile) hipEventRecord(lev[oi + 1], s);
+  }
+  if (layer_profile) {
+    hipStreamSynchronize(s);
+    static const char* kn[] = {"stem", "pw", "dw", "conv3", "spp", "upsample", "addact", "pred"};
+    const double esz = (double)act_esz(net);
+    double tot_us = 0, tot_b = 0;
+    fprintf(stderr, "# layer profile: net %d, N=%d, train=%d, slot=%d\n", ni, N, train, slot);
+    for (int oi = 0; oi < n_ops; ++oi) {
+      const Op& op = net.ops[oi];
+      float ms = 0;
+      hipEventElapsedTime(&ms, lev[oi], lev[oi + 1]);
+      const double in_e = op.kind == OP_STEM ? 3.0 * net.P * net.P * 4.0 / esz : (double)op.in.H * op.in.W * op.in.C;
+      double out_e = (double)op.out.H * op.out.W * op.out.C;
+      double elems = in_e + out_e;
+      if (op.kind == OP_ADDACT) elems += out_e;
+      if (op.kind == OP_SPP) elems = in_e * 4;
+      const double bytes = elems * esz * N;
+      tot_us += ms * 1e3; tot_b += bytes;
+      fprintf(stderr, "%-8s %-44s in %3dx%3dx%3d out %3dx%3dx%3d s%d  %8.1f us  %7.1f MB  %7.0f GB/s\n", kn[op.kind], op.name.c_str(),
+              op.in.H, op.in.W, op.in.C, op.out.H, op.out.W, op.out.C, op.stride, ms * 1e3, bytes / 1e6, bytes / (ms * 1e-3) / 1e9);
+    }
+    fprintf(stderr, "# total %.1f us, %.1f MB, %.0f GB/s\n", tot_us, tot_b / 1e6, tot_b / (tot_us * 1e-6) / 1e9);
+    for (auto& e : lev) hipEventDestroy(e);
   }
   JN_HIP(hipGetLastError());
   if (train) net.eval_tab_dirty = true;     // running statistics moved
@@ -672,7 +704,7 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
 }
 
 // ---- training state --------------------------------------------------------------------
-static int ensure_train_state(jn_ctx* ctx) {
+static int ensure_train_state(jn_ctx* ctx, int g_slots = 1) {
   int rc;
   if (!ctx->grads) {
     if ((rc = dev_alloc(ctx, &ctx->grads, ctx->arena_size))) return rc;
@@ -690,23 +722,39 @@ static int ensure_train_state(jn_ctx* ctx) {
   for (int ni = 0; ni < 2; ++ni) {
     if (!ctx->has_net[ni]) continue;
     Net& net = ctx->nets[ni];
-    if (net.gact) continue;
-    if ((rc = dev_alloc(ctx, &net.gact, net.per_image_floats * (size_t)ctx->cfg.max_batch))) return rc;
-    if ((rc = dev_alloc(ctx, &net.bred, (size_t)JN_NREP * 2 * net.stat_channels))) return rc;
-    if ((rc = dev_alloc(ctx, &net.bconsts, (size_t)3 * net.stat_channels))) return rc;
+    const int want = ni == ctx->enc_net ? g_slots : 1;
+    if (net.g_slots >= want) continue;
+    // (a smaller earlier allocation stays owned by the context until jn_destroy)
+    if ((rc = dev_alloc(ctx, &net.gact, (size_t)want * net.per_image_floats * ctx->cfg.max_batch))) return rc;
+    if ((rc = dev_alloc(ctx, &net.bred, (size_t)want * JN_NREP * 2 * net.stat_channels))) return rc;
+    if ((rc = dev_alloc(ctx, &net.bconsts, (size_t)want * 3 * net.stat_channels))) return rc;
+    net.g_slots = want;
   }
   return JN_OK;
 }
 
 static inline float* grad_of(const jn_ctx* ctx, const float* param) { return ctx->grads + (param - ctx->params); }
 
-// Backward of one train-mode PAFPN pass (slot `slot`, N patches): g[fpn views] must hold the
-// incoming gradients; parameter gradients are accumulated into ctx->grads.
-static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, hipStream_t s) {
+// Backward of `nsl` train-mode PAFPN passes (workspace slots slot .. slot + nsl - 1, N patches each; gradient
+// slots 0 .. nsl - 1): every kernel is launched ONCE for all the passes (SlotBatch), so a 20-step trajectory
+// costs the launches of one pass.  g[fpn views] must hold the incoming gradients; parameter gradients are
+// accumulated into ctx->grads.  ss.positions belongs to the first pass, pos_slot_stride int64s separate passes.
+static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, hipStream_t s, int nsl = 1,
+                            long long pos_slot_stride = 0) {
   Net& net = ctx->nets[ni];
   const int MB = ctx->cfg.max_batch;
-  JN_HIP(hipMemsetAsync(net.bred, 0, (size_t)JN_NREP * 2 * net.stat_channels * sizeof(double), s));
+  JN_CHECK(nsl >= 1 && nsl <= net.g_slots && slot + nsl <= net.n_slots, JN_ESTATE, "backward over %d slots from %d: not allocated", nsl, slot);
+  JN_HIP(hipMemsetAsync(net.bred, 0, (size_t)nsl * JN_NREP * 2 * net.stat_channels * sizeof(double), s));
   const long long rep_stride = 2LL * net.stat_channels;
+  SlotBatch sb;
+  sb.n = nsl;
+  sb.act = (long long)net.per_image_floats * MB;
+  sb.grad = (long long)net.per_image_floats * MB;
+  sb.tab = 3LL * net.tab_channels;
+  sb.save = 2LL * net.stat_channels;
+  sb.red = (long long)JN_NREP * 2 * net.stat_channels;
+  sb.consts = 3LL * net.stat_channels;
+  sb.pos = pos_slot_stride;
   float* save = slot_save(net, slot);
   auto ptr = [&](const View& v) { return view_ptr(net, slot, MB, v); };
   auto gptr = [&](const View& v) { return net.gact + net.buf_off[v.buf] * (size_t)MB + v.coff; };
@@ -722,11 +770,11 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
       double* red = net.bred + 2 * cw.stat_off;
       float* consts = net.bconsts + 3 * cw.stat_off;
       launch_bn_bwd_reduce(gptr(op.out), ld(op.out), ptr(op.out), net.act_dtype, ld(op.out), tab(op.out), save + 2 * cw.stat_off, cw.cout,
-                           M, red, rep_stride, s);
+                           M, red, rep_stride, s, sb);
       launch_bn_bwd_consts(red, rep_stride, (double)M, cw.gamma_dev, save + 2 * cw.stat_off, consts,
-                           grad_of(ctx, cw.gamma_dev), grad_of(ctx, cw.beta_dev), cw.cout, s);
+                           grad_of(ctx, cw.gamma_dev), grad_of(ctx, cw.beta_dev), cw.cout, s, sb);
       launch_bn_bwd_gz(gptr(op.out), ld(op.out), ptr(op.out), net.act_dtype, ld(op.out), tab(op.out), save + 2 * cw.stat_off, consts,
-                       cw.cout, M, s);
+                       cw.cout, M, s, sb);
       float* gw = grad_of(ctx, cw.w_dev);
       if (op.kind == OP_PW) {
         ConvArgs a{};
@@ -735,18 +783,19 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
         a.N = N; a.H = op.out.H; a.W = op.out.W; a.OH = op.out.H; a.OW = op.out.W;
         a.cin = cw.cout; a.cout = cw.cin; a.stride = 1; a.act = ACT_NONE;
         a.accumulate = op.acc_in ? 1 : 0; a.w_transposed = 1;
+        a.n_slots = nsl; a.in_slot_stride = sb.grad; a.out_slot_stride = sb.grad; a.tab_slot_stride = 0;
         launch_pw(a, s);
         launch_pw_bwd_weight(gptr(op.out), ld(op.out), ptr(op.in), net.act_dtype, ld(op.in), tab(op.in), gw, ctx->wpart, M, cw.cout,
-                             cw.cin, s);
+                             cw.cin, s, sb);
       } else if (op.kind == OP_DW) {
         launch_dw_bwd_data(gptr(op.out), ld(op.out), cw.w_dev, gptr(op.in), ld(op.in), cw.cout, op.in.H, op.in.W, op.out.H,
-                           op.out.W, N, op.stride, op.acc_in ? 1 : 0, s);
+                           op.out.W, N, op.stride, op.acc_in ? 1 : 0, s, sb);
         launch_dw_bwd_weight(gptr(op.out), ld(op.out), ptr(op.in), net.act_dtype, ld(op.in), tab(op.in), gw, ctx->wpart, cw.cout, op.in.H,
-                             op.in.W, op.out.H, op.out.W, N, op.stride, s);
+                             op.in.W, op.out.H, op.out.W, N, op.stride, s, sb);
       } else if (op.kind == OP_STEM) {
         StemArgs a{ss.src, ss.positions, ss.pos_stride, ss.sample_stride, ss.chan_stride, ss.row_stride, net.P, N, cw.cout,
                    cw.w_dev, nullptr, 0, JN_F32, nullptr, 0, nullptr, 0};
-        launch_stem_bwd_weight(a, gptr(op.out), ld(op.out), gw, ctx->wpart, s);
+        launch_stem_bwd_weight(a, gptr(op.out), ld(op.out), gw, ctx->wpart, s, sb);
       } else {
         set_error("backward of dense 3x3 conv (%s) is not implemented", op.name.c_str());
         return JN_ESTATE;
@@ -756,18 +805,18 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
     switch (op.kind) {
       case OP_ADDACT: {
         const long long M = (long long)N * op.out.H * op.out.W;
-        launch_grad_copy(gptr(op.out), ld(op.out), gptr(op.in), ld(op.in), op.out.C, M, op.acc_in ? 1 : 0, s);
-        launch_grad_copy(gptr(op.out), ld(op.out), gptr(op.res), ld(op.res), op.out.C, M, op.acc_res ? 1 : 0, s);
+        launch_grad_copy(gptr(op.out), ld(op.out), gptr(op.in), ld(op.in), op.out.C, M, op.acc_in ? 1 : 0, s, sb);
+        launch_grad_copy(gptr(op.out), ld(op.out), gptr(op.res), ld(op.res), op.out.C, M, op.acc_res ? 1 : 0, s, sb);
         break;
       }
       case OP_SPP: {
         const View full = net_full_view(net, op.out.buf);
-        launch_spp_bwd(ptr(full), net.act_dtype, gptr(full), ld(op.out), op.in.C, op.in.H, op.in.W, N, tab(op.in), s);
+        launch_spp_bwd(ptr(full), net.act_dtype, gptr(full), ld(op.out), op.in.C, op.in.H, op.in.W, N, tab(op.in), s, sb);
         break;
       }
       case OP_UPSAMPLE:
         launch_upsample_bwd(gptr(op.out), ld(op.out), gptr(op.in), ld(op.in), op.in.C, op.in.H, op.in.W, N,
-                            op.acc_in ? 1 : 0, s);
+                            op.acc_in ? 1 : 0, s, sb);
         break;
       default: break;
     }
@@ -1183,15 +1232,27 @@ static int rollout_impl(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev
   StemSrc ss{e.images, e.positions, 3LL * e.H * e.W, (long long)e.H * e.W, e.W};
   int rc;
   if (train) {
-    if ((rc = ensure_slots(ctx, ctx->nets[ctx->enc_net], T + 1))) return rc;
-    if ((rc = ensure_train_state(ctx))) return rc;
+    Net& tn = ctx->nets[ctx->enc_net];
+    if ((rc = ensure_slots(ctx, tn, T + 1))) return rc;
+    int g_want = tn.g_slots;
+    if (g_want < T) {
+      // gradient buffers for as many glimpse steps as fit in ~80 % of the free HBM (the whole trajectory on a
+      // 288 GB MI355X at the headline sizes); the backward then runs in ceil(S / g_slots) step-batched passes
+      size_t free_b = 0, total_b = 0;
+      JN_HIP(hipMemGetInfo(&free_b, &total_b));
+      const size_t per_slot = (size_t)tn.per_image_floats * c.max_batch * sizeof(float) + (1u << 20);
+      const long long fit = (long long)((double)free_b * 0.8 / (double)per_slot);
+      g_want = (int)std::max<long long>(1, std::min<long long>(T, fit));
+      if (const char* cap = std::getenv("JN_GRAD_SLOTS")) g_want = std::max(1, std::min(g_want, std::atoi(cap)));
+    }
+    if ((rc = ensure_train_state(ctx, g_want))) return rc;
     if (!ctx->efpn_train) {
       const size_t MBt = (size_t)c.max_batch * c.block_size;
       if ((rc = dev_alloc(ctx, &ctx->efpn_train, MBt * ctx->efpn_h * ctx->efpn_w * C))) return rc;
       if ((rc = dev_alloc(ctx, &ctx->tok_emb_train, MBt * C))) return rc;
       if ((rc = dev_alloc(ctx, &ctx->d_tok_emb, MBt * C))) return rc;
       if ((rc = dev_alloc(ctx, &ctx->dlogits, MBt * nA))) return rc;
-      if ((rc = dev_alloc(ctx, &ctx->de_ws, (size_t)c.max_batch * ctx->efpn_h * ctx->efpn_w * C))) return rc;
+      if ((rc = dev_alloc(ctx, &ctx->de_ws, MBt * ctx->efpn_h * ctx->efpn_w * C))) return rc;
     }
   }
   for (int t = 0; t < T; ++t) {
@@ -1320,6 +1381,7 @@ int jn_reinforce_step(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, 
   ba.n_done = ctx->n_done; ba.final_emb = out->final_emb_dev; ba.dlogits = ctx->dlogits; ba.actions = out->actions_dev;
   ba.positions = out->positions_dev; ba.pos_tokens = T + 1; ba.pos1d_by_token = 0; ba.tok_actions = nullptr;
   ba.tok_emb = ctx->tok_emb_train; ba.d_tok_emb = ctx->d_tok_emb;
+  ba.dte_stride_b = 1; ba.dte_stride_t = B;          // [T][B][C]: the rows of one glimpse step are contiguous
   ba.wte = g.wte; ba.wpe = g.wpe; ba.proj_wt = g.proj_wt; ba.pos1d = g.pos1d; ba.pe2 = g.pos2d_col; ba.head_wt = g.head_wt;
   ba.lnf_w = g.lnf_w; ba.lnf_b = g.lnf_b; ba.layers = ctx->layers_dev; ba.g_layers = ctx->g_layers_dev;
   ba.g_wte = grad_of(ctx, g.wte); ba.g_wpe = g.wpe ? grad_of(ctx, g.wpe) : nullptr;
@@ -1329,33 +1391,49 @@ int jn_reinforce_step(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, 
   ba.scratch = ctx->gpt_bwd_scratch; ba.scratch_per_agent = per_agent;
   launch_gpt_backward(ba, s);
 
-  // per executed glimpse step, newest first: embed_fpn backward, then the patch encoder
+  // patch-encoder side: all executed glimpse steps in ONE set of launches (chunks of net.g_slots steps
+  // when the gradient buffers of a whole trajectory do not fit): embed_fpn backward, then the PAFPN.
   Net& net = ctx->nets[ctx->enc_net];
   const int MB = c.max_batch, HW = ctx->efpn_h * ctx->efpn_w, K = HW * C;
   const View& f2 = net.fpn[2];
   const ChanTab ident{ctx->ident, ctx->ident + 2048, ctx->ident + 4096};
-  for (int t = S - 1; t >= 0; --t) {
-    const int slot = t + 1;
-    const float* e_t = ctx->efpn_train + (size_t)t * B * K;
-    launch_efpn_linear_bwd(e_t, g.efpn_lin_wt, ctx->d_tok_emb + (size_t)t * C, (long long)T * C, ctx->de_ws,
-                           grad_of(ctx, g.efpn_lin_wt), grad_of(ctx, g.efpn_lin_b), B, K, C, s);
+  const long long g_slot = (long long)net.per_image_floats * MB;
+  for (int t0 = 0; t0 < S; t0 += net.g_slots) {
+    const int g_n = std::min(net.g_slots, S - t0);
+    const long long Mr = (long long)g_n * B;                       // (step, agent) rows of this chunk
+    const float* e_c = ctx->efpn_train + (size_t)t0 * B * K;       // [g_n*B][K] embed_fpn.0 activations
+    const float* dpe = ctx->d_tok_emb + (size_t)t0 * B * C;        // [g_n*B][C]  d loss / d patch embedding
+    // Linear backward as two GEMMs on the 1x1-conv kernels: de = dpe . W^T (then the ReLU mask), dW = e^T . dpe
+    ConvArgs la2{};
+    la2.in = dpe; la2.in_ld = C; la2.in_dtype = JN_F32; la2.itab = ident; la2.w = g.efpn_lin_wt; la2.bias = nullptr;
+    la2.out = ctx->de_ws; la2.out_ld = K; la2.out_dtype = JN_F32; la2.bf16_mfma = 0;
+    la2.N = (int)Mr; la2.H = 1; la2.W = 1; la2.OH = 1; la2.OW = 1; la2.cin = C; la2.cout = K; la2.stride = 1; la2.act = ACT_NONE;
+    launch_pw(la2, s);
+    launch_relu_mask(ctx->de_ws, e_c, Mr * K, s);
+    launch_pw_bwd_weight(e_c, K, dpe, JN_F32, C, ident, grad_of(ctx, g.efpn_lin_wt), nullptr, Mr, K, C, s);
+    launch_colsum_add(dpe, Mr, C, grad_of(ctx, g.efpn_lin_b), s);
+    // embed_fpn.0 (1x1 conv) backward into the f2 gradient view of every slot
+    SlotBatch sb;
+    sb.n = g_n; sb.act = g_slot; sb.grad = g_slot; sb.tab = 3LL * net.tab_channels;
     float* g_f2 = net.gact + net.buf_off[f2.buf] * (size_t)MB + f2.coff;
     ConvArgs a{};
     a.in = ctx->de_ws; a.in_ld = C; a.in_dtype = JN_F32; a.itab = ident; a.w = g.efpn_w; a.bias = nullptr;
-    a.out = g_f2; a.out_ld = net.bufs[f2.buf].C; a.out_dtype = JN_F32; a.bf16_mfma = net.act_dtype == JN_BF16;
+    a.out = g_f2; a.out_ld = net.bufs[f2.buf].C; a.out_dtype = JN_F32; a.bf16_mfma = 0;
     a.N = B; a.H = f2.H; a.W = f2.W; a.OH = f2.H; a.OW = f2.W; a.cin = C; a.cout = f2.C; a.stride = 1; a.act = ACT_NONE;
     a.accumulate = 0; a.w_transposed = 1;
+    a.n_slots = g_n; a.in_slot_stride = (long long)B * K; a.out_slot_stride = g_slot; a.tab_slot_stride = 0;
     launch_pw(a, s);
-    launch_pw_bwd_weight(ctx->de_ws, C, view_ptr(net, slot, MB, f2), net.act_dtype, net.bufs[f2.buf].C, view_tab(net, slot, f2),
-                         grad_of(ctx, g.efpn_w), ctx->wpart, (long long)B * HW, C, f2.C, s);
+    launch_pw_bwd_weight(ctx->de_ws, C, view_ptr(net, t0 + 1, MB, f2), net.act_dtype, net.bufs[f2.buf].C, view_tab(net, t0 + 1, f2),
+                         grad_of(ctx, g.efpn_w), ctx->wpart, (long long)B * HW, C, f2.C, s, sb, (long long)B * K);
     for (int i = 0; i < 2; ++i) {
       const View& f = net.fpn[i];
-      JN_HIP(hipMemsetAsync(net.gact + net.buf_off[f.buf] * (size_t)MB + f.coff, 0,
-                            (size_t)B * f.H * f.W * f.C * sizeof(float), s));
+      for (int j = 0; j < g_n; ++j)
+        JN_HIP(hipMemsetAsync(net.gact + (size_t)j * g_slot + net.buf_off[f.buf] * (size_t)MB + f.coff, 0,
+                              (size_t)B * f.H * f.W * f.C * sizeof(float), s));
     }
-    StemSrc ss{e.images, out->positions_dev + 2 * t, 3LL * e.H * e.W, (long long)e.H * e.W, e.W};
+    StemSrc ss{e.images, out->positions_dev + 2 * t0, 3LL * e.H * e.W, (long long)e.H * e.W, e.W};
     ss.pos_stride = 2 * (T + 1);
-    if ((rc = run_net_backward(ctx, ctx->enc_net, B, ss, slot, s))) return rc;
+    if ((rc = run_net_backward(ctx, ctx->enc_net, B, ss, t0 + 1, s, g_n, 2))) return rc;
   }
   (void)P;
   JN_HIP(hipGetLastError());
@@ -1390,7 +1468,7 @@ int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* cur
     if ((rc = dev_alloc(ctx, &ctx->tok_emb_train, MBt * C))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->d_tok_emb, MBt * C))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->dlogits, MBt * nA))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->de_ws, (size_t)c.max_batch * HW * C))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->de_ws, MBt * HW * C))) return rc;
   }
   if (!ctx->sup_final_emb) {
     if ((rc = dev_alloc(ctx, &ctx->sup_final_emb, (size_t)c.max_batch * (c.block_size + 1) * C))) return rc;
@@ -1438,7 +1516,7 @@ int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* cur
   ba.dec_pos_enc = c.decoder_pos_encoding; ba.pe2_ch = (int)std::ceil(C / 4.0) * 2;
   ba.n_done = ctx->n_done; ba.final_emb = ctx->sup_final_emb; ba.dlogits = ctx->dlogits; ba.actions = current_actions_dev;
   ba.tok_actions = current_actions_dev; ba.positions = positions_dev; ba.pos_tokens = T; ba.pos1d_by_token = 1;
-  ba.tok_emb = ctx->tok_emb_train; ba.d_tok_emb = ctx->d_tok_emb;
+  ba.tok_emb = ctx->tok_emb_train; ba.d_tok_emb = ctx->d_tok_emb; ba.dte_stride_b = T; ba.dte_stride_t = 1;
   ba.wte = g.wte; ba.wpe = g.wpe; ba.proj_wt = g.proj_wt; ba.pos1d = g.pos1d; ba.pe2 = g.pos2d_col; ba.head_wt = g.head_wt;
   ba.lnf_w = g.lnf_w; ba.lnf_b = g.lnf_b; ba.layers = ctx->layers_dev; ba.g_layers = ctx->g_layers_dev;
   ba.g_wte = grad_of(ctx, g.wte); ba.g_wpe = g.wpe ? grad_of(ctx, g.wpe) : nullptr;
@@ -1450,8 +1528,16 @@ int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* cur
   const int MB = c.max_batch;
   const View& f2 = net.fpn[2];
   const ChanTab ident{ctx->ident, ctx->ident + 2048, ctx->ident + 4096};
-  launch_efpn_linear_bwd(ctx->efpn_train, g.efpn_lin_wt, ctx->d_tok_emb, (long long)C, ctx->de_ws,
-                         grad_of(ctx, g.efpn_lin_wt), grad_of(ctx, g.efpn_lin_b), N, K, C, s);
+  {   // Linear backward as two GEMMs (see jn_reinforce_step)
+    ConvArgs la2{};
+    la2.in = ctx->d_tok_emb; la2.in_ld = C; la2.in_dtype = JN_F32; la2.itab = ident; la2.w = g.efpn_lin_wt; la2.bias = nullptr;
+    la2.out = ctx->de_ws; la2.out_ld = K; la2.out_dtype = JN_F32; la2.bf16_mfma = 0;
+    la2.N = N; la2.H = 1; la2.W = 1; la2.OH = 1; la2.OW = 1; la2.cin = C; la2.cout = K; la2.stride = 1; la2.act = ACT_NONE;
+    launch_pw(la2, s);
+    launch_relu_mask(ctx->de_ws, ctx->efpn_train, (long long)N * K, s);
+    launch_pw_bwd_weight(ctx->efpn_train, K, ctx->d_tok_emb, JN_F32, C, ident, grad_of(ctx, g.efpn_lin_wt), nullptr, N, K, C, s);
+    launch_colsum_add(ctx->d_tok_emb, N, C, grad_of(ctx, g.efpn_lin_b), s);
+  }
   float* g_f2 = net.gact + net.buf_off[f2.buf] * (size_t)MB + f2.coff;
   ConvArgs ca{};
   ca.in = ctx->de_ws; ca.in_ld = C; ca.in_dtype = JN_F32; ca.itab = ident; ca.w = g.efpn_w; ca.bias = nullptr;

@@ -109,9 +109,10 @@ struct Net {
   float* tab = nullptr;           // [n_slots][3][tab_channels]
   float* save = nullptr;          // [n_slots][2 * stat_channels]  (mean, invstd)
   double* stats = nullptr;        // [n_slots][2 * stat_channels]  (sum, sumsq)
-  float* gact = nullptr;          // gradient buffers, one slot: mirror of `act`
-  double* bred = nullptr;         // [JN_NREP][2 * stat_channels] backward reductions (sum g_y, sum g_y * zhat)
-  float* bconsts = nullptr;       // [3 * stat_channels] per-channel backward constants
+  int g_slots = 0;                // slots of the three gradient-side buffers below (backward is step-batched)
+  float* gact = nullptr;          // [g_slots] gradient buffers: mirror of one `act` slot each
+  double* bred = nullptr;         // [g_slots][JN_NREP][2 * stat_channels] backward reductions (sum g_y, sum g_y * zhat)
+  float* bconsts = nullptr;       // [g_slots][3 * stat_channels] per-channel backward constants
   bool eval_tab_dirty = true;     // slot-0 table must be rebuilt from the running statistics
 };
 

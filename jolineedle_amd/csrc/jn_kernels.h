@@ -25,6 +25,20 @@ struct ChanTab {
   float* sc; float* sh; float* fl;
 };
 
+// Step batching of the backward: ONE launch covers `n` workspace slots (glimpse steps of a trajectory, each
+// with its own batch-statistics tables); slot j adds j * stride to the per-slot pointers.  The default is the
+// single-pass case.
+struct SlotBatch {
+  int n = 1;
+  long long act = 0;      // activation elements between slots (z / x buffers)
+  long long grad = 0;     // gradient floats between slots
+  long long tab = 0;      // table floats between slots (the sc / sh / fl arrays each move by this)
+  long long save = 0;     // saved (mean, invstd) floats between slots
+  long long red = 0;      // doubles between slots of the reduction scratch
+  long long consts = 0;   // floats between slots of the per-channel constants
+  long long pos = 0;      // int64 elements between slots of the stem's patch positions
+};
+
 struct StemArgs {
   const float* src; const int64_t* positions; int pos_stride;   // positions[pos_stride * n + {0,1}] = (y, x)
   long long sample_stride, chan_stride; int row_stride;
@@ -45,6 +59,8 @@ struct ConvArgs {
   int w_transposed;                      // pw: w is [cin][cout] and read transposed (data-gradient)
   double* stats; long long stats_rep_stride;
   const int* skip_flag; int skip_when;
+  int n_slots;                           // pw: gridDim.z slots, pointers advance by the strides below (0 -> 1 slot)
+  long long in_slot_stride, out_slot_stride, tab_slot_stride;
 };
 
 int launch_stem(const StemArgs& a, hipStream_t s);
@@ -76,28 +92,33 @@ int launch_postprocess(const float* raw, int A, int N, float conf, float nms_thr
 
 // ---- backward of the conv stack (kernels_bwd.hip) ----------------------------------------
 int launch_bn_bwd_reduce(const float* g, int g_ld, const void* z, int z_dtype, int z_ld, ChanTab t, const float* save,
-                         int C, long long M, double* red_out, long long rep_stride, hipStream_t s);
+                         int C, long long M, double* red_out, long long rep_stride, hipStream_t s,
+                         const SlotBatch& sb = SlotBatch{});
 // sums the replicas -> consts[c] = {sum_gy/n, sum_gy_zhat/n, gamma*invstd}; dgamma/dbeta += totals
 int launch_bn_bwd_consts(const double* red, long long rep_stride, double count, const float* gamma, const float* save,
-                         float* consts, float* g_gamma, float* g_beta, int C, hipStream_t s);
+                         float* consts, float* g_gamma, float* g_beta, int C, hipStream_t s,
+                         const SlotBatch& sb = SlotBatch{});
 int launch_bn_bwd_gz(float* g, int g_ld, const void* z, int z_dtype, int z_ld, ChanTab t, const float* save,
-                     const float* consts, int C, long long M, hipStream_t s);
+                     const float* consts, int C, long long M, hipStream_t s, const SlotBatch& sb = SlotBatch{});
 // weight-gradient kernels add into wpart (replicated scratch, zero on entry and on exit) when the
 // tensor fits, else straight into gw; launch_wpart_reduce folds the replicas into gw.
 int launch_pw_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, int x_ld, ChanTab it, float* gw,
-                         float* wpart, long long M, int N, int K, hipStream_t s);
+                         float* wpart, long long M, int N, int K, hipStream_t s, const SlotBatch& sb = SlotBatch{},
+                         long long gz_slot_stride = -1);
 int launch_wpart_reduce(float* gw, float* wpart, int n, hipStream_t s);
 int launch_dw_bwd_data(const float* gz, int g_ld, const float* w, float* gin, int gin_ld, int C, int H, int W, int OH,
-                       int OW, int N, int stride, int accumulate, hipStream_t s);
+                       int OW, int N, int stride, int accumulate, hipStream_t s, const SlotBatch& sb = SlotBatch{});
 int launch_dw_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, int x_ld, ChanTab it, float* gw,
-                         float* wpart, int C, int H, int W, int OH, int OW, int N, int stride, hipStream_t s);
-int launch_stem_bwd_weight(const StemArgs& a, const float* gz, int g_ld, float* gw, float* wpart, hipStream_t s);
+                         float* wpart, int C, int H, int W, int OH, int OW, int N, int stride, hipStream_t s,
+                         const SlotBatch& sb = SlotBatch{});
+int launch_stem_bwd_weight(const StemArgs& a, const float* gz, int g_ld, float* gw, float* wpart, hipStream_t s,
+                           const SlotBatch& sb = SlotBatch{});
 int launch_spp_bwd(const void* cat, int dtype, float* gcat, int ld, int h, int H, int W, int N, ChanTab it,
-                   hipStream_t s);
+                   hipStream_t s, const SlotBatch& sb = SlotBatch{});
 int launch_upsample_bwd(const float* gdst, int dst_ld, float* gsrc, int src_ld, int C, int H, int W, int N,
-                        int accumulate, hipStream_t s);
+                        int accumulate, hipStream_t s, const SlotBatch& sb = SlotBatch{});
 int launch_grad_copy(const float* src, int src_ld, float* dst, int dst_ld, int C, long long M, int accumulate,
-                     hipStream_t s);
+                     hipStream_t s, const SlotBatch& sb = SlotBatch{});
 int launch_nchw_to_nhwc_grad(const float* in, float* out, int out_ld, int C, int HW, int N, int accumulate,
                              hipStream_t s);
 
@@ -188,7 +209,8 @@ struct GptBwdArgs {
   int pos_tokens;                   // T + 1 (rollout history) or T
   int pos1d_by_token;               // 1: token t has 1-D position t (full-sequence forward)
   const float* tok_emb;             // [B][T][C] patch embeddings
-  float* d_tok_emb;                 // [B][T][C] out
+  float* d_tok_emb;                 // out: row of (agent b, token t) at (b * dte_stride_b + t * dte_stride_t) * C
+  long long dte_stride_b, dte_stride_t;
   const float *wte, *wpe, *proj_wt, *pos1d, *pe2, *head_wt, *lnf_w, *lnf_b;
   const GptLayerPtrs* layers;       // weights
   const GptLayerPtrs* g_layers;     // gradients (same layout, non-const use)
@@ -198,8 +220,9 @@ struct GptBwdArgs {
 int launch_gpt_backward(const GptBwdArgs& a, hipStream_t s);
 int launch_ce_loss(const float* logits, const int64_t* target, const uint8_t* masks, float stop_weight, float* dlogits,
                    float* metrics, int n, int nA, int T, hipStream_t s);
-int launch_efpn_linear_bwd(const float* e, const float* wt, const float* dpe, long long dpe_stride, float* de,
-                           float* gwt, float* gb, int N, int K, int Co, hipStream_t s);
+// de[m][k] = 0 where e[m][k] <= 0 (ReLU mask of embed_fpn.0);  gb[o] += sum_m dpe[m][o]
+int launch_relu_mask(float* de, const float* e, long long n, hipStream_t s);
+int launch_colsum_add(const float* dpe, long long M, int Co, float* gb, hipStream_t s);
 int launch_adamw(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                  float eps, float wd, int step, float clip, float grad_scale, hipStream_t s);
 

@@ -35,8 +35,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const ZT* __restrict__ z, int z_ld, ChanTab t,
                                                             const float* __restrict__ save, int C, long long M,
                                                             int rows_per_block, double* __restrict__ red_out,
-                                                            long long rep_stride) {
+                                                            long long rep_stride, SlotBatch sb) {
   extern __shared__ float red[];    // [C][2]
+  {
+    const long long sl = blockIdx.y;
+    g += sl * sb.grad; z += sl * sb.act; save += sl * sb.save; red_out += sl * sb.red;
+    t.sc += sl * sb.tab; t.sh += sl * sb.tab;
+  }
   for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.0f;
   __syncthreads();
   const int C4 = C >> 2;
@@ -87,16 +92,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 
 int launch_bn_bwd_reduce(const float* g, int g_ld, const void* z, int z_dtype, int z_ld, ChanTab t, const float* save,
-                         int C, long long M, double* red_out, long long rep_stride, hipStream_t s) {
+                         int C, long long M, double* red_out, long long rep_stride, hipStream_t s, const SlotBatch& sb) {
   const int rstep = 256 / (C / 4) > 0 ? 256 / (C / 4) : 1;
   const int rows_per_block = rstep * 32;
-  const unsigned blocks = (unsigned)((M + rows_per_block - 1) / rows_per_block);
+  const dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block), sb.n);
   if (z_dtype == JN_BF16)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(blocks), dim3(256), (size_t)2 * C * sizeof(float), s, g, g_ld,
-                       (const bf16_t*)z, z_ld, t, save, C, M, rows_per_block, red_out, rep_stride);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), (size_t)2 * C * sizeof(float), s, g, g_ld,
+                       (const bf16_t*)z, z_ld, t, save, C, M, rows_per_block, red_out, rep_stride, sb);
   else
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), (size_t)2 * C * sizeof(float), s, g, g_ld,
-                       (const float*)z, z_ld, t, save, C, M, rows_per_block, red_out, rep_stride);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), (size_t)2 * C * sizeof(float), s, g, g_ld,
+                       (const float*)z, z_ld, t, save, C, M, rows_per_block, red_out, rep_stride, sb);
   return 0;
 }
 
@@ -104,29 +109,39 @@ int launch_bn_bwd_reduce(const float* g, int g_ld, const void* z, int z_dtype, i
 __global__ void bn_bwd_consts_kernel(const double* __restrict__ red, long long rep_stride, double count,
                                      const float* __restrict__ gamma, const float* __restrict__ save,
                                      float* __restrict__ consts, float* __restrict__ g_gamma,
-                                     float* __restrict__ g_beta, int C) {
+                                     float* __restrict__ g_beta, int C, SlotBatch sb) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
+  const int sl = blockIdx.y;
+  const double* rd = red + sl * sb.red;
+  const float* sv = save + sl * sb.save;
+  float* cs = consts + sl * sb.consts;
   double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < JN_NREP; ++r) { s1 += red[r * rep_stride + 2 * c]; s2 += red[r * rep_stride + 2 * c + 1]; }
-  consts[3 * c] = (float)(s1 / count);
-  consts[3 * c + 1] = (float)(s2 / count);
-  consts[3 * c + 2] = gamma[c] * save[2 * c + 1];
-  g_beta[c] += (float)s1;
-  g_gamma[c] += (float)s2;
+  for (int r = 0; r < JN_NREP; ++r) { s1 += rd[r * rep_stride + 2 * c]; s2 += rd[r * rep_stride + 2 * c + 1]; }
+  cs[3 * c] = (float)(s1 / count);
+  cs[3 * c + 1] = (float)(s2 / count);
+  cs[3 * c + 2] = gamma[c] * sv[2 * c + 1];
+  if (sb.n == 1) { g_beta[c] += (float)s1; g_gamma[c] += (float)s2; }
+  else { atomicAdd(&g_beta[c], (float)s1); atomicAdd(&g_gamma[c], (float)s2); }
 }
 
 int launch_bn_bwd_consts(const double* red, long long rep_stride, double count, const float* gamma, const float* save,
-                         float* consts, float* g_gamma, float* g_beta, int C, hipStream_t s) {
-  hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((C + 63) / 64), dim3(64), 0, s, red, rep_stride, count, gamma, save,
-                     consts, g_gamma, g_beta, C);
+                         float* consts, float* g_gamma, float* g_beta, int C, hipStream_t s, const SlotBatch& sb) {
+  hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((C + 63) / 64, sb.n), dim3(64), 0, s, red, rep_stride, count, gamma, save,
+                     consts, g_gamma, g_beta, C, sb);
   return 0;
 }
 
 template <typename ZT>
 __global__ __launch_bounds__(256) void bn_bwd_gz_kernel(float* __restrict__ g, int g_ld, const ZT* __restrict__ z,
                                                         int z_ld, ChanTab t, const float* __restrict__ save,
-                                                        const float* __restrict__ consts, int C, long long M) {
+                                                        const float* __restrict__ consts, int C, long long M,
+                                                        SlotBatch sb) {
+  {
+    const long long sl = blockIdx.y;
+    g += sl * sb.grad; z += sl * sb.act; save += sl * sb.save; consts += sl * sb.consts;
+    t.sc += sl * sb.tab; t.sh += sl * sb.tab;
+  }
   const int C4 = C >> 2;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= M * C4) return;
@@ -148,13 +163,13 @@ __global__ __launch_bounds__(256) void bn_bwd_gz_kernel(float* __restrict__ g, i
 }
 
 int launch_bn_bwd_gz(float* g, int g_ld, const void* z, int z_dtype, int z_ld, ChanTab t, const float* save,
-                     const float* consts, int C, long long M, hipStream_t s) {
+                     const float* consts, int C, long long M, hipStream_t s, const SlotBatch& sb) {
   const long long total = M * (C / 4);
-  const dim3 grid((unsigned)((total + 255) / 256));
+  const dim3 grid((unsigned)((total + 255) / 256), sb.n);
   if (z_dtype == JN_BF16)
-    hipLaunchKernelGGL(bn_bwd_gz_kernel<bf16_t>, grid, dim3(256), 0, s, g, g_ld, (const bf16_t*)z, z_ld, t, save, consts, C, M);
+    hipLaunchKernelGGL(bn_bwd_gz_kernel<bf16_t>, grid, dim3(256), 0, s, g, g_ld, (const bf16_t*)z, z_ld, t, save, consts, C, M, sb);
   else
-    hipLaunchKernelGGL(bn_bwd_gz_kernel<float>, grid, dim3(256), 0, s, g, g_ld, (const float*)z, z_ld, t, save, consts, C, M);
+    hipLaunchKernelGGL(bn_bwd_gz_kernel<float>, grid, dim3(256), 0, s, g, g_ld, (const float*)z, z_ld, t, save, consts, C, M, sb);
   return 0;
 }
 
@@ -182,8 +197,12 @@ template <int CTN, int CTK, typename XT>
 __global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const float* __restrict__ gz, int g_ld,
                                                             const XT* __restrict__ x, int x_ld, ChanTab it,
                                                             float* __restrict__ gw, int rep, long long M, int N,
-                                                            int K, int rows_per_block) {
+                                                            int K, int rows_per_block, int chunks_per_slot,
+                                                            long long gz_slot, long long x_slot, long long tab_slot) {
   constexpr int LDN = 16 * CTN + 4, LDK = 16 * CTK + 4;
+  const int slot = blockIdx.x / chunks_per_slot, chunk = blockIdx.x - slot * chunks_per_slot;
+  gz += slot * gz_slot; x += slot * x_slot;
+  it.sc += slot * tab_slot; it.sh += slot * tab_slot; it.fl += slot * tab_slot;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Gs = sm;                      // [WG_RB][LDN]
   float* As = sm + WG_RB * LDN;        // [WG_RB][LDK]
@@ -191,7 +210,7 @@ __global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const float* __restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.y * 16 * CTN, k0 = blockIdx.z * 16 * CTK;
-  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r0 = (long long)chunk * rows_per_block;
   const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
   f32x4 acc[CTN][CTK];
 #pragma unroll
@@ -256,31 +275,34 @@ __global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const float* __restr
 
 template <int CTN, int CTK>
 static void launch_pw_bw_t(const float* gz, int g_ld, const void* x, int x_dtype, int x_ld, ChanTab it, float* gw, int rep,
-                           long long M, int N, int K, hipStream_t s) {
+                           long long M, int N, int K, hipStream_t s, const SlotBatch& sb, long long gz_slot) {
   // aim at ~768 workgroups: enough to fill 256 CUs x 3, few enough that the final atomics stay cheap
   const long long tiles = (long long)((N + 16 * CTN - 1) / (16 * CTN)) * ((K + 16 * CTK - 1) / (16 * CTK));
-  long long rpb = (M * tiles / 768 + 63) / 64 * 64;
+  long long rpb = (M * sb.n * tiles / 768 + 63) / 64 * 64;
   if (rpb < 64) rpb = 64;
   if (rpb > 4096) rpb = 4096;
   const int rows_per_block = (int)rpb;
-  dim3 grid((unsigned)((M + rows_per_block - 1) / rows_per_block), (N + 16 * CTN - 1) / (16 * CTN),
-            (K + 16 * CTK - 1) / (16 * CTK));
+  const int chunks_per_slot = (int)((M + rows_per_block - 1) / rows_per_block);
+  const long long x_slot = sb.act, tab_slot = sb.tab;
+  dim3 grid((unsigned)(chunks_per_slot * sb.n), (N + 16 * CTN - 1) / (16 * CTN), (K + 16 * CTK - 1) / (16 * CTK));
   const size_t smem = ((size_t)WG_RB * (16 * CTN + 4 + 16 * CTK + 4) + 256 * CTN * CTK) * sizeof(float);
   if (x_dtype == JN_BF16)
     hipLaunchKernelGGL((pw_bwd_weight_kernel<CTN, CTK, bf16_t>), grid, dim3(256), smem, s, gz, g_ld, (const bf16_t*)x, x_ld,
-                       it, gw, rep, M, N, K, rows_per_block);
+                       it, gw, rep, M, N, K, rows_per_block, chunks_per_slot, gz_slot, x_slot, tab_slot);
   else
     hipLaunchKernelGGL((pw_bwd_weight_kernel<CTN, CTK, float>), grid, dim3(256), smem, s, gz, g_ld, (const float*)x, x_ld,
-                       it, gw, rep, M, N, K, rows_per_block);
+                       it, gw, rep, M, N, K, rows_per_block, chunks_per_slot, gz_slot, x_slot, tab_slot);
 }
 
 int launch_pw_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, int x_ld, ChanTab it, float* gw_final,
-                         float* wpart, long long M, int N, int K, hipStream_t s) {
+                         float* wpart, long long M, int N, int K, hipStream_t s, const SlotBatch& sb,
+                         long long gz_slot_stride) {
+  const long long gz_slot = gz_slot_stride >= 0 ? gz_slot_stride : sb.grad;
   const int rep = (wpart && N * K <= JN_WPART_MAX) ? 1 : 0;
   float* gw = rep ? wpart : gw_final;
   const int tn = (N + 15) / 16, tk = (K + 15) / 16;
   const int cn = tn >= 4 ? 4 : (tn == 3 ? 3 : tn), ck = tk >= 4 ? 4 : (tk == 3 ? 3 : tk);
-#define JN_BW(A, B) if (cn == A && ck == B) { launch_pw_bw_t<A, B>(gz, g_ld, x, x_dtype, x_ld, it, gw, rep, M, N, K, s); \
+#define JN_BW(A, B) if (cn == A && ck == B) { launch_pw_bw_t<A, B>(gz, g_ld, x, x_dtype, x_ld, it, gw, rep, M, N, K, s, sb, gz_slot); \
     if (rep) launch_wpart_reduce(gw_final, wpart, N * K, s); return 0; }
   JN_BW(1, 1) JN_BW(1, 2) JN_BW(1, 3) JN_BW(1, 4) JN_BW(2, 1) JN_BW(2, 2) JN_BW(2, 3) JN_BW(2, 4)
   JN_BW(3, 1) JN_BW(3, 2) JN_BW(3, 3) JN_BW(3, 4) JN_BW(4, 1) JN_BW(4, 2) JN_BW(4, 3) JN_BW(4, 4)
@@ -294,7 +316,8 @@ template <int S>
 __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restrict__ gz, int g_ld,
                                                           const float* __restrict__ w, float* __restrict__ gin,
                                                           int gin_ld, int C, int H, int W, int OH, int OW, int N,
-                                                          int accumulate) {
+                                                          int accumulate, long long g_slot) {
+  gz += blockIdx.y * g_slot; gin += blockIdx.y * g_slot;
   const int C4 = C >> 2;
   const long long total = (long long)N * H * W * C4;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -326,15 +349,15 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restric
 }
 
 int launch_dw_bwd_data(const float* gz, int g_ld, const float* w, float* gin, int gin_ld, int C, int H, int W, int OH,
-                       int OW, int N, int stride, int accumulate, hipStream_t s) {
+                       int OW, int N, int stride, int accumulate, hipStream_t s, const SlotBatch& sb) {
   const long long total = (long long)N * H * W * (C / 4);
-  const unsigned blocks = (unsigned)((total + 255) / 256);
+  const dim3 blocks((unsigned)((total + 255) / 256), sb.n);
   if (stride == 1)
-    hipLaunchKernelGGL(dw_bwd_data_kernel<1>, dim3(blocks), dim3(256), 0, s, gz, g_ld, w, gin, gin_ld, C, H, W, OH, OW, N,
-                       accumulate);
+    hipLaunchKernelGGL(dw_bwd_data_kernel<1>, blocks, dim3(256), 0, s, gz, g_ld, w, gin, gin_ld, C, H, W, OH, OW, N,
+                       accumulate, sb.grad);
   else
-    hipLaunchKernelGGL(dw_bwd_data_kernel<2>, dim3(blocks), dim3(256), 0, s, gz, g_ld, w, gin, gin_ld, C, H, W, OH, OW, N,
-                       accumulate);
+    hipLaunchKernelGGL(dw_bwd_data_kernel<2>, blocks, dim3(256), 0, s, gz, g_ld, w, gin, gin_ld, C, H, W, OH, OW, N,
+                       accumulate, sb.grad);
   return 0;
 }
 
@@ -343,8 +366,13 @@ template <int S, typename XT>
 __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ gz, int g_ld,
                                                             const XT* __restrict__ x, int x_ld, ChanTab it,
                                                             float* __restrict__ gw, int rep, int C, int H, int W,
-                                                            int OH, int OW, int N) {
+                                                            int OH, int OW, int N, SlotBatch sb) {
   extern __shared__ float red[];   // [9][C]
+  {
+    const long long sl = blockIdx.y;
+    gz += sl * sb.grad; x += sl * sb.act;
+    it.sc += sl * sb.tab; it.sh += sl * sb.tab; it.fl += sl * sb.tab;
+  }
   for (int i = threadIdx.x; i < 9 * C; i += 256) red[i] = 0.0f;
   __syncthreads();
   const int C4 = C >> 2;
@@ -401,23 +429,25 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
       }
   }
   __syncthreads();
-  float* dst = rep ? gw + (blockIdx.x % JN_NREP) * JN_WPART_MAX : gw;
+  float* dst = rep ? gw + ((blockIdx.x + 5 * blockIdx.y) % JN_NREP) * JN_WPART_MAX : gw;
   for (int i = threadIdx.x; i < 9 * C; i += 256) atomicAdd(&dst[i], red[i]);
 }
 
 int launch_dw_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, int x_ld, ChanTab it, float* gw_final,
-                         float* wpart, int C, int H, int W, int OH, int OW, int N, int stride, hipStream_t s) {
+                         float* wpart, int C, int H, int W, int OH, int OW, int N, int stride, hipStream_t s,
+                         const SlotBatch& sb) {
   const int rep = (wpart && 9 * C <= JN_WPART_MAX) ? 1 : 0;
   float* gw = rep ? wpart : gw_final;
   const int YS = (OH + 3) / 4;
   const long long total = (long long)N * YS * OW * (C / 4);
   long long nb = (total + 255) / 256;
-  if (nb > 2048) nb = 2048;                       // grid-stride: each thread folds many strips before its atomics
-  const unsigned blocks = (unsigned)nb;
+  const long long cap = sb.n >= 8 ? 256 : 2048 / sb.n;
+  if (nb > cap) nb = cap;                         // grid-stride: each thread folds many strips before its atomics
+  const dim3 blocks((unsigned)nb, sb.n);
   const size_t smem = (size_t)9 * C * sizeof(float);
 #define JN_DWW(S_, T_)                                                                                            \
-  hipLaunchKernelGGL((dw_bwd_weight_kernel<S_, T_>), dim3(blocks), dim3(256), smem, s, gz, g_ld, (const T_*)x, x_ld, it, \
-                     gw, rep, C, H, W, OH, OW, N)
+  hipLaunchKernelGGL((dw_bwd_weight_kernel<S_, T_>), blocks, dim3(256), smem, s, gz, g_ld, (const T_*)x, x_ld, it, \
+                     gw, rep, C, H, W, OH, OW, N, sb)
   if (x_dtype == JN_BF16) { if (stride == 1) JN_DWW(1, bf16_t); else JN_DWW(2, bf16_t); }
   else { if (stride == 1) JN_DWW(1, float); else JN_DWW(2, float); }
 #undef JN_DWW
@@ -431,8 +461,10 @@ constexpr int SB_TY = 8, SB_TX = 32, SB_IH = 2 * SB_TY + 4, SB_IW = 2 * SB_TX + 
 __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
     const float* __restrict__ src, const long long* __restrict__ pos, int pos_stride, long long sample_stride,
     long long chan_stride, int row_stride, int P, const float* __restrict__ gz, int g_ld, int cout, int ocg,
-    int tiles_x, int tiles_y, int n_tiles, float* __restrict__ gw) {
+    int tiles_x, int tiles_y, int n_tiles, float* __restrict__ gw, long long pos_slot, long long g_slot) {
   __shared__ __attribute__((aligned(16))) float tile[3 * SB_IH * SB_IW];
+  if (pos) pos += blockIdx.z * pos_slot;
+  gz += blockIdx.z * g_slot;
   __shared__ float Gz[SB_TY * SB_TX * 16];
   __shared__ float Ts[16 * 112];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -487,21 +519,23 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
 #pragma unroll
     for (int r = 0; r < 4; ++r) atomicAdd(&Ts[(4 * g + r) * 112 + 16 * t + lm], acc[t][r]);
   __syncthreads();
-  float* dst = gw + (blockIdx.x % JN_NREP) * JN_WPART_MAX;
+  float* dst = gw + ((blockIdx.x + 5 * blockIdx.z) % JN_NREP) * JN_WPART_MAX;
   for (int i = tid; i < 16 * 108; i += 256) {
     const int oc = i / 108, k = i % 108;
     atomicAdd(&dst[(long long)k * cout + og * 16 + oc], Ts[oc * 112 + k]);
   }
 }
 
-int launch_stem_bwd_weight(const StemArgs& a, const float* gz, int g_ld, float* gw, float* wpart, hipStream_t s) {
+int launch_stem_bwd_weight(const StemArgs& a, const float* gz, int g_ld, float* gw, float* wpart, hipStream_t s,
+                           const SlotBatch& sb) {
   const int OH = a.P / 2, ocg = a.cout / 16;
   const int tiles_x = (OH + SB_TX - 1) / SB_TX, tiles_y = (OH + SB_TY - 1) / SB_TY;
   const int n_tiles = tiles_x * tiles_y * a.N;
-  dim3 grid(n_tiles < 1024 ? n_tiles : 1024, ocg);
+  const int cap = sb.n >= 4 ? 256 : 1024 / sb.n;
+  dim3 grid(n_tiles < cap ? n_tiles : cap, ocg, sb.n);
   hipLaunchKernelGGL(stem_bwd_weight_kernel, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.pos_stride,
                      a.sample_stride, a.chan_stride, a.row_stride, a.P, gz, g_ld, a.cout, ocg, tiles_x, tiles_y, n_tiles,
-                     wpart);
+                     wpart, sb.pos, sb.grad);
   launch_wpart_reduce(gw, wpart, 108 * a.cout, s);
   return 0;
 }
@@ -509,8 +543,13 @@ int launch_stem_bwd_weight(const StemArgs& a, const float* gz, int g_ld, float* 
 // ---- SPP backward: g0 += route(g1, argmax5) + route(g2, argmax9) + route(g3, argmax13) ----------
 template <typename AT>
 __global__ __launch_bounds__(256) void spp_bwd_kernel(const AT* __restrict__ cat, float* __restrict__ gcat, int ld,
-                                                      int h, int H, int W, int cb, ChanTab it) {
+                                                      int h, int H, int W, int cb, ChanTab it, SlotBatch sb) {
   extern __shared__ float sp[];
+  {
+    const long long sl = blockIdx.z;
+    cat += sl * sb.act; gcat += sl * sb.grad;
+    it.sc += sl * sb.tab; it.sh += sl * sb.tab; it.fl += sl * sb.tab;
+  }
   const int HW = H * W;
   float* A = sp;                 // activation of slice 0
   float* G = sp + HW * cb;       // gradient accumulator for slice 0
@@ -544,23 +583,24 @@ __global__ __launch_bounds__(256) void spp_bwd_kernel(const AT* __restrict__ cat
 }
 
 int launch_spp_bwd(const void* cat, int dtype, float* gcat, int ld, int h, int H, int W, int N, ChanTab it,
-                   hipStream_t s) {
+                   hipStream_t s, const SlotBatch& sb) {
   int cb = 32;
   while (cb > 4 && (size_t)H * W * cb * 2 * sizeof(float) > 48 * 1024) cb >>= 1;
-  dim3 grid(h / cb, N);
+  dim3 grid(h / cb, N, sb.n);
   if (dtype == JN_BF16)
     hipLaunchKernelGGL(spp_bwd_kernel<bf16_t>, grid, dim3(256), (size_t)H * W * cb * 2 * sizeof(float), s, (const bf16_t*)cat,
-                       gcat, ld, h, H, W, cb, it);
+                       gcat, ld, h, H, W, cb, it, sb);
   else
     hipLaunchKernelGGL(spp_bwd_kernel<float>, grid, dim3(256), (size_t)H * W * cb * 2 * sizeof(float), s, (const float*)cat,
-                       gcat, ld, h, H, W, cb, it);
+                       gcat, ld, h, H, W, cb, it, sb);
   return 0;
 }
 
 // upsample backward: g_src (=|+=) sum of the 2x2 children
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ gdst, int dst_ld,
                                                            float* __restrict__ gsrc, int src_ld, int C, int H, int W,
-                                                           long long total, int accumulate) {
+                                                           long long total, int accumulate, long long g_slot) {
+  gdst += blockIdx.y * g_slot; gsrc += blockIdx.y * g_slot;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int C4 = C >> 2;
@@ -581,17 +621,18 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
 }
 
 int launch_upsample_bwd(const float* gdst, int dst_ld, float* gsrc, int src_ld, int C, int H, int W, int N,
-                        int accumulate, hipStream_t s) {
+                        int accumulate, hipStream_t s, const SlotBatch& sb) {
   const long long total = (long long)N * H * W * (C / 4);
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gdst, dst_ld, gsrc,
-                     src_ld, C, H, W, total, accumulate);
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)((total + 255) / 256), sb.n), dim3(256), 0, s, gdst, dst_ld, gsrc,
+                     src_ld, C, H, W, total, accumulate, sb.grad);
   return 0;
 }
 
 // dst (=|+=) src over a [M][C] view (shortcut backward, gradient seeding)
 __global__ __launch_bounds__(256) void grad_copy_kernel(const float* __restrict__ src, int src_ld,
                                                         float* __restrict__ dst, int dst_ld, int C, long long M,
-                                                        int accumulate) {
+                                                        int accumulate, long long g_slot) {
+  src += blockIdx.y * g_slot; dst += blockIdx.y * g_slot;
   const int C4 = C >> 2;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= M * C4) return;
@@ -603,10 +644,10 @@ __global__ __launch_bounds__(256) void grad_copy_kernel(const float* __restrict_
 }
 
 int launch_grad_copy(const float* src, int src_ld, float* dst, int dst_ld, int C, long long M, int accumulate,
-                     hipStream_t s) {
+                     hipStream_t s, const SlotBatch& sb) {
   const long long total = M * (C / 4);
-  hipLaunchKernelGGL(grad_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, src_ld, dst, dst_ld,
-                     C, M, accumulate);
+  hipLaunchKernelGGL(grad_copy_kernel, dim3((unsigned)((total + 255) / 256), sb.n), dim3(256), 0, s, src, src_ld, dst, dst_ld,
+                     C, M, accumulate, sb.grad);
   return 0;
 }
 

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include "jn_kernels.h"
+#include "jn_types.h"
 
 namespace jnr {
 
@@ -487,13 +488,13 @@ __global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
     if (!a.dec_pos_enc && a.g_wpe)
       for (int c = tid; c < C; c += TB) atomicAdd(&a.g_wpe[p1 * C + c], dparts[p_pos * C + c]);
     if (p_patch >= 0)
-      for (int c = tid; c < C; c += TB) a.d_tok_emb[((long long)b * a.T + t) * C + c] = dparts[p_patch * C + c];
+      for (int c = tid; c < C; c += TB) a.d_tok_emb[((long long)b * a.dte_stride_b + t * a.dte_stride_t) * C + c] = dparts[p_patch * C + c];
     (void)p_pos2;
     __syncthreads();
   }
   // steps that were never executed get a zero patch-embedding gradient
   for (int t = S; t < a.T; ++t)
-    for (int c = tid; c < C; c += TB) a.d_tok_emb[((long long)b * a.T + t) * C + c] = 0.0f;
+    for (int c = tid; c < C; c += TB) a.d_tok_emb[((long long)b * a.dte_stride_b + t * a.dte_stride_t) * C + c] = 0.0f;
 }
 
 int launch_gpt_backward(const GptBwdArgs& a, hipStream_t s) {
@@ -501,55 +502,39 @@ int launch_gpt_backward(const GptBwdArgs& a, hipStream_t s) {
   return 0;
 }
 
-// ---- embed_fpn backward for one glimpse step ---------------------------------------------------
-// patch_emb[n][o] = b[o] + sum_k e[n][k] * Wt[k][o],  e = relu(conv1x1(a))   (k = hw*C + c)
-// de[n][k] = (e > 0) * sum_o dpe[n][o] * Wt[k][o];   gWt[k][o] += sum_n e[n][k]*dpe[n][o];  gb += sum_n dpe
-__global__ __launch_bounds__(TB) void efpn_linear_bwd_kernel(const float* __restrict__ e, const float* __restrict__ wt,
-                                                             const float* __restrict__ dpe, long long dpe_stride,
-                                                             float* __restrict__ de, float* __restrict__ gwt,
-                                                             float* __restrict__ gb, int N, int K, int Co) {
-  extern __shared__ float sd[];     // [N][Co] dpe
-  for (int i = threadIdx.x; i < N * Co; i += TB) sd[i] = dpe[(long long)(i / Co) * dpe_stride + (i % Co)];
-  __syncthreads();
-  const int k = blockIdx.x * TB + threadIdx.x;
-  if (blockIdx.x == 0)
-    for (int o = threadIdx.x; o < Co; o += TB) {
-      float acc = 0.0f;
-      for (int n = 0; n < N; ++n) acc += sd[n * Co + o];
-      gb[o] += acc;
-    }
-  if (k >= K) return;
-  float w[8];
-  for (int o0 = 0; o0 < Co; o0 += 8) {
+__global__ __launch_bounds__(TB) void relu_mask_kernel(float* __restrict__ de, const float* __restrict__ e, long long n4) {
+  const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 d = reinterpret_cast<f32x4*>(de)[i];
+  const f32x4 ev = reinterpret_cast<const f32x4*>(e)[i];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) w[q] = (o0 + q < Co) ? wt[(long long)k * Co + o0 + q] : 0.0f;
-    float gacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int n = 0; n < N; ++n) {
-      const float ev = e[(long long)n * K + k];
-      float d = 0.0f;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        if (o0 + q < Co) {
-          const float dv = sd[n * Co + o0 + q];
-          d = fmaf(dv, w[q], d);
-          gacc[q] = fmaf(ev, dv, gacc[q]);
-        }
-      }
-      const float prev = o0 ? de[(long long)n * K + k] : 0.0f;
-      de[(long long)n * K + k] = prev + d;
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (o0 + q < Co) gwt[(long long)k * Co + o0 + q] += gacc[q];
-  }
-  for (int n = 0; n < N; ++n)
-    if (e[(long long)n * K + k] <= 0.0f) de[(long long)n * K + k] = 0.0f;     // ReLU mask
+  for (int q = 0; q < 4; ++q) if (ev[q] <= 0.0f) d[q] = 0.0f;
+  reinterpret_cast<f32x4*>(de)[i] = d;
 }
 
-int launch_efpn_linear_bwd(const float* e, const float* wt, const float* dpe, long long dpe_stride, float* de,
-                           float* gwt, float* gb, int N, int K, int Co, hipStream_t s) {
-  hipLaunchKernelGGL(efpn_linear_bwd_kernel, dim3((K + TB - 1) / TB), dim3(TB), (size_t)N * Co * sizeof(float), s, e, wt,
-                     dpe, dpe_stride, de, gwt, gb, N, K, Co);
+int launch_relu_mask(float* de, const float* e, long long n, hipStream_t s) {
+  const long long n4 = n / 4;       // n = rows * h*w*C with C % 4 == 0
+  hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)((n4 + TB - 1) / TB)), dim3(TB), 0, s, de, e, n4);
+  return 0;
+}
+
+__global__ __launch_bounds__(TB) void colsum_add_kernel(const float* __restrict__ dpe, long long M, int Co,
+                                                        float* __restrict__ gb) {
+  __shared__ float part[TB];
+  const int o = blockIdx.x;
+  float acc = 0.0f;
+  for (long long m = threadIdx.x; m < M; m += TB) acc += dpe[m * Co + o];
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int st = TB / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gb[o] += part[0];
+}
+
+int launch_colsum_add(const float* dpe, long long M, int Co, float* gb, hipStream_t s) {
+  hipLaunchKernelGGL(colsum_add_kernel, dim3(Co), dim3(TB), 0, s, dpe, M, Co, gb);
   return 0;
 }
 

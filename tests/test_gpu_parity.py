@@ -413,10 +413,13 @@ def _oracle_reinforce_grads(oracle, images, bboxes, start, forced, P, Tn, stop, 
     return ro, m
 
 
-@pytest.mark.parametrize("stop,B,P,Tn", [(True, 3, 64, 4), (False, 2, 96, 3)])
-def test_reinforce_iteration_gradients_vs_oracle(stop, B, P, Tn):
+@pytest.mark.parametrize("stop,B,P,Tn,grad_slots", [(True, 3, 64, 4, None), (False, 2, 96, 3, None), (True, 3, 64, 4, 3)])
+def test_reinforce_iteration_gradients_vs_oracle(stop, B, P, Tn, grad_slots, monkeypatch):
     """loss.backward() of a whole REINFORCE iteration (train-mode BN per glimpse step, T backbone
-    passes, causal GPT over the trajectory) against torch autograd on the CPU oracle."""
+    passes, causal GPT over the trajectory) against torch autograd on the CPU oracle.  The backward is
+    step-batched: all T passes per launch, or chunks of `grad_slots` passes when memory is capped."""
+    if grad_slots:
+        monkeypatch.setenv("JN_GRAD_SLOTS", str(grad_slots))
     nA = 9 if stop else 8
     product, oracle = make_pair(5, patch_size=P, block_size=Tn, nclasses=nA, with_detector=False, image_processor=None)
     images, bboxes, start = synth_batch(B, 3, 4, P, seed=41)
