@@ -773,9 +773,20 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
                            M, red, rep_stride, s, sb);
       launch_bn_bwd_consts(red, rep_stride, (double)M, cw.gamma_dev, save + 2 * cw.stat_off, consts,
                            grad_of(ctx, cw.gamma_dev), grad_of(ctx, cw.beta_dev), cw.cout, s, sb);
+      float* gw = grad_of(ctx, cw.w_dev);
+      static const bool no_fused = std::getenv("JN_NO_FUSED_BWD") != nullptr;
+      if (op.kind == OP_PW && net.act_dtype == JN_F32 && !no_fused && pw_bwd_fused_supported(cw.cout, cw.cin)) {
+        PwBwdFusedArgs fa{};
+        fa.g = gptr(op.out); fa.g_ld = ld(op.out); fa.z = (const float*)ptr(op.out); fa.z_ld = ld(op.out); fa.ot = tab(op.out);
+        fa.save = save + 2 * cw.stat_off; fa.consts = consts;
+        fa.x = (const float*)ptr(op.in); fa.x_ld = ld(op.in); fa.it = tab(op.in); fa.w = cw.w_dev;
+        fa.gx = gptr(op.in); fa.gx_ld = ld(op.in); fa.accumulate = op.acc_in ? 1 : 0;
+        fa.gw = gw; fa.wpart = ctx->wpart; fa.M = M; fa.cout = cw.cout; fa.cin = cw.cin; fa.sb = sb;
+        launch_pw_bwd_fused(fa, s);
+        continue;
+      }
       launch_bn_bwd_gz(gptr(op.out), ld(op.out), ptr(op.out), net.act_dtype, ld(op.out), tab(op.out), save + 2 * cw.stat_off, consts,
                        cw.cout, M, s, sb);
-      float* gw = grad_of(ctx, cw.w_dev);
       if (op.kind == OP_PW) {
         ConvArgs a{};
         a.in = gptr(op.out); a.in_ld = ld(op.out); a.in_dtype = JN_F32; a.itab = ident; a.w = cw.w_dev; a.bias = nullptr;

@@ -106,6 +106,20 @@ int launch_pw_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, 
                          float* wpart, long long M, int N, int K, hipStream_t s, const SlotBatch& sb = SlotBatch{},
                          long long gz_slot_stride = -1);
 int launch_wpart_reduce(float* gw, float* wpart, int n, hipStream_t s);
+// bn_bwd_gz + data gradient + weight gradient of a pointwise layer in one pass (few-channel layers; fp32 buffers)
+struct PwBwdFusedArgs {
+  const float* g; int g_ld;              // d loss / d activation of the layer output
+  const float* z; int z_ld; ChanTab ot;  // raw layer output and its table
+  const float* save; const float* consts;
+  const float* x; int x_ld; ChanTab it;  // raw layer input and its table
+  const float* w;                        // [cout][cin]
+  float* gx; int gx_ld; int accumulate;  // d loss / d activation of the layer input
+  float* gw; float* wpart;
+  long long M; int cout, cin;
+  SlotBatch sb;
+};
+bool pw_bwd_fused_supported(int cout, int cin);
+int launch_pw_bwd_fused(const PwBwdFusedArgs& a, hipStream_t s);
 int launch_dw_bwd_data(const float* gz, int g_ld, const float* w, float* gin, int gin_ld, int C, int H, int W, int OH,
                        int OW, int N, int stride, int accumulate, hipStream_t s, const SlotBatch& sb = SlotBatch{});
 int launch_dw_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, int x_ld, ChanTab it, float* gw,

@@ -310,6 +310,208 @@ int launch_pw_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, 
   return -1;
 }
 
+// ---- 2+3+4 fused for pointwise layers with few channels ------------------------------------------
+// One pass over (g_a, z) of the layer output and z of the layer input does the whole layer:
+//   g_z = k * (g_a * silu'(y) - c1 - zhat * c2)      (never written to HBM)
+//   g_in (=|+=) g_z . W                              (phase 2: the forward kernel's MFMA loop with X = g_z, W^T)
+//   dW  += g_z^T . a_in                              (phase 3: contraction over the 64 pixels of the tile)
+// HBM traffic 8 B/output + 8 B/input element instead of 20 + 8 for the bn_bwd_gz / data / weight kernels.
+// Workgroup = 4 waves, 64 pixels per iteration, persistent over the tiles of ONE slot (blockIdx.y) so the
+// per-channel constants sit in registers and dW in accumulators; Cout = 16*CTN, Cin = 16*CTK, CTN*CTK <= 16.
+template <int CTN, int CTK>
+__global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
+    const float* __restrict__ g, int g_ld, const float* __restrict__ z, int z_ld, ChanTab ot,
+    const float* __restrict__ save, const float* __restrict__ consts, const float* __restrict__ x, int x_ld,
+    ChanTab it, const float* __restrict__ w, float* __restrict__ gx, int gx_ld, int accumulate,
+    float* __restrict__ gw, int rep, long long M, SlotBatch sb) {
+  constexpr int N = 16 * CTN, K = 16 * CTK;          // output / input channels
+  constexpr int LDG = N + 4, LDA = K + 4, LDW = N + 4;
+  constexpr int NG = 64 * (N / 4) / 256, NA = 64 * (K / 4) / 256;     // f32x4 per thread per tile (may be 0 -> 1)
+  constexpr int NGq = NG > 0 ? NG : 1, NAq = NA > 0 ? NA : 1;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Gs = sm;                       // [64][LDG]  g_z tile
+  float* As = Gs + 64 * LDG;            // [64][LDA]  activated input tile
+  float* Wt = As + 64 * LDA;            // [K][LDW]   W^T (cin-major, cout contiguous)
+  float* Ts = Wt + K * LDW;             // [N][K]     cross-wave dW sum
+  {
+    const long long sl = blockIdx.y;
+    g += sl * sb.grad; z += sl * sb.act; x += sl * sb.act; gx += sl * sb.grad;
+    save += sl * sb.save; consts += sl * sb.consts;
+    ot.sc += sl * sb.tab; ot.sh += sl * sb.tab;
+    it.sc += sl * sb.tab; it.sh += sl * sb.tab; it.fl += sl * sb.tab;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, gq = lane >> 4;
+  for (int i = tid; i < N * K; i += 256) {           // w is [N][K] row-major
+    const int n = i / K, k = i - n * K;
+    Wt[k * LDW + n] = w[i];
+  }
+  // per-thread channel quads of the staging loops never change (256 % (N/4) == 0, 256 % (K/4) == 0)
+  const int nq = tid % (N / 4), kq = tid % (K / 4);
+  f32x4 o_sc, o_sh, o_mean, o_istd, o_c1, o_c2, o_k;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = 4 * nq + q;
+    o_sc[q] = ot.sc[c]; o_sh[q] = ot.sh[c]; o_mean[q] = save[2 * c]; o_istd[q] = save[2 * c + 1];
+    o_c1[q] = consts[3 * c]; o_c2[q] = consts[3 * c + 1]; o_k[q] = consts[3 * c + 2];
+  }
+  const f32x4 i_sc = *reinterpret_cast<const f32x4*>(it.sc + 4 * kq), i_sh = *reinterpret_cast<const f32x4*>(it.sh + 4 * kq),
+              i_fl = *reinterpret_cast<const f32x4*>(it.fl + 4 * kq);
+  f32x4 dw[CTN][CTK];
+#pragma unroll
+  for (int a = 0; a < CTN; ++a)
+#pragma unroll
+    for (int b = 0; b < CTK; ++b) dw[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const long long n_tiles = (M + 63) / 64;
+  f32x4 rg[NGq], rz[NGq], rx[NAq];
+  auto fetch = [&](long long m0) {
+#pragma unroll
+    for (int j = 0; j < NGq; ++j) {
+      const int i = tid + 256 * j, r = i / (N / 4);
+      rg[j] = f32x4{0.f, 0.f, 0.f, 0.f}; rz[j] = rg[j];
+      if (i < 64 * (N / 4) && m0 + r < M) {
+        rg[j] = *reinterpret_cast<const f32x4*>(g + (m0 + r) * g_ld + 4 * nq);
+        rz[j] = *reinterpret_cast<const f32x4*>(z + (m0 + r) * z_ld + 4 * nq);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NAq; ++j) {
+      const int i = tid + 256 * j, r = i / (K / 4);
+      rx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < 64 * (K / 4) && m0 + r < M) rx[j] = *reinterpret_cast<const f32x4*>(x + (m0 + r) * x_ld + 4 * kq);
+    }
+  };
+  auto stage = [&](long long m0) {
+#pragma unroll
+    for (int j = 0; j < NGq; ++j) {
+      const int i = tid + 256 * j, r = i / (N / 4);
+      if (i < 64 * (N / 4)) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m0 + r < M) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float zh = (rz[j][q] - o_mean[q]) * o_istd[q];
+            const float gy = rg[j][q] * dsilu_(fmaf(rz[j][q], o_sc[q], o_sh[q]));
+            v[q] = o_k[q] * (gy - o_c1[q] - zh * o_c2[q]);
+          }
+        }
+        *reinterpret_cast<f32x4*>(Gs + r * LDG + 4 * nq) = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NAq; ++j) {
+      const int i = tid + 256 * j, r = i / (K / 4);
+      if (i < 64 * (K / 4)) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m0 + r < M) v = tf4_(rx[j], i_sc, i_sh, i_fl);
+        *reinterpret_cast<f32x4*>(As + r * LDA + 4 * kq) = v;
+      }
+    }
+  };
+
+  long long tile = blockIdx.x;
+  if (tile < n_tiles) fetch(tile * 64);
+  for (; tile < n_tiles; tile += gridDim.x) {
+    const long long m0 = tile * 64;
+    __syncthreads();                                  // previous tile's readers are done (and Wt is in place)
+    stage(m0);
+    __syncthreads();
+    if (tile + gridDim.x < n_tiles) fetch((tile + gridDim.x) * 64);
+    // ---- phase 2: g_in[pixel][cin] = sum_cout g_z[pixel][cout] * W[cout][cin]; D = W^T . G^T, wave = 16 pixels
+    {
+      f32x4 acc[CTK];
+#pragma unroll
+      for (int b = 0; b < CTK; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* grow = Gs + (wave * 16 + lm) * LDG + 4 * gq;
+      const float* wrow = Wt + lm * LDW + 4 * gq;
+#pragma unroll
+      for (int kk = 0; kk < N; kk += 16) {
+        const f32x4 gb = *reinterpret_cast<const f32x4*>(grow + kk);
+#pragma unroll
+        for (int b = 0; b < CTK; ++b) {
+          const f32x4 wa = *reinterpret_cast<const f32x4*>(wrow + b * 16 * LDW + kk);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], gb[j], acc[b], 0, 0, 0);
+        }
+      }
+      const long long m = m0 + wave * 16 + lm;
+      if (m < M) {
+#pragma unroll
+        for (int b = 0; b < CTK; ++b) {
+          float* op = gx + m * gx_ld + 16 * b + 4 * gq;
+          f32x4 v = acc[b];
+          if (accumulate) v += *reinterpret_cast<const f32x4*>(op);
+          *reinterpret_cast<f32x4*>(op) = v;
+        }
+      }
+    }
+    // ---- phase 3: dW[cout][cin] += sum_pixel g_z[pixel][cout] * a[pixel][cin]; wave = 16 pixels = 4 k-steps
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int row = wave * 16 + 4 * st + gq;
+      float av[CTN], bv[CTK];
+#pragma unroll
+      for (int a = 0; a < CTN; ++a) av[a] = Gs[row * LDG + 16 * a + lm];
+#pragma unroll
+      for (int b = 0; b < CTK; ++b) bv[b] = As[row * LDA + 16 * b + lm];
+#pragma unroll
+      for (int a = 0; a < CTN; ++a)
+#pragma unroll
+        for (int b = 0; b < CTK; ++b) dw[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], dw[a][b], 0, 0, 0);
+    }
+  }
+  // cross-wave sum of dW (one wave at a time: plain LDS read-modify-write), then one set of atomics
+  for (int wv = 0; wv < 4; ++wv) {
+    __syncthreads();
+    if (wave == wv) {
+#pragma unroll
+      for (int a = 0; a < CTN; ++a)
+#pragma unroll
+        for (int b = 0; b < CTK; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* tp = &Ts[(16 * a + 4 * gq + r) * K + 16 * b + lm];
+            *tp = (wv == 0 ? 0.0f : *tp) + dw[a][b][r];
+          }
+    }
+  }
+  __syncthreads();
+  float* dst = rep ? gw + ((blockIdx.x + 5 * blockIdx.y) % JN_NREP) * JN_WPART_MAX : gw;
+  for (int i = tid; i < N * K; i += 256) atomicAdd(&dst[i], Ts[i]);
+}
+
+template <int CTN, int CTK>
+static void launch_pw_bwd_fused_t(const PwBwdFusedArgs& a, hipStream_t s) {
+  constexpr int N = 16 * CTN, K = 16 * CTK;
+  const size_t smem = ((size_t)64 * (N + 4) + 64 * (K + 4) + (size_t)K * (N + 4) + (size_t)N * K) * sizeof(float);
+  const long long n_tiles = (a.M + 63) / 64;
+  long long bx = 1024 / a.sb.n;                       // ~1024 persistent workgroups over all slots
+  if (bx < 32) bx = 32;
+  if (bx > n_tiles) bx = n_tiles;
+  const int rep = (a.wpart && N * K <= JN_WPART_MAX) ? 1 : 0;
+  hipLaunchKernelGGL((pw_bwd_fused_kernel<CTN, CTK>), dim3((unsigned)bx, a.sb.n), dim3(256), smem, s, a.g, a.g_ld, a.z,
+                     a.z_ld, a.ot, a.save, a.consts, a.x, a.x_ld, a.it, a.w, a.gx, a.gx_ld, a.accumulate,
+                     rep ? a.wpart : a.gw, rep, a.M, a.sb);
+  if (rep) launch_wpart_reduce(a.gw, a.wpart, N * K, s);
+}
+
+bool pw_bwd_fused_supported(int cout, int cin) {
+  if (cout % 16 || cin % 16) return false;
+  const int tn = cout / 16, tk = cin / 16;
+  auto pow2 = [](int v) { return v == 1 || v == 2 || v == 4 || v == 8; };
+  return pow2(tn) && pow2(tk) && tn * tk <= 16;
+}
+
+int launch_pw_bwd_fused(const PwBwdFusedArgs& a, hipStream_t s) {
+  const int tn = a.cout / 16, tk = a.cin / 16;
+#define JN_PF(A, B) if (tn == A && tk == B) { launch_pw_bwd_fused_t<A, B>(a, s); return 0; }
+  JN_PF(1, 1) JN_PF(1, 2) JN_PF(1, 4) JN_PF(1, 8) JN_PF(2, 1) JN_PF(2, 2) JN_PF(2, 4) JN_PF(2, 8)
+  JN_PF(4, 1) JN_PF(4, 2) JN_PF(4, 4) JN_PF(8, 1) JN_PF(8, 2)
+#undef JN_PF
+  return -1;
+}
+
 // ---- 3b. depthwise data gradient ----------------------------------------------------------------
 // g_in[iy][ix][c] (=|+=) sum_{ky,kx} gz[(iy+1-ky)/S][(ix+1-kx)/S][c] * w[ky][kx][c]   (where divisible)
 template <int S>
