@@ -785,6 +785,13 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
         launch_pw_bwd_fused(fa, s);
         continue;
       }
+      if (op.kind == OP_STEM && net.act_dtype == JN_F32 && !no_fused) {
+        StemArgs a{ss.src, ss.positions, ss.pos_stride, ss.sample_stride, ss.chan_stride, ss.row_stride, net.P, N, cw.cout,
+                   cw.w_dev, nullptr, 0, JN_F32, nullptr, 0, nullptr, 0};
+        launch_stem_bwd_weight(a, gptr(op.out), ld(op.out), gw, ctx->wpart, s, sb, (const float*)ptr(op.out), ld(op.out),
+                               tab(op.out), save + 2 * cw.stat_off, consts);
+        continue;
+      }
       launch_bn_bwd_gz(gptr(op.out), ld(op.out), ptr(op.out), net.act_dtype, ld(op.out), tab(op.out), save + 2 * cw.stat_off, consts,
                        cw.cout, M, s, sb);
       if (op.kind == OP_PW) {

@@ -125,8 +125,11 @@ int launch_dw_bwd_data(const float* gz, int g_ld, const float* w, float* gin, in
 int launch_dw_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, int x_ld, ChanTab it, float* gw,
                          float* wpart, int C, int H, int W, int OH, int OW, int N, int stride, hipStream_t s,
                          const SlotBatch& sb = SlotBatch{});
+// z != null: gz is d loss / d activation and the BN + SiLU backward (g_z) is applied while staging
 int launch_stem_bwd_weight(const StemArgs& a, const float* gz, int g_ld, float* gw, float* wpart, hipStream_t s,
-                           const SlotBatch& sb = SlotBatch{});
+                           const SlotBatch& sb = SlotBatch{}, const float* z = nullptr, int z_ld = 0,
+                           ChanTab ot = ChanTab{nullptr, nullptr, nullptr}, const float* save = nullptr,
+                           const float* consts = nullptr);
 int launch_spp_bwd(const void* cat, int dtype, float* gcat, int ld, int h, int H, int W, int N, ChanTab it,
                    hipStream_t s, const SlotBatch& sb = SlotBatch{});
 int launch_upsample_bwd(const float* gdst, int dst_ld, float* gsrc, int src_ld, int C, int H, int W, int N,

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
   float* Gs = sm;                       // [64][LDG]  g_z tile
   float* As = Gs + 64 * LDG;            // [64][LDA]  activated input tile
   float* Wt = As + 64 * LDA;            // [K][LDW]   W^T (cin-major, cout contiguous)
-  float* Ts = Wt + K * LDW;             // [N][K]     cross-wave dW sum
+  float* Ts = sm;                       // [N][K]     cross-wave dW sum; reuses the tile space after the loop
   {
     const long long sl = blockIdx.y;
     g += sl * sb.grad; z += sl * sb.act; x += sl * sb.act; gx += sl * sb.grad;
@@ -484,7 +484,16 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
 template <int CTN, int CTK>
 static void launch_pw_bwd_fused_t(const PwBwdFusedArgs& a, hipStream_t s) {
   constexpr int N = 16 * CTN, K = 16 * CTK;
-  const size_t smem = ((size_t)64 * (N + 4) + 64 * (K + 4) + (size_t)K * (N + 4) + (size_t)N * K) * sizeof(float);
+  size_t smem = ((size_t)64 * (N + 4) + 64 * (K + 4) + (size_t)K * (N + 4)) * sizeof(float);
+  if (smem < (size_t)N * K * sizeof(float)) smem = (size_t)N * K * sizeof(float);
+  if (smem > 64 * 1024) {
+    static bool raised = false;       // per instantiation
+    if (!raised) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_fused_kernel<CTN, CTK>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      raised = true;
+    }
+  }
   const long long n_tiles = (a.M + 63) / 64;
   long long bx = 1024 / a.sb.n;                       // ~1024 persistent workgroups over all slots
   if (bx < 32) bx = 32;
@@ -500,14 +509,14 @@ bool pw_bwd_fused_supported(int cout, int cin) {
   if (cout % 16 || cin % 16) return false;
   const int tn = cout / 16, tk = cin / 16;
   auto pow2 = [](int v) { return v == 1 || v == 2 || v == 4 || v == 8; };
-  return pow2(tn) && pow2(tk) && tn * tk <= 16;
+  return pow2(tn) && pow2(tk) && tn * tk <= 32;
 }
 
 int launch_pw_bwd_fused(const PwBwdFusedArgs& a, hipStream_t s) {
   const int tn = a.cout / 16, tk = a.cin / 16;
 #define JN_PF(A, B) if (tn == A && tk == B) { launch_pw_bwd_fused_t<A, B>(a, s); return 0; }
   JN_PF(1, 1) JN_PF(1, 2) JN_PF(1, 4) JN_PF(1, 8) JN_PF(2, 1) JN_PF(2, 2) JN_PF(2, 4) JN_PF(2, 8)
-  JN_PF(4, 1) JN_PF(4, 2) JN_PF(4, 4) JN_PF(8, 1) JN_PF(8, 2)
+  JN_PF(4, 1) JN_PF(4, 2) JN_PF(4, 4) JN_PF(4, 8) JN_PF(8, 1) JN_PF(8, 2) JN_PF(8, 4)
 #undef JN_PF
   return -1;
 }
@@ -663,10 +672,25 @@ constexpr int SB_TY = 8, SB_TX = 32, SB_IH = 2 * SB_TY + 4, SB_IW = 2 * SB_TX + 
 __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
     const float* __restrict__ src, const long long* __restrict__ pos, int pos_stride, long long sample_stride,
     long long chan_stride, int row_stride, int P, const float* __restrict__ gz, int g_ld, int cout, int ocg,
-    int tiles_x, int tiles_y, int n_tiles, float* __restrict__ gw, long long pos_slot, long long g_slot) {
+    int tiles_x, int tiles_y, int n_tiles, float* __restrict__ gw, long long pos_slot, long long g_slot,
+    const float* __restrict__ z, int z_ld, ChanTab ot, const float* __restrict__ save,
+    const float* __restrict__ consts, SlotBatch sb) {
   __shared__ __attribute__((aligned(16))) float tile[3 * SB_IH * SB_IW];
   if (pos) pos += blockIdx.z * pos_slot;
   gz += blockIdx.z * g_slot;
+  // z != null: `gz` holds d loss / d activation and g_z is formed while staging (no bn_bwd_gz pass over the
+  // largest map of the network)
+  f32x4 o_sc, o_sh, o_mean, o_istd, o_c1, o_c2, o_k;
+  if (z) {
+    const long long sl = blockIdx.z;
+    z += sl * sb.act; save += sl * sb.save; consts += sl * sb.consts; ot.sc += sl * sb.tab; ot.sh += sl * sb.tab;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = blockIdx.y * 16 + 4 * (threadIdx.x & 3) + q;
+      o_sc[q] = ot.sc[c]; o_sh[q] = ot.sh[c]; o_mean[q] = save[2 * c]; o_istd[q] = save[2 * c + 1];
+      o_c1[q] = consts[3 * c]; o_c2[q] = consts[3 * c + 1]; o_k[q] = consts[3 * c + 2];
+    }
+  }
   __shared__ float Gz[SB_TY * SB_TX * 16];
   __shared__ float Ts[16 * 112];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -701,8 +725,19 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
     for (int i = tid; i < SB_TY * SB_TX * 4; i += 256) {
       const int p = i >> 2, q = i & 3, ty = p / SB_TX, tx = p % SB_TX;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (oy0 + ty < OH && ox0 + tx < OH)
-        v = *reinterpret_cast<const f32x4*>(gz + (((long long)n * OH + oy0 + ty) * OH + ox0 + tx) * g_ld + og * 16 + 4 * q);
+      if (oy0 + ty < OH && ox0 + tx < OH) {
+        const long long pix = ((long long)n * OH + oy0 + ty) * OH + ox0 + tx;
+        v = *reinterpret_cast<const f32x4*>(gz + pix * g_ld + og * 16 + 4 * q);
+        if (z) {
+          const f32x4 zv = *reinterpret_cast<const f32x4*>(z + pix * z_ld + og * 16 + 4 * q);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float zh = (zv[k] - o_mean[k]) * o_istd[k];
+            const float gy = v[k] * dsilu_(fmaf(zv[k], o_sc[k], o_sh[k]));
+            v[k] = o_k[k] * (gy - o_c1[k] - zh * o_c2[k]);
+          }
+        }
+      }
       *reinterpret_cast<f32x4*>(&Gz[p * 16 + 4 * q]) = v;
     }
     __syncthreads();
@@ -729,7 +764,8 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
 }
 
 int launch_stem_bwd_weight(const StemArgs& a, const float* gz, int g_ld, float* gw, float* wpart, hipStream_t s,
-                           const SlotBatch& sb) {
+                           const SlotBatch& sb, const float* z, int z_ld, ChanTab ot, const float* save,
+                           const float* consts) {
   const int OH = a.P / 2, ocg = a.cout / 16;
   const int tiles_x = (OH + SB_TX - 1) / SB_TX, tiles_y = (OH + SB_TY - 1) / SB_TY;
   const int n_tiles = tiles_x * tiles_y * a.N;
@@ -737,7 +773,7 @@ int launch_stem_bwd_weight(const StemArgs& a, const float* gz, int g_ld, float* 
   dim3 grid(n_tiles < cap ? n_tiles : cap, ocg, sb.n);
   hipLaunchKernelGGL(stem_bwd_weight_kernel, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.pos_stride,
                      a.sample_stride, a.chan_stride, a.row_stride, a.P, gz, g_ld, a.cout, ocg, tiles_x, tiles_y, n_tiles,
-                     wpart, sb.pos, sb.grad);
+                     wpart, sb.pos, sb.grad, z, z_ld, ot, save, consts, sb);
   launch_wpart_reduce(gw, wpart, 108 * a.cout, s);
   return 0;
 }
