@@ -785,6 +785,19 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
         launch_pw_bwd_fused(fa, s);
         continue;
       }
+      static const bool no_fused_dw = std::getenv("JN_NO_FUSED_DW") != nullptr;
+      if (op.kind == OP_DW && net.act_dtype == JN_F32 && !no_fused && !no_fused_dw &&
+          dw_bwd_fused_supported(cw.cout, op.in.H, op.in.W, op.out.H, op.out.W, op.stride)) {
+        DwBwdFusedArgs fa{};
+        fa.g = gptr(op.out); fa.g_ld = ld(op.out); fa.z = (const float*)ptr(op.out); fa.z_ld = ld(op.out); fa.ot = tab(op.out);
+        fa.save = save + 2 * cw.stat_off; fa.consts = consts;
+        fa.x = (const float*)ptr(op.in); fa.x_ld = ld(op.in); fa.it = tab(op.in); fa.w = cw.w_dev;
+        fa.gin = gptr(op.in); fa.gin_ld = ld(op.in); fa.accumulate = op.acc_in ? 1 : 0; fa.gw = gw; fa.wpart = ctx->wpart;
+        fa.C = cw.cout; fa.H = op.in.H; fa.W = op.in.W; fa.OH = op.out.H; fa.OW = op.out.W; fa.N = N; fa.stride = op.stride;
+        fa.sb = sb;
+        launch_dw_bwd_fused(fa, s);
+        continue;
+      }
       if (op.kind == OP_STEM && net.act_dtype == JN_F32 && !no_fused) {
         StemArgs a{ss.src, ss.positions, ss.pos_stride, ss.sample_stride, ss.chan_stride, ss.row_stride, net.P, N, cw.cout,
                    cw.w_dev, nullptr, 0, JN_F32, nullptr, 0, nullptr, 0};

@@ -118,6 +118,15 @@ struct PwBwdFusedArgs {
   long long M; int cout, cin;
   SlotBatch sb;
 };
+struct DwBwdFusedArgs {                  // the depthwise counterpart (3x3, pad 1, stride 1 / 2)
+  const float* g; int g_ld; const float* z; int z_ld; ChanTab ot; const float* save; const float* consts;
+  const float* x; int x_ld; ChanTab it; const float* w;      // w: [9][C]
+  float* gin; int gin_ld; int accumulate; float* gw; float* wpart;
+  int C, H, W, OH, OW, N, stride;
+  SlotBatch sb;
+};
+bool dw_bwd_fused_supported(int C, int H, int W, int OH, int OW, int stride);
+int launch_dw_bwd_fused(const DwBwdFusedArgs& a, hipStream_t s);
 bool pw_bwd_fused_supported(int cout, int cin);
 int launch_pw_bwd_fused(const PwBwdFusedArgs& a, hipStream_t s);
 int launch_dw_bwd_data(const float* gz, int g_ld, const float* w, float* gin, int gin_ld, int C, int H, int W, int OH,

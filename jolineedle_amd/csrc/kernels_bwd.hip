@@ -666,6 +666,182 @@ int launch_dw_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, 
   return 0;
 }
 
+// ---- 2+3b+4b fused for depthwise layers ------------------------------------------------------------
+// One LDS-tiled pass: g_z (from g_a, z) over the output tile + halo and the activated input tile + halo are
+// staged once; every thread then forms the data gradient of its input pixel(s) and its share of the 9-tap weight
+// gradient from LDS.  HBM traffic ~ (8 B/output + 4 B/input) x halo factor + 4 B/input written, instead of
+// bn_bwd_gz (12) + dw_bwd_data (4 + 4) + dw_bwd_weight (4 + 4).  Tile = 8 x 16 output pixels, CB channels;
+// stride 2: thread (a, b) owns output pixel (a, b) and the 2 x 2 input block under it.
+constexpr int DF_TH = 8, DF_TW = 16;
+
+template <int S, int CB>
+__global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
+    const float* __restrict__ g, int g_ld, const float* __restrict__ z, int z_ld, ChanTab ot,
+    const float* __restrict__ save, const float* __restrict__ consts, const float* __restrict__ x, int x_ld,
+    ChanTab it, const float* __restrict__ w, float* __restrict__ gin, int gin_ld, int accumulate,
+    float* __restrict__ gw, int rep, int C, int H, int W, int OH, int OW, int tiles_x, int tiles_y, int n_tiles,
+    SlotBatch sb) {
+  constexpr int Q = CB / 4, PS = S == 1 ? CB : CB + 4;     // stride-1 taps: a wave reads 1 KB contiguous, no padding
+  constexpr int GH = S == 1 ? DF_TH + 2 : DF_TH + 1, GW = S == 1 ? DF_TW + 2 : DF_TW + 1;
+  constexpr int AH = S == 1 ? DF_TH + 2 : 2 * DF_TH + 1, AW = S == 1 ? DF_TW + 2 : 2 * DF_TW + 1;
+  constexpr int GROUPS = 256 / (DF_TW * Q), RPG = DF_TH / GROUPS;
+  static_assert(RPG >= 1 && RPG * GROUPS == DF_TH, "tile / thread mapping");
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Gs = sm;                        // [GH*GW][PS] g_z
+  float* As = Gs + GH * GW * PS;         // [AH*AW][PS] activated input
+  float* red = As + AH * AW * PS;        // [9][CB]
+  {
+    const long long sl = blockIdx.y;
+    g += sl * sb.grad; z += sl * sb.act; x += sl * sb.act; gin += sl * sb.grad;
+    save += sl * sb.save; consts += sl * sb.consts;
+    ot.sc += sl * sb.tab; ot.sh += sl * sb.tab;
+    it.sc += sl * sb.tab; it.sh += sl * sb.tab; it.fl += sl * sb.tab;
+  }
+  const int tid = threadIdx.x;
+  const int ncb = C / CB, cb = blockIdx.x % ncb;
+  const int q = tid % Q, c = cb * CB + 4 * q;
+  for (int i = tid; i < 9 * CB; i += 256) red[i] = 0.0f;
+  f32x4 wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(w + t * C + c);
+  f32x4 o_sc, o_sh, o_mean, o_istd, o_c1, o_c2, o_k;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    o_sc[k] = ot.sc[c + k]; o_sh[k] = ot.sh[c + k]; o_mean[k] = save[2 * (c + k)]; o_istd[k] = save[2 * (c + k) + 1];
+    o_c1[k] = consts[3 * (c + k)]; o_c2[k] = consts[3 * (c + k) + 1]; o_k[k] = consts[3 * (c + k) + 2];
+  }
+  const f32x4 i_sc = *reinterpret_cast<const f32x4*>(it.sc + c), i_sh = *reinterpret_cast<const f32x4*>(it.sh + c),
+              i_fl = *reinterpret_cast<const f32x4*>(it.fl + c);
+  f32x4 dw[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) dw[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int xx = (tid / Q) % DF_TW, grp = tid / (Q * DF_TW), j0 = grp * RPG;
+  const int wg = blockIdx.x / ncb, n_wg = gridDim.x / ncb;
+  for (int tile = wg; tile < n_tiles; tile += n_wg) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int oy0 = ty * DF_TH, ox0 = tx * DF_TW;
+    const int gy0 = S == 1 ? oy0 - 1 : oy0, gx0 = S == 1 ? ox0 - 1 : ox0;         // first output row / col in Gs
+    const int ay0 = oy0 * S - 1, ax0 = ox0 * S - 1;                              // first input row / col in As
+    __syncthreads();
+    for (int i = tid; i < GH * GW * Q; i += 256) {
+      const int p = i / Q, r = p / GW, cx = p - r * GW;
+      const int oy = gy0 + r, ox = gx0 + cx;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (oy >= 0 && oy < OH && ox >= 0 && ox < OW) {
+        const long long pix = ((long long)n * OH + oy) * OW + ox;
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + pix * g_ld + c);
+        const f32x4 zv = *reinterpret_cast<const f32x4*>(z + pix * z_ld + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float zh = (zv[k] - o_mean[k]) * o_istd[k];
+          const float gy = gv[k] * dsilu_(fmaf(zv[k], o_sc[k], o_sh[k]));
+          v[k] = o_k[k] * (gy - o_c1[k] - zh * o_c2[k]);
+        }
+      }
+      *reinterpret_cast<f32x4*>(Gs + p * PS + 4 * q) = v;
+    }
+    for (int i = tid; i < AH * AW * Q; i += 256) {
+      const int p = i / Q, r = p / AW, cx = p - r * AW;
+      const int iy = ay0 + r, ix = ax0 + cx;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+        v = tf4_(*reinterpret_cast<const f32x4*>(x + (((long long)n * H + iy) * W + ix) * x_ld + c), i_sc, i_sh, i_fl);
+      *reinterpret_cast<f32x4*>(As + p * PS + 4 * q) = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int j = 0; j < RPG; ++j) {
+      const int y = j0 + j;                       // tile-relative output row of this thread
+      if (S == 1) {
+        // input pixel (y, xx) == output pixel (y, xx); Gs / As carry a 1-pixel halo
+        const f32x4 gc = *reinterpret_cast<const f32x4*>(Gs + ((y + 1) * GW + xx + 1) * PS + 4 * q);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            acc += *reinterpret_cast<const f32x4*>(Gs + ((y + 2 - ky) * GW + xx + 2 - kx) * PS + 4 * q) * wv[ky * 3 + kx];
+            dw[ky * 3 + kx] += gc * *reinterpret_cast<const f32x4*>(As + ((y + ky) * AW + xx + kx) * PS + 4 * q);
+          }
+        const int iy = oy0 + y, ix = ox0 + xx;
+        if (iy < H && ix < W) {
+          float* op = gin + (((long long)n * H + iy) * W + ix) * gin_ld + c;
+          if (accumulate) acc += *reinterpret_cast<const f32x4*>(op);
+          *reinterpret_cast<f32x4*>(op) = acc;
+        }
+      } else {
+        const f32x4 g00 = *reinterpret_cast<const f32x4*>(Gs + (y * GW + xx) * PS + 4 * q);
+        const f32x4 g01 = *reinterpret_cast<const f32x4*>(Gs + (y * GW + xx + 1) * PS + 4 * q);
+        const f32x4 g10 = *reinterpret_cast<const f32x4*>(Gs + ((y + 1) * GW + xx) * PS + 4 * q);
+        const f32x4 g11 = *reinterpret_cast<const f32x4*>(Gs + ((y + 1) * GW + xx + 1) * PS + 4 * q);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+            dw[ky * 3 + kx] += g00 * *reinterpret_cast<const f32x4*>(As + ((2 * y + ky) * AW + 2 * xx + kx) * PS + 4 * q);
+        // the 2 x 2 input block (2y + dy, 2xx + dx): taps with (dy + 1 - ky), (dx + 1 - kx) even
+        f32x4 r[4];
+        r[0] = g00 * wv[4];                                              // (even, even): ky = kx = 1
+        r[1] = g01 * wv[3] + g00 * wv[5];                                // (even, odd): ky = 1, kx = 0 | 2
+        r[2] = g10 * wv[1] + g00 * wv[7];                                // (odd, even): kx = 1, ky = 0 | 2
+        r[3] = g11 * wv[0] + g10 * wv[2] + g01 * wv[6] + g00 * wv[8];    // (odd, odd)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const int iy = 2 * (oy0 + y) + (d >> 1), ix = 2 * (ox0 + xx) + (d & 1);
+          if (iy < H && ix < W) {
+            float* op = gin + (((long long)n * H + iy) * W + ix) * gin_ld + c;
+            f32x4 v = r[d];
+            if (accumulate) v += *reinterpret_cast<const f32x4*>(op);
+            *reinterpret_cast<f32x4*>(op) = v;
+          }
+        }
+      }
+    }
+  }
+  // lanes l, l + Q, ... hold the same channel quad: butterfly, then Q lanes per wave add into LDS
+  const int lane = tid & 63;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v = dw[t][k];
+      for (int off = Q; off < 64; off <<= 1) v += __shfl_xor(v, off);
+      if (lane < Q) atomicAdd(&red[t * CB + 4 * q + k], v);
+    }
+  __syncthreads();
+  float* dst = (rep ? gw + ((wg + 5 * blockIdx.y) % JN_NREP) * JN_WPART_MAX : gw);
+  for (int i = tid; i < 9 * CB; i += 256) atomicAdd(&dst[(i / CB) * C + cb * CB + (i % CB)], red[i]);
+}
+
+template <int S, int CB>
+static void launch_dw_bwd_fused_t(const DwBwdFusedArgs& a, hipStream_t s) {
+  constexpr int PS = S == 1 ? CB : CB + 4;
+  constexpr int GH = S == 1 ? DF_TH + 2 : DF_TH + 1, GW = S == 1 ? DF_TW + 2 : DF_TW + 1;
+  constexpr int AH = S == 1 ? DF_TH + 2 : 2 * DF_TH + 1, AW = S == 1 ? DF_TW + 2 : 2 * DF_TW + 1;
+  const size_t smem = ((size_t)(GH * GW + AH * AW) * PS + 9 * CB) * sizeof(float);
+  const int tiles_x = (a.OW + DF_TW - 1) / DF_TW, tiles_y = (a.OH + DF_TH - 1) / DF_TH;
+  const int n_tiles = tiles_x * tiles_y * a.N, ncb = a.C / CB;
+  int n_wg = 1536 / (ncb * a.sb.n);                 // persistent: one set of weight-gradient atomics per workgroup
+  if (n_wg < 8) n_wg = 8;
+  if (n_wg > n_tiles) n_wg = n_tiles;
+  const int rep = (a.wpart && 9 * a.C <= JN_WPART_MAX) ? 1 : 0;
+  hipLaunchKernelGGL((dw_bwd_fused_kernel<S, CB>), dim3((unsigned)(n_wg * ncb), a.sb.n), dim3(256), smem, s, a.g, a.g_ld, a.z,
+                     a.z_ld, a.ot, a.save, a.consts, a.x, a.x_ld, a.it, a.w, a.gin, a.gin_ld, a.accumulate,
+                     rep ? a.wpart : a.gw, rep, a.C, a.H, a.W, a.OH, a.OW, tiles_x, tiles_y, n_tiles, a.sb);
+  if (rep) launch_wpart_reduce(a.gw, a.wpart, 9 * a.C, s);
+}
+
+bool dw_bwd_fused_supported(int C, int H, int W, int OH, int OW, int stride) {
+  if (C % 16) return false;
+  return stride == 1 ? (OH == H && OW == W) : (stride == 2 && OH == (H + 1) / 2 && OW == (W + 1) / 2);
+}
+
+int launch_dw_bwd_fused(const DwBwdFusedArgs& a, hipStream_t s) {
+  if (a.stride == 1) { if (a.C % 32 == 0) launch_dw_bwd_fused_t<1, 32>(a, s); else launch_dw_bwd_fused_t<1, 16>(a, s); }
+  else launch_dw_bwd_fused_t<2, 16>(a, s);
+  return 0;
+}
+
 // ---- 4c. stem weight gradient: dW[(c,dy,dx)][oc] += sum_pixels gz[p][oc] * img[c][2oy-2+dy][2ox-2+dx]
 constexpr int SB_TY = 8, SB_TX = 32, SB_IH = 2 * SB_TY + 4, SB_IW = 2 * SB_TX + 4;
 
