@@ -49,17 +49,24 @@ __device__ __forceinline__ f32x4 tf4(f32x4 z, f32x4 sc, f32x4 sh, f32x4 fl) {
   return r;
 }
 
-// Sum over the 16 lanes of a DPP row (lanes that share lane>>4).
+// Sum over the 16 lanes of a DPP row (lanes that share lane>>4): four v_add_f32_dpp (quad_perm [1,0,3,2],
+// quad_perm [2,3,0,1], row_half_mirror, row_mirror).  __shfl_xor would go through ds_bpermute (LDS crossbar) and
+// made this reduction 8 % of a train-mode pass.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float row16_sum(float v) {
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 8);
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
   return v;
 }
 
 // Epilogue helper of the MFMA kernels: s1/s2[t] hold sum / sumsq over this lane's pixels of channels
-// (16 t + 4g .. +3).  Adds the wave's per-channel totals into LDS scratch `red` [nch][2].
+// (16 t + 4g .. +3).  Stores the wave's per-channel totals into ITS OWN LDS slots `red` [nch][2] (plain stores:
+// LDS float atomics are slow); the caller sums the slots of the waves that share channels.
 template <int NT>
 __device__ __forceinline__ void wave_stats_to_lds(const f32x4 (&s1)[NT], const f32x4 (&s2)[NT], float* red,
                                                   int lane, int nch) {
@@ -72,8 +79,8 @@ __device__ __forceinline__ void wave_stats_to_lds(const f32x4 (&s1)[NT], const f
       const float b = row16_sum(s2[t][r]);
       const int ch = 16 * t + 4 * g + r;
       if (lm == 0 && ch < nch) {
-        atomicAdd(&red[2 * ch], a);
-        atomicAdd(&red[2 * ch + 1], b);
+        red[2 * ch] = a;
+        red[2 * ch + 1] = b;
       }
     }
   }
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(
     const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
   __shared__ __attribute__((aligned(16))) float tile[3 * ST_IH * ST_IW];
-  __shared__ float red[32];
+  __shared__ float red[4 * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, g = lane >> 4;
   const int n = blockIdx.z / ocg, og = blockIdx.z % ocg;
@@ -103,7 +110,6 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(
   const int oy0 = blockIdx.y * ST_TY, ox0 = blockIdx.x * ST_TX;
   const float* base = src + (long long)n * sample_stride;
   if (pos) base += pos[(long long)pos_stride * n] * (long long)P * row_stride + pos[(long long)pos_stride * n + 1] * (long long)P;
-  if (tid < 32) red[tid] = 0.0f;
   for (int i = tid; i < 3 * ST_IH * ST_IW; i += 256) {
     const int c = i / (ST_IH * ST_IW), r = (i / ST_IW) % ST_IH, q = i % ST_IW;
     const int iy = 2 * oy0 - 2 + r, ix = 2 * ox0 - 2 + q;
@@ -143,10 +149,11 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(
     }
   }
   if (stats) {
-    wave_stats_to_lds<1>(s1, s2, red, lane, 16);
+    wave_stats_to_lds<1>(s1, s2, red + 32 * wave, lane, 16);
     __syncthreads();
     const int rep = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z) % JN_NREP;
-    if (tid < 32) atomicAdd(&stats[rep * rep_stride + 2 * (og * 16) + tid], (double)red[tid]);
+    if (tid < 32)
+      atomicAdd(&stats[rep * rep_stride + 2 * (og * 16) + tid], (double)(red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid]));
   }
 }
 
@@ -275,7 +282,6 @@ __global__ __launch_bounds__(256) void dw3x3_lds_kernel(
   const int c = cb * CB + 4 * q;
   const int oy0 = ty * DW_TH, ox0 = tx * DW_TW;
   const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
-  if (stats && tid < 2 * CB) red[tid] = 0.0f;
   {
     const f32x4 sc = *reinterpret_cast<const f32x4*>(it.sc + c), sh = *reinterpret_cast<const f32x4*>(it.sh + c),
                 fl = *reinterpret_cast<const f32x4*>(it.fl + c);
@@ -324,19 +330,28 @@ __global__ __launch_bounds__(256) void dw3x3_lds_kernel(
     }
   }
   if (stats) {
-    const int lane = tid & 63;                        // lanes l, l + Q, ... share the channel quad: butterfly first
+    // lanes l, l + Q, ... of a 16-lane DPP row share the channel quad: rotate-and-add inside the row (v_add_dpp
+    // row_ror), then each of the 16 rows of the workgroup stores its totals in its own LDS slot (no LDS atomics)
+    const int lane = tid & 63;
+    float* slot = red + ((tid >> 6) * 4 + (lane >> 4)) * 2 * CB;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float a = s1[k], b = s2[k];
-      for (int off = Q; off < 64; off <<= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
-      if (lane < Q) {
-        atomicAdd(&red[2 * (4 * q + k)], a);
-        atomicAdd(&red[2 * (4 * q + k) + 1], b);
+      if (Q <= 4) { a += dpp_mov<0x124>(a); b += dpp_mov<0x124>(b); }     // row_ror:4
+      a += dpp_mov<0x128>(a); b += dpp_mov<0x128>(b);                     // row_ror:8
+      if ((lane & 15) < Q) {
+        slot[2 * (4 * q + k)] = a;
+        slot[2 * (4 * q + k) + 1] = b;
       }
     }
     __syncthreads();
     double* st = stats + ((blockIdx.x + 3 * blockIdx.y) % JN_NREP) * rep_stride + 2 * cb * CB;
-    if (tid < 2 * CB) atomicAdd(&st[tid], (double)red[tid]);
+    if (tid < 2 * CB) {
+      float v = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v += red[r * 2 * CB + tid];
+      atomicAdd(&st[tid], (double)v);
+    }
   }
 }
 
@@ -344,7 +359,7 @@ template <int S, int CB, typename AT>
 static void launch_dw_lds(const ConvArgs& a, hipStream_t s) {
   constexpr int IH = S * (DW_TH - 1) + 3, IW = S * (DW_TW - 1) + 3;
   const int tiles_x = (a.OW + DW_TW - 1) / DW_TW, tiles_y = (a.OH + DW_TH - 1) / DW_TH;
-  const size_t smem = ((size_t)IH * IW * (S == 1 ? CB : CB + 4) + 2 * CB) * sizeof(float);
+  const size_t smem = ((size_t)IH * IW * (S == 1 ? CB : CB + 4) + 16 * 2 * CB) * sizeof(float);
   dim3 grid((unsigned)(tiles_x * tiles_y * (a.cin / CB)), (unsigned)a.N);
   hipLaunchKernelGGL((dw3x3_lds_kernel<S, CB, AT>), grid, dim3(256), smem, s, (const AT*)a.in, a.in_ld, a.itab, a.w,
                      (AT*)a.out, a.out_ld, a.cin, a.H, a.W, a.OH, a.OW, tiles_x, tiles_y, a.stats, a.stats_rep_stride,
@@ -410,14 +425,13 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   LT* Xs = reinterpret_cast<LT*>(smem_raw);     // [BM][PW_LD]
   LT* Ws = Xs + BM * PW_LD;                      // [16*CT][PW_LD]
-  float* red = reinterpret_cast<float*>(Ws + 16 * CT * PW_LD);   // [16*CT][2]
+  float* red = reinterpret_cast<float*>(Ws + 16 * CT * PW_LD);   // [WM][16*CT][2]: one slot set per pixel-wave
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM;
   const int lm = lane & 15, g = lane >> 4;
   const long long m0 = (long long)blockIdx.x * BM;
   const int n0 = blockIdx.y * (16 * CT);
-  if (stats && tid < 32 * CT) red[tid] = 0.0f;
 
   f32x4 acc[2][CTW];
 #pragma unroll
@@ -534,10 +548,18 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
     }
   }
   if (stats) {
-    wave_stats_to_lds<CTW>(s1, s2, red + 2 * (wn * CTW * 16), lane, Nc - n0 - wn * CTW * 16);
+#ifndef JN_DBG_NO_LDS_STATS
+    wave_stats_to_lds<CTW>(s1, s2, red + wm * 32 * CT + 2 * (wn * CTW * 16), lane, Nc - n0 - wn * CTW * 16);
+#endif
     __syncthreads();
-    if (tid < 32 * CT && n0 + (tid >> 1) < Nc)
-      atomicAdd(&stats[(blockIdx.x % JN_NREP) * rep_stride + 2 * n0 + tid], (double)red[tid]);
+#ifndef JN_DBG_NO_GLOBAL_STATS
+    if (tid < 32 * CT && n0 + (tid >> 1) < Nc) {
+      float v = 0.0f;
+#pragma unroll
+      for (int q = 0; q < WM; ++q) v += red[q * 32 * CT + tid];
+      atomicAdd(&stats[(blockIdx.x % JN_NREP) * rep_stride + 2 * n0 + tid], (double)v);
+    }
+#endif
   }
 }
 
@@ -546,7 +568,7 @@ static void launch_pw_cfg(const ConvArgs& a, long long M, hipStream_t s) {
   constexpr int KC = BF ? 64 : ((CT > 4) ? 32 : 64);
   constexpr int BM = 32 * WM;
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.cout + 16 * CT - 1) / (16 * CT)), a.n_slots > 1 ? a.n_slots : 1);
-  const size_t smem = (size_t)(BM + 16 * CT) * (KC + (BF ? 8 : 4)) * (BF ? 2 : 4) + 32 * CT * sizeof(float);
+  const size_t smem = (size_t)(BM + 16 * CT) * (KC + (BF ? 8 : 4)) * (BF ? 2 : 4) + WM * 32 * CT * sizeof(float);
   hipLaunchKernelGGL((pw_mfma_kernel<CT, KC, WT, WM, IT, OT, BF>), grid, dim3(256), smem, s, (const IT*)a.in, a.in_ld,
                      a.itab, a.w, a.bias, (OT*)a.out, a.out_ld, M, a.cin, a.cout, a.act, a.accumulate, a.stats,
                      a.stats_rep_stride, a.skip_flag, a.skip_when, a.in_slot_stride, a.out_slot_stride, a.tab_slot_stride);
