@@ -171,7 +171,36 @@ int upload_t(jn_ctx* ctx, const TensorMap& tm, const std::string& name, int out_
 constexpr float kBnEps = 1e-3f;
 constexpr float kBnMomentum = 0.03f;
 
+// The two halves of a merged pair (ConvW::prefix2): every tensor kind is stored first-half then second-half, back to
+// back, so the kernels see one conv of cout channels.
+int pack_conv_pair(jn_ctx* ctx, const TensorMap& tm, ConvW& cw) {
+  const int h = cw.cout_first, h2 = cw.cout - h;
+  int rc;
+  auto pair_raw = [&](const std::string& leaf, size_t n1, size_t n2, float** out) -> int {
+    float *a = nullptr, *b = nullptr;
+    if ((rc = upload_raw(ctx, tm, cw.prefix + leaf, n1, &a))) return rc;
+    if ((rc = upload_raw(ctx, tm, cw.prefix2 + leaf, n2, &b))) return rc;
+    JN_CHECK(b == a + n1, JN_ESTATE, "merged conv pair '%s': halves of %s are not contiguous in the arena", cw.prefix.c_str(), leaf.c_str());
+    *out = a;
+    return JN_OK;
+  };
+  auto pair_buf = [&](const std::string& leaf, float** out) -> int {
+    const float* a = tm.f32(cw.prefix + leaf, h);
+    const float* b = tm.f32(cw.prefix2 + leaf, h2);
+    if (!a || !b) return JN_ENOTFOUND;
+    std::vector<float> both(a, a + h);
+    both.insert(both.end(), b, b + h2);
+    return dev_upload(ctx, out, both);
+  };
+  if ((rc = pair_raw(".bn.weight", h, h2, &cw.gamma_dev))) return rc;
+  if ((rc = pair_raw(".bn.bias", h, h2, &cw.beta_dev))) return rc;
+  if ((rc = pair_buf(".bn.running_mean", &cw.rmean_dev))) return rc;
+  if ((rc = pair_buf(".bn.running_var", &cw.rvar_dev))) return rc;
+  return pair_raw(".conv.weight", (size_t)h * cw.cin, (size_t)h2 * cw.cin, &cw.w_dev);
+}
+
 int pack_conv(jn_ctx* ctx, const TensorMap& tm, ConvW& cw, OpKind kind) {
+  if (!cw.prefix2.empty()) return pack_conv_pair(ctx, tm, cw);
   const int cig = cw.cin / cw.groups;
   const std::string wname = cw.prefix + (cw.has_bn ? ".conv.weight" : ".weight");
   const float* w = tm.f32(wname, (size_t)cw.cout * cig * cw.k * cw.k);
@@ -775,14 +804,23 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
                            grad_of(ctx, cw.gamma_dev), grad_of(ctx, cw.beta_dev), cw.cout, s, sb);
       float* gw = grad_of(ctx, cw.w_dev);
       static const bool no_fused = std::getenv("JN_NO_FUSED_BWD") != nullptr;
-      if (op.kind == OP_PW && net.act_dtype == JN_F32 && !no_fused && pw_bwd_fused_supported(cw.cout, cw.cin)) {
-        PwBwdFusedArgs fa{};
-        fa.g = gptr(op.out); fa.g_ld = ld(op.out); fa.z = (const float*)ptr(op.out); fa.z_ld = ld(op.out); fa.ot = tab(op.out);
-        fa.save = save + 2 * cw.stat_off; fa.consts = consts;
-        fa.x = (const float*)ptr(op.in); fa.x_ld = ld(op.in); fa.it = tab(op.in); fa.w = cw.w_dev;
-        fa.gx = gptr(op.in); fa.gx_ld = ld(op.in); fa.accumulate = op.acc_in ? 1 : 0;
-        fa.gw = gw; fa.wpart = ctx->wpart; fa.M = M; fa.cout = cw.cout; fa.cin = cw.cin; fa.sb = sb;
-        launch_pw_bwd_fused(fa, s);
+      // a merged pair too wide for the fused kernel is differentiated as its two halves (independent output rows)
+      const bool whole = pw_bwd_fused_supported(cw.cout, cw.cin);
+      const bool halves = !whole && !cw.prefix2.empty() && 2 * cw.cout_first == cw.cout && pw_bwd_fused_supported(cw.cout_first, cw.cin);
+      if (op.kind == OP_PW && net.act_dtype == JN_F32 && !no_fused && (whole || halves)) {
+        const int parts = whole ? 1 : 2, pc = cw.cout / parts;
+        for (int part = 0; part < parts; ++part) {
+          const int c0 = part * pc;
+          ChanTab ot = tab(op.out);
+          ot.sc += c0; ot.sh += c0; ot.fl += c0;
+          PwBwdFusedArgs fa{};
+          fa.g = gptr(op.out) + c0; fa.g_ld = ld(op.out); fa.z = (const float*)ptr(op.out) + c0; fa.z_ld = ld(op.out); fa.ot = ot;
+          fa.save = save + 2 * (cw.stat_off + c0); fa.consts = consts + 3 * c0;
+          fa.x = (const float*)ptr(op.in); fa.x_ld = ld(op.in); fa.it = tab(op.in); fa.w = cw.w_dev + (size_t)c0 * cw.cin;
+          fa.gx = gptr(op.in); fa.gx_ld = ld(op.in); fa.accumulate = (op.acc_in || part > 0) ? 1 : 0;
+          fa.gw = gw + (size_t)c0 * cw.cin; fa.wpart = ctx->wpart; fa.M = M; fa.cout = pc; fa.cin = cw.cin; fa.sb = sb;
+          launch_pw_bwd_fused(fa, s);
+        }
         continue;
       }
       static const bool no_fused_dw = std::getenv("JN_NO_FUSED_DW") != nullptr;
@@ -1004,11 +1042,18 @@ int jn_read_tensor(jn_ctx* ctx, const char* name, float* host_out, size_t numel)
   for (int ni = 0; ni < 2; ++ni) {
     if (!ctx->has_net[ni]) continue;
     for (const ConvW& cw : ctx->nets[ni].convs) {
-      if (!cw.has_bn || nm.compare(0, cw.prefix.size(), cw.prefix) != 0) continue;
-      const std::string leaf = nm.substr(cw.prefix.size());
+      if (!cw.has_bn) continue;
+      // a merged pair answers for both of its modules: [0, cout_first) and [cout_first, cout)
+      const bool first = nm.compare(0, cw.prefix.size(), cw.prefix) == 0 && nm.size() > cw.prefix.size() && nm[cw.prefix.size()] == '.';
+      const bool second = !cw.prefix2.empty() && nm.compare(0, cw.prefix2.size(), cw.prefix2) == 0 &&
+                          nm.size() > cw.prefix2.size() && nm[cw.prefix2.size()] == '.';
+      if (!first && !second) continue;
+      const std::string leaf = nm.substr(first ? cw.prefix.size() : cw.prefix2.size());
       const float* src = leaf == ".bn.running_mean" ? cw.rmean_dev : leaf == ".bn.running_var" ? cw.rvar_dev : nullptr;
       if (!src) continue;
-      JN_CHECK(numel == (size_t)cw.cout, JN_EINVAL, "'%s' has %d elements, not %zu", name, cw.cout, numel);
+      int n_here = cw.cout;
+      if (!cw.prefix2.empty()) { n_here = first ? cw.cout_first : cw.cout - cw.cout_first; if (second) src += cw.cout_first; }
+      JN_CHECK(numel == (size_t)n_here, JN_EINVAL, "'%s' has %d elements, not %zu", name, n_here, numel);
       JN_HIP(hipDeviceSynchronize());
       JN_HIP(hipMemcpy(host_out, src, numel * sizeof(float), hipMemcpyDeviceToHost));
       return JN_OK;

@@ -74,6 +74,10 @@ struct Op {
 // Packed (device) weights of one conv layer.
 struct ConvW {
   std::string prefix;       // "<...>.conv" / "<...>.bn" live under this module prefix
+  // Two 1x1 BaseConvs that read the same input (CSPLayer.conv2 and .conv1) run as ONE conv of cout channels:
+  // rows [0, cout_first) belong to `prefix`, the rest to `prefix2`; their tensors are stored back to back.
+  std::string prefix2;
+  int cout_first = 0;
   int cin = 0, cout = 0, k = 1, groups = 1;
   bool has_bn = true;       // BaseConv; false = plain Conv2d with optional bias
   bool has_bias = false;    // plain Conv2d bias

@@ -59,6 +59,22 @@ struct Builder {
     return (int)net.convs.size() - 1;
   }
 
+  // conv `a` (first rows) and conv `b` as one 1x1 conv of 2h output channels over the same input
+  int add_conv_pair(const std::string& a, const std::string& b, int cin, int h) {
+    ConvW w; w.prefix = mod_prefix + a; w.prefix2 = mod_prefix + b; w.cin = cin; w.cout = 2 * h; w.cout_first = h;
+    w.k = 1; w.groups = 1; w.has_bn = true; w.has_bias = false;
+    net.convs.push_back(w);
+    for (const std::string& pre : {w.prefix, w.prefix2}) {
+      add_param(pre + ".conv.weight", {h, cin, 1, 1}, 0, false, true);
+      add_param(pre + ".bn.weight", {h}, 0, false, true);
+      add_param(pre + ".bn.bias", {h}, 0, false, true);
+      add_param(pre + ".bn.running_mean", {h}, 0, true, true);
+      add_param(pre + ".bn.running_var", {h}, 0, true, true);
+      add_param(pre + ".bn.num_batches_tracked", {}, 1, true, false);
+    }
+    return (int)net.convs.size() - 1;
+  }
+
   static int out_dim(int x, int s) { return (x + 2 - 3) / s + 1; }   // 3x3, pad 1
 
   // BaseConv(cin, cout, k, s, groups): conv + BN + SiLU.
@@ -94,19 +110,28 @@ struct Builder {
     View u = base_conv(name + ".conv1", in, in.C, 1, 1, false);
     return conv(name + ".conv2", u, in.C, 3, 1, dst, shortcut ? &in : nullptr);
   }
+  // CSPLayer: conv1 and conv2 read the same input, so they run as ONE 1x1 conv of 2h channels writing the slices
+  // [conv2 | conv1] of a 3h-channel buffer [m(conv1) | conv2 | conv1]; conv3 reads the first 2h channels
+  // (= cat(m(conv1), conv2), the reference's order).  Halves the input reads and the launches of the pair, in
+  // eval and train mode alike (BN statistics are per channel).
   View csp(const std::string& name, View in, int cout, int n, bool shortcut, const View* dst = nullptr) {
     int h = cout / 2;
-    View cat = fresh(in.H, in.W, 2 * h);
-    View s0 = slice(cat, 0, h), s1 = slice(cat, h, h);
     if (n == 0) {
+      View cat = fresh(in.H, in.W, 2 * h);
+      View s0 = slice(cat, 0, h), s1 = slice(cat, h, h);
       base_conv(name + ".conv1", in, h, 1, 1, false, &s0);
-    } else {
-      View t = base_conv(name + ".conv1", in, h, 1, 1, false);
-      for (int i = 0; i < n; ++i)
-        t = bottleneck(name + ".m." + std::to_string(i), t, shortcut, i == n - 1 ? &s0 : nullptr);
+      base_conv(name + ".conv2", in, h, 1, 1, false, &s1);
+      return base_conv(name + ".conv3", cat, cout, 1, 1, false, dst);
     }
-    base_conv(name + ".conv2", in, h, 1, 1, false, &s1);
-    return base_conv(name + ".conv3", cat, cout, 1, 1, false, dst);
+    View buf3 = fresh(in.H, in.W, 3 * h);
+    View s0 = slice(buf3, 0, h), pair = slice(buf3, h, 2 * h), t = slice(buf3, 2 * h, h);
+    Op op;
+    op.kind = OP_PW; op.in = in; op.out = pair; op.stride = 1; op.act = ACT_NONE; op.name = name + ".conv2|conv1";
+    op.wslot = add_conv_pair(name + ".conv2", name + ".conv1", in.C, h);
+    net.ops.push_back(op);
+    for (int i = 0; i < n; ++i)
+      t = bottleneck(name + ".m." + std::to_string(i), t, shortcut, i == n - 1 ? &s0 : nullptr);
+    return base_conv(name + ".conv3", slice(buf3, 0, 2 * h), cout, 1, 1, false, dst);
   }
   View spp(const std::string& name, View in, int cout) {
     int h = in.C / 2;
