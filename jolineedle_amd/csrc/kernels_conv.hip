@@ -565,7 +565,8 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
 
 template <int CT, bool WT, int WM, typename IT, typename OT, bool BF>
 static void launch_pw_cfg(const ConvArgs& a, long long M, hipStream_t s) {
-  constexpr int KC = BF ? 64 : ((CT > 4) ? 32 : 64);
+  // K chunk: 64 wherever the tiles fit in 64 KB of LDS (fewer load -> LDS -> MFMA round trips)
+  constexpr int KC = BF ? 64 : ((CT > 4 && WM == 4) ? 32 : 64);
   constexpr int BM = 32 * WM;
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.cout + 16 * CT - 1) / (16 * CT)), a.n_slots > 1 ? a.n_slots : 1);
   const size_t smem = (size_t)(BM + 16 * CT) * (KC + (BF ? 8 : 4)) * (BF ? 2 : 4) + WM * 32 * CT * sizeof(float);
@@ -577,13 +578,17 @@ static void launch_pw_cfg(const ConvArgs& a, long long M, hipStream_t s) {
 template <int CT, typename IT, typename OT, bool BF>
 static void launch_pw_ct(const ConvArgs& a, long long M, hipStream_t s) {
   // few pixels (14x14 / 28x28 maps): 64-pixel workgroups double the workgroup count
-  constexpr bool can_split = (CT % 2 == 0);
-  const bool small_m = M * (a.n_slots > 1 ? a.n_slots : 1) <= 65536;
+  constexpr bool can_split = (CT % 2 == 0), can_split4 = (CT % 4 == 0);
+  const long long Mtot = M * (a.n_slots > 1 ? a.n_slots : 1);
+  const bool small_m = Mtot <= 65536, tiny_m = Mtot <= 16384;     // 28x28 | 14x14 maps at 64 patches
   if (a.w_transposed) {
     if (can_split && small_m) launch_pw_cfg<CT, true, can_split ? 2 : 4, IT, OT, BF>(a, M, s);
     else launch_pw_cfg<CT, true, 4, IT, OT, BF>(a, M, s);
   } else {
-    if (can_split && small_m) launch_pw_cfg<CT, false, can_split ? 2 : 4, IT, OT, BF>(a, M, s);
+    // 14x14 maps with K <= 128: 32-pixel workgroups (the four waves split the channel tiles) quadruple the
+    // workgroup count; with a longer K the re-staged weight tile costs more than the parallelism gains
+    if (can_split4 && tiny_m && a.cin <= 128) launch_pw_cfg<CT, false, can_split4 ? 1 : 4, IT, OT, BF>(a, M, s);
+    else if (can_split && small_m) launch_pw_cfg<CT, false, can_split ? 2 : 4, IT, OT, BF>(a, M, s);
     else launch_pw_cfg<CT, false, 4, IT, OT, BF>(a, M, s);
   }
 }
@@ -745,10 +750,16 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long r
                                    int C, float eps, float momentum, const int* __restrict__ skip_flag,
                                    int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  // 8 lanes per channel, 4 replicas each (independent loads), then three DPP-free xor steps inside the octet
+  const int sub = threadIdx.x & 7;
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+  const int cc = c < C ? c : C - 1;
   double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < JN_NREP; ++r) { s1 += stats[r * rep_stride + 2 * c]; s2 += stats[r * rep_stride + 2 * c + 1]; }
+#pragma unroll
+  for (int r = sub; r < JN_NREP; r += 8) { s1 += stats[r * rep_stride + 2 * cc]; s2 += stats[r * rep_stride + 2 * cc + 1]; }
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
+  if (sub != 0 || c >= C) return;
   const double mean = s1 / count;
   double var = s2 / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -768,7 +779,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long r
 int launch_bn_finalize(const double* stats, long long rep_stride, double count, const float* gamma, const float* beta, float* run_mean,
                        float* run_var, float* save, ChanTab t0, ChanTab t1, int C, float eps, float momentum,
                        const int* skip_flag, int skip_when, hipStream_t s) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, stats, rep_stride, count, gamma, beta, run_mean,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((8 * C + 255) / 256), dim3(256), 0, s, stats, rep_stride, count, gamma, beta, run_mean,
                      run_var,
                      save, t0, t1, C, eps, momentum, skip_flag, skip_when);
   return 0;
