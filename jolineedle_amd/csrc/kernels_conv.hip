@@ -94,29 +94,24 @@ constexpr int ST_TY = 16, ST_TX = 32;
 constexpr int ST_IH = 2 * ST_TY + 4, ST_IW = 2 * ST_TX + 4;   // 36 x 68
 constexpr int ST_KS = 27;                                     // 108 / 4 k-steps
 
+// Persistent: a workgroup keeps its weight fragments in registers and walks over (patch, tile) pairs; the image
+// values of the NEXT tile are fetched into registers while the MFMAs of the current one run (the per-tile
+// load -> LDS -> MFMA sequence left the matrix pipe idle two thirds of the time).
+constexpr int ST_NL = (3 * ST_IH * ST_IW + 255) / 256;        // image values per thread per tile
+
 template <typename OT>
 __global__ __launch_bounds__(256) void stem_mfma_kernel(
     const float* __restrict__ src, const long long* __restrict__ pos, int pos_stride, long long sample_stride,
     long long chan_stride, int row_stride, int P, const float* __restrict__ w, OT* __restrict__ out,
-    int out_ld, int cout, int ocg, double* __restrict__ stats, long long rep_stride,
+    int out_ld, int cout, int tiles_x, int tiles_y, int n_tiles, double* __restrict__ stats, long long rep_stride,
     const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
   __shared__ __attribute__((aligned(16))) float tile[3 * ST_IH * ST_IW];
   __shared__ float red[4 * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, g = lane >> 4;
-  const int n = blockIdx.z / ocg, og = blockIdx.z % ocg;
+  const int og = blockIdx.y;
   const int OH = P / 2;
-  const int oy0 = blockIdx.y * ST_TY, ox0 = blockIdx.x * ST_TX;
-  const float* base = src + (long long)n * sample_stride;
-  if (pos) base += pos[(long long)pos_stride * n] * (long long)P * row_stride + pos[(long long)pos_stride * n + 1] * (long long)P;
-  for (int i = tid; i < 3 * ST_IH * ST_IW; i += 256) {
-    const int c = i / (ST_IH * ST_IW), r = (i / ST_IW) % ST_IH, q = i % ST_IW;
-    const int iy = 2 * oy0 - 2 + r, ix = 2 * ox0 - 2 + q;
-    float v = 0.0f;
-    if (iy >= 0 && iy < P && ix >= 0 && ix < P) v = base[c * chan_stride + (long long)iy * row_stride + ix];
-    tile[i] = v;
-  }
   // A operand (weights): lane holds W[oc = lm][k = 4s + g] for every k-step s; B operand offset table
   float wreg[ST_KS];
   int koff[ST_KS];
@@ -127,31 +122,60 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(
     const int c = k / 36, dy = (k % 36) / 6, dx = k % 6;
     koff[s] = (c * ST_IH + dy) * ST_IW + dx;
   }
-  __syncthreads();
+  float pre[ST_NL];
+  auto fetch = [&](int tl) {
+    const int n = tl / (tiles_x * tiles_y), tr = tl - n * (tiles_x * tiles_y);
+    const int oy0 = (tr / tiles_x) * ST_TY, ox0 = (tr % tiles_x) * ST_TX;
+    const float* base = src + (long long)n * sample_stride;
+    if (pos) base += pos[(long long)pos_stride * n] * (long long)P * row_stride + pos[(long long)pos_stride * n + 1] * (long long)P;
+#pragma unroll
+    for (int j = 0; j < ST_NL; ++j) {
+      const int i = tid + 256 * j;
+      const int c = i / (ST_IH * ST_IW), r = (i / ST_IW) % ST_IH, q = i % ST_IW;
+      const int iy = 2 * oy0 - 2 + r, ix = 2 * ox0 - 2 + q;
+      float v = 0.0f;
+      if (i < 3 * ST_IH * ST_IW && iy >= 0 && iy < P && ix >= 0 && ix < P) v = base[c * chan_stride + (long long)iy * row_stride + ix];
+      pre[j] = v;
+    }
+  };
   f32x4 s1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, s2[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+  int tl = blockIdx.x;
+  if (tl < n_tiles) fetch(tl);
+  for (; tl < n_tiles; tl += gridDim.x) {
+    const int n = tl / (tiles_x * tiles_y), tr = tl - n * (tiles_x * tiles_y);
+    const int oy0 = (tr / tiles_x) * ST_TY, ox0 = (tr % tiles_x) * ST_TX;
+    __syncthreads();                                   // the previous tile's MFMAs have read their operands
+#pragma unroll
+    for (int j = 0; j < ST_NL; ++j) {
+      const int i = tid + 256 * j;
+      if (i < 3 * ST_IH * ST_IW) tile[i] = pre[j];
+    }
+    __syncthreads();
+    if (tl + (int)gridDim.x < n_tiles) fetch(tl + gridDim.x);
 #pragma unroll 1
-  for (int r = 0; r < 4; ++r) {
-    const int ty = wave * 4 + r;
-    const int oy = oy0 + ty;
+    for (int r = 0; r < 4; ++r) {
+      const int ty = wave * 4 + r;
+      const int oy = oy0 + ty;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int pbase = (2 * ty) * ST_IW + 2 * (16 * h + lm);
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int h = 0; h < 2; ++h) {
+        const int pbase = (2 * ty) * ST_IW + 2 * (16 * h + lm);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < ST_KS; ++s)
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], tile[pbase + koff[s]], acc, 0, 0, 0);
-      const int ox = ox0 + 16 * h + lm;
-      if (oy < OH && ox < OH) {
-        st4(out + (((long long)n * OH + oy) * OH + ox) * out_ld + og * 16 + 4 * g, acc);
-        s1[0] += acc;
-        s2[0] += acc * acc;
+        for (int s = 0; s < ST_KS; ++s)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s], tile[pbase + koff[s]], acc, 0, 0, 0);
+        const int ox = ox0 + 16 * h + lm;
+        if (oy < OH && ox < OH) {
+          st4(out + (((long long)n * OH + oy) * OH + ox) * out_ld + og * 16 + 4 * g, acc);
+          s1[0] += acc;
+          s2[0] += acc * acc;
+        }
       }
     }
   }
   if (stats) {
     wave_stats_to_lds<1>(s1, s2, red + 32 * wave, lane, 16);
     __syncthreads();
-    const int rep = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z) % JN_NREP;
+    const int rep = (blockIdx.x + blockIdx.y) % JN_NREP;
     if (tid < 32)
       atomicAdd(&stats[rep * rep_stride + 2 * (og * 16) + tid], (double)(red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid]));
   }
@@ -160,15 +184,19 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(
 int launch_stem(const StemArgs& a, hipStream_t s) {
   const int OH = a.P / 2;
   const int ocg = a.cout / 16;
-  dim3 grid((OH + ST_TX - 1) / ST_TX, (OH + ST_TY - 1) / ST_TY, a.N * ocg);
+  const int tiles_x = (OH + ST_TX - 1) / ST_TX, tiles_y = (OH + ST_TY - 1) / ST_TY, n_tiles = tiles_x * tiles_y * a.N;
+  int nwg = 512 / ocg;                                 // 2 persistent workgroups per CU (222 VGPRs)
+  if (nwg < 1) nwg = 1;
+  if (nwg > n_tiles) nwg = n_tiles;
+  dim3 grid(nwg, ocg);
   if (a.out_dtype == JN_BF16)
     hipLaunchKernelGGL(stem_mfma_kernel<bf16_t>, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.pos_stride,
-                       a.sample_stride, a.chan_stride, a.row_stride, a.P, a.w, (bf16_t*)a.out, a.out_ld, a.cout, ocg,
-                       a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when);
+                       a.sample_stride, a.chan_stride, a.row_stride, a.P, a.w, (bf16_t*)a.out, a.out_ld, a.cout, tiles_x,
+                       tiles_y, n_tiles, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when);
   else
     hipLaunchKernelGGL(stem_mfma_kernel<float>, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.pos_stride,
-                       a.sample_stride, a.chan_stride, a.row_stride, a.P, a.w, (float*)a.out, a.out_ld, a.cout, ocg,
-                       a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when);
+                       a.sample_stride, a.chan_stride, a.row_stride, a.P, a.w, (float*)a.out, a.out_ld, a.cout, tiles_x,
+                       tiles_y, n_tiles, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when);
   return 0;
 }
 
