@@ -36,7 +36,7 @@ NANO_448_ELEMS_PER_PATCH = 17.44e6
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 # HBM traffic of ONE forward conv-stack pass at B=64, 448 px from the PMC counters (separate --pmc FETCH_SIZE and
 # --pmc WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM): profiles/r01_c_pmc_conv_stack_traffic.txt
-PMC_TRAFFIC_BYTES_B64_448 = 5.581e9
+PMC_TRAFFIC_BYTES_B64_448 = 5.552e9
 
 
 def synth_inputs(B, G, P, seed, device):

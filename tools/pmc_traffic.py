@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter CSVs of the conv stack into HBM bytes per pass.
+
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <glimpse steps in the run> <batch>
+
+Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KB;
+FETCH_SIZE reports half of the bytes of wide coalesced streaming reads, so read bytes = 2 * FETCH_SIZE * 1024.
+"""
+import collections
+import csv
+import re
+import sys
+
+CONV = ("stem_mfma_kernel", "dw3x3", "pw_mfma_kernel", "addact_kernel", "spp_kernel", "upsample_kernel", "conv3_mfma")
+
+
+def short(name):
+    name = re.sub(r"^void\s+", "", name)
+    name = name.replace("jnr::", "")
+    return re.sub(r"\(.*", "", name)
+
+
+def load(path, counter):
+    tot, calls = collections.Counter(), collections.Counter()
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = short(r["Kernel_Name"])
+        if not any(c in k for c in CONV):
+            continue
+        tot[k] += float(r["Counter_Value"])
+        calls[k] += 1
+    return tot, calls
+
+
+def main():
+    fetch, calls = load(sys.argv[1], "FETCH_SIZE")
+    write, _ = load(sys.argv[2], "WRITE_SIZE")
+    steps, batch = int(sys.argv[3]), int(sys.argv[4])
+    print(f"{'kernel':58s} {'calls':>6s} {'FETCH_SIZE_KB':>14s} {'WRITE_SIZE_KB':>14s}")
+    for k in sorted(fetch, key=lambda k: -(fetch[k] + write[k])):
+        print(f"{k:58s} {calls[k]:6d} {fetch[k]:14.0f} {write[k]:14.0f}")
+    f, w = sum(fetch.values()), sum(write.values())
+    rd, wr = 2 * f * 1024 / steps, w * 1024 / steps
+    algo = 17.44e6 * 4 * batch
+    print(f"# conv stack, {steps} glimpse steps: FETCH {f:.0f} KB, WRITE {w:.0f} KB")
+    print(f"# per glimpse step (one pass over {batch} patches): reads 2*{f * 1024 / steps / 1e9:.3f} = {rd / 1e9:.3f} GB, "
+          f"writes {wr / 1e9:.3f} GB, total {(rd + wr) / 1e9:.3f} GB")
+    print(f"# algorithmic (SURVEY 8d, fp32): 17.44 M elems * 4 B * {batch} = {algo / 1e9:.3f} GB -> traffic / algorithmic = "
+          f"{(rd + wr) / algo:.2f}")
+
+
+if __name__ == "__main__":
+    main()
