@@ -670,7 +670,6 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
       case OP_CONV3:
       case OP_DW: {
         const ConvW& cw = net.convs[op.wslot];
-        JN_CHECK(!(train && op.kind == OP_CONV3), JN_ESTATE, "train-mode dense 3x3 conv (%s) is not implemented", op.name.c_str());
         ConvArgs a{};
         a.in = ptr(op.in); a.in_ld = ld(op.in); a.in_dtype = net.act_dtype; a.itab = tab(op.in); a.w = cw.w_dev;
         a.bias = cw.b_dev; a.out = ptr(op.out); a.out_ld = ld(op.out); a.out_dtype = net.act_dtype;
@@ -865,8 +864,28 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
         StemArgs a{ss.src, ss.positions, ss.pos_stride, ss.sample_stride, ss.chan_stride, ss.row_stride, net.P, N, cw.cout,
                    cw.w_dev, nullptr, 0, JN_F32, nullptr, 0, nullptr, 0};
         launch_stem_bwd_weight(a, gptr(op.out), ld(op.out), gw, ctx->wpart, s, sb);
+      } else if (op.kind == OP_CONV3) {
+        // dense 3x3 (non-depthwise patch encoders, e.g. yolox-s): stride 1 = the forward kernel over g_z with
+        // mirrored taps and the transposed weight; stride 2 = one MFMA tile loop per input-pixel parity class
+        int rc3 = 0;
+        if (op.stride == 1) {
+          ConvArgs a{};
+          a.in = gptr(op.out); a.in_ld = ld(op.out); a.in_dtype = JN_F32; a.itab = ident; a.w = cw.w_dev; a.bias = nullptr;
+          a.out = gptr(op.in); a.out_ld = ld(op.in); a.out_dtype = JN_F32;
+          a.N = N; a.H = op.out.H; a.W = op.out.W; a.OH = op.in.H; a.OW = op.in.W;
+          a.cin = cw.cout; a.cout = cw.cin; a.stride = 1; a.act = ACT_NONE;
+          a.accumulate = op.acc_in ? 1 : 0; a.w_transposed = 1;
+          a.n_slots = nsl; a.in_slot_stride = sb.grad; a.out_slot_stride = sb.grad;
+          rc3 = launch_conv3(a, s);
+        } else {
+          rc3 = launch_conv3_bwd_data_s2(gptr(op.out), ld(op.out), cw.w_dev, gptr(op.in), ld(op.in), op.in.H, op.in.W, op.out.H,
+                                         op.out.W, cw.cout, cw.cin, N, op.acc_in ? 1 : 0, s, sb);
+        }
+        JN_CHECK(rc3 == 0, JN_ESTATE, "backward of dense 3x3 conv %s: unsupported shape", op.name.c_str());
+        launch_conv3_bwd_weight(gptr(op.out), ld(op.out), ptr(op.in), net.act_dtype, ld(op.in), tab(op.in), gw, op.in.H, op.in.W,
+                                op.out.H, op.out.W, cw.cout, cw.cin, N, op.stride, s, sb);
       } else {
-        set_error("backward of dense 3x3 conv (%s) is not implemented", op.name.c_str());
+        set_error("backward of op %s is not implemented", op.name.c_str());
         return JN_ESTATE;
       }
       continue;

@@ -81,7 +81,13 @@ int launch_efpn_linear(const float* e, const float* wt, float* part, int N, int 
                        const int* skip_flag, int skip_when, hipStream_t s);
 
 // ---- detector (kernels_det.hip) --------------------------------------------------------------
-int launch_conv3(const ConvArgs& a, hipStream_t s);
+int launch_conv3(const ConvArgs& a, hipStream_t s);     // w_transposed: data gradient of a stride-1 layer
+int launch_conv3_bwd_data_s2(const float* gz, int g_ld, const float* w, float* gin, int gin_ld, int H, int W, int OH,
+                             int OW, int Co, int Ci, int N, int accumulate, hipStream_t s,
+                             const SlotBatch& sb = SlotBatch{});
+int launch_conv3_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, int x_ld, ChanTab it, float* gw, int H,
+                            int W, int OH, int OW, int Co, int Ci, int N, int stride, hipStream_t s,
+                            const SlotBatch& sb = SlotBatch{});
 int launch_head_pred(const void* reg, int reg_ld, ChanTab rt, const void* cls, int cls_ld, ChanTab ct, int dtype,
                      const float* wp, const float* bp, float* raw, int hid, int Hl, int Wl, int stride, int A, int a0,
                      int N, hipStream_t s);

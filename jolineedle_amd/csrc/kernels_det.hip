@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "jn_kernels.h"
+#include "jn_reduce.h"
 #include "jn_types.h"
 
 namespace jnr {
@@ -26,17 +27,24 @@ __device__ __forceinline__ f32x4 tf4_d(f32x4 z, f32x4 sc, f32x4 sh, f32x4 fl) {
 // ------------------------------------------------------------------------------------
 constexpr int C3_TH = 8, C3_TW = 16, C3_KC = 16, C3_LD = C3_KC + 4, C3_BN = 64;
 
-template <int S, typename AT>
+// WT (stride 1 only): the data gradient of a stride-1 layer is the same conv over g_z with the taps mirrored and the
+// weight read transposed: w'[tap][n][k] = w[8 - tap][k][n] (w is the forward [tap][Nc_fwd = K here][K_fwd = Nc here]).
+// accumulate: out += (gradient views with several writers); stats: BN sum / sumsq accumulators (train mode).
+template <int S, typename AT, bool WT>
 __global__ __launch_bounds__(256) void conv3_mfma_kernel(const AT* __restrict__ x, int x_ld, ChanTab it,
                                                          const float* __restrict__ w, AT* __restrict__ out,
                                                          int out_ld, int H, int W, int OH, int OW, int K, int Nc,
-                                                         int tiles_x, int tiles_y, const int* __restrict__ skip_flag,
-                                                         int skip_when) {
+                                                         int tiles_x, int tiles_y, int accumulate,
+                                                         double* __restrict__ stats, long long rep_stride,
+                                                         const int* __restrict__ skip_flag, int skip_when,
+                                                         long long x_slot, long long out_slot) {
   if (skip_flag && *skip_flag >= skip_when) return;
+  x += blockIdx.z * x_slot; out += blockIdx.z * out_slot;          // step-batched gradient launches
   constexpr int IH = C3_TH * S + 2, IW = C3_TW * S + 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;                              // [IH*IW][C3_LD]
   float* Ws = smem + IH * IW * C3_LD;            // [9][C3_BN][C3_LD]
+  float* red = Ws + 9 * C3_BN * C3_LD;           // [4 waves][C3_BN][2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, g = lane >> 4;
   const int tile = blockIdx.x % (tiles_x * tiles_y);
@@ -66,7 +74,15 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const AT* __restrict__ 
     for (int i = tid; i < 9 * C3_BN * 4; i += 256) {
       const int q = i & 3, r = (i >> 2) % C3_BN, tp = i / (4 * C3_BN);
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (n0 + r < Nc) v = *reinterpret_cast<const f32x4*>(w + ((long long)tp * Nc + n0 + r) * K + k0 + 4 * q);
+      if (n0 + r < Nc) {
+        if (WT) {
+          const float* wp = w + ((long long)(8 - tp) * K + k0 + 4 * q) * Nc + n0 + r;
+          const int kr = K - (k0 + 4 * q);           // K % 4 == 0 is checked by the launcher
+          if (kr > 0) v = f32x4{wp[0], wp[Nc], wp[2 * Nc], wp[3 * Nc]};
+        } else {
+          v = *reinterpret_cast<const f32x4*>(w + ((long long)tp * Nc + n0 + r) * K + k0 + 4 * q);
+        }
+      }
       *reinterpret_cast<f32x4*>(Ws + (tp * C3_BN + r) * C3_LD + 4 * q) = v;
     }
     __syncthreads();
@@ -87,6 +103,9 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const AT* __restrict__ 
         }
     }
   }
+  f32x4 s1[4], s2[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { s1[c] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[c] = s1[c]; }
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     const int oy = oy0 + 2 * wave + p, ox = ox0 + lm;
@@ -95,31 +114,249 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const AT* __restrict__ 
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int n = n0 + 16 * c + 4 * g;
-      if (n < Nc) st4(op + n, acc[p][c]);
+      if (n < Nc) {
+        f32x4 v = acc[p][c];
+        if (accumulate) v += ld4(op + n);
+        st4(op + n, v);
+        s1[c] += v;
+        s2[c] += v * v;
+      }
     }
+  }
+  if (stats) {
+    __syncthreads();                               // the MFMA loop's LDS readers are done; red aliases nothing but be safe
+    wave_stats_to_lds<4>(s1, s2, red + wave * 2 * C3_BN, lane, Nc - n0);
+    __syncthreads();
+    if (tid < 2 * C3_BN && n0 + (tid >> 1) < Nc)
+      atomicAdd(&stats[(blockIdx.x % JN_NREP) * rep_stride + 2 * n0 + tid],
+                (double)(red[tid] + red[2 * C3_BN + tid] + red[4 * C3_BN + tid] + red[6 * C3_BN + tid]));
   }
 }
 
-template <int S, typename AT>
+template <int S, typename AT, bool WT>
 static void launch_conv3_t(const ConvArgs& a, hipStream_t s) {
   const int tiles_x = (a.OW + C3_TW - 1) / C3_TW, tiles_y = (a.OH + C3_TH - 1) / C3_TH;
-  dim3 grid(tiles_x * tiles_y * a.N, (a.cout + C3_BN - 1) / C3_BN);
-  const size_t smem = ((size_t)(S * C3_TH + 2) * (S * C3_TW + 2) + 9 * C3_BN) * C3_LD * sizeof(float);
+  dim3 grid(tiles_x * tiles_y * a.N, (a.cout + C3_BN - 1) / C3_BN, a.n_slots > 1 ? a.n_slots : 1);
+  const size_t smem = (((size_t)(S * C3_TH + 2) * (S * C3_TW + 2) + 9 * C3_BN) * C3_LD + 4 * 2 * C3_BN) * sizeof(float);
   if (smem > 64 * 1024) {             // stride 2: 95 KB of the CU's 160 KB LDS, above the 64 KB default cap
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_mfma_kernel<S, AT>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_mfma_kernel<S, AT, WT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       attr_set = true;
     }
   }
-  hipLaunchKernelGGL((conv3_mfma_kernel<S, AT>), grid, dim3(256), smem, s, (const AT*)a.in, a.in_ld, a.itab, a.w, (AT*)a.out,
-                     a.out_ld, a.H, a.W, a.OH, a.OW, a.cin, a.cout, tiles_x, tiles_y, a.skip_flag, a.skip_when);
+  hipLaunchKernelGGL((conv3_mfma_kernel<S, AT, WT>), grid, dim3(256), smem, s, (const AT*)a.in, a.in_ld, a.itab, a.w,
+                     (AT*)a.out, a.out_ld, a.H, a.W, a.OH, a.OW, a.cin, a.cout, tiles_x, tiles_y, a.accumulate, a.stats,
+                     a.stats_rep_stride, a.skip_flag, a.skip_when, a.in_slot_stride, a.out_slot_stride);
 }
 
 int launch_conv3(const ConvArgs& a, hipStream_t s) {
-  if (a.in_dtype == JN_BF16) { if (a.stride == 1) launch_conv3_t<1, bf16_t>(a, s); else launch_conv3_t<2, bf16_t>(a, s); }
-  else { if (a.stride == 1) launch_conv3_t<1, float>(a, s); else launch_conv3_t<2, float>(a, s); }
+  if (a.w_transposed) {               // data gradient of a stride-1 layer (fp32 gradient buffers)
+    if (a.stride != 1 || a.in_dtype != JN_F32 || a.cin % 4) return -1;
+    launch_conv3_t<1, float, true>(a, s);
+    return 0;
+  }
+  if (a.in_dtype == JN_BF16) { if (a.stride == 1) launch_conv3_t<1, bf16_t, false>(a, s); else launch_conv3_t<2, bf16_t, false>(a, s); }
+  else { if (a.stride == 1) launch_conv3_t<1, float, false>(a, s); else launch_conv3_t<2, float, false>(a, s); }
+  return 0;
+}
+
+// ---- data gradient of a stride-2 dense 3x3 layer -------------------------------------------------------
+// g_in[iy][ix][k] = sum over taps with (iy + 1 - ky), (ix + 1 - kx) even of g_z[(iy+1-ky)/2][(ix+1-kx)/2][o] * w[tap][o][k].
+// The input pixels of one parity class (iy & 1, ix & 1) over a 16 x 32 input tile form an 8 x 16 grid that maps 1:1
+// onto output pixels (a, b) = (iy >> 1, ix >> 1) (+1 for the odd taps): the same MFMA tile loop as the forward
+// kernel with 1 / 2 / 2 / 4 taps.  blockIdx.z = parity class (x slot); g_z tile (9 x 17 pixels) per K chunk in LDS.
+__global__ __launch_bounds__(256) void conv3_bwd_data_s2_kernel(const float* __restrict__ gz, int g_ld,
+                                                                const float* __restrict__ w, float* __restrict__ gin,
+                                                                int gin_ld, int H, int W, int OH, int OW, int Co, int Ci,
+                                                                int tiles_x, int tiles_y, int accumulate,
+                                                                long long g_slot) {
+  constexpr int GH = C3_TH + 1, GW = C3_TW + 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Gs = smem;                              // [GH*GW][C3_LD]   g_z, K chunk of 16 output channels
+  float* Ws = smem + GH * GW * C3_LD;            // [4][C3_BN][C3_LD] the class's taps: [cin row][cout chunk]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, g = lane >> 4;
+  const int cls = blockIdx.z & 3, py = cls >> 1, px = cls & 1;
+  const long long sl = blockIdx.z >> 2;
+  gz += sl * g_slot; gin += sl * g_slot;
+  const int tile = blockIdx.x % (tiles_x * tiles_y), n_img = blockIdx.x / (tiles_x * tiles_y);
+  const int a0 = (tile / tiles_x) * C3_TH, b0 = (tile % tiles_x) * C3_TW;     // output-space origin of the tile
+  const int n0 = blockIdx.y * C3_BN;                                          // input-channel block
+  // taps of this class: even coordinate -> k = 1 (offset 0); odd -> k = 0 (offset +1) and k = 2 (offset 0)
+  const int nky = py ? 2 : 1, nkx = px ? 2 : 1;
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < Co; k0 += C3_KC) {
+    if (k0) __syncthreads();
+    for (int i = tid; i < GH * GW * 4; i += 256) {
+      const int pix = i >> 2, q = i & 3;
+      const int oy = a0 + pix / GW, ox = b0 + pix % GW;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (oy < OH && ox < OW && k0 + 4 * q < Co)
+        v = *reinterpret_cast<const f32x4*>(gz + (((long long)n_img * OH + oy) * OW + ox) * g_ld + k0 + 4 * q);
+      *reinterpret_cast<f32x4*>(Gs + pix * C3_LD + 4 * q) = v;
+    }
+    for (int i = tid; i < nky * nkx * C3_BN * 4; i += 256) {
+      const int q = i & 3, r = (i >> 2) % C3_BN, tq = i / (4 * C3_BN);
+      const int ky = py ? (tq / nkx) * 2 : 1, kx = px ? (tq % nkx) * 2 : 1;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n0 + r < Ci && k0 + 4 * q < Co) {
+        const float* wp = w + ((long long)(ky * 3 + kx) * Co + k0 + 4 * q) * Ci + n0 + r;      // w[tap][o][k]
+        v = f32x4{wp[0], wp[Ci], wp[2 * Ci], wp[3 * Ci]};
+      }
+      *reinterpret_cast<f32x4*>(Ws + (tq * C3_BN + r) * C3_LD + 4 * q) = v;
+    }
+    __syncthreads();
+    for (int tq = 0; tq < nky * nkx; ++tq) {
+      const int ky = py ? (tq / nkx) * 2 : 1, kx = px ? (tq % nkx) * 2 : 1;
+      const int dy = ky == 0 ? 1 : 0, dx = kx == 0 ? 1 : 0;       // (iy + 1 - ky) / 2 - a
+      f32x4 xb0 = *reinterpret_cast<const f32x4*>(Gs + ((2 * wave + dy) * GW + lm + dx) * C3_LD + 4 * g);
+      f32x4 xb1 = *reinterpret_cast<const f32x4*>(Gs + ((2 * wave + 1 + dy) * GW + lm + dx) * C3_LD + 4 * g);
+      f32x4 wa[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wa[c] = *reinterpret_cast<const f32x4*>(Ws + (tq * C3_BN + 16 * c + lm) * C3_LD + 4 * g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][j], xb0[j], acc[0][c], 0, 0, 0);
+          acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][j], xb1[j], acc[1][c], 0, 0, 0);
+        }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int iy = 2 * (a0 + 2 * wave + p) + py, ix = 2 * (b0 + lm) + px;
+    if (iy >= H || ix >= W) continue;
+    float* op = gin + (((long long)n_img * H + iy) * W + ix) * gin_ld;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int n = n0 + 16 * c + 4 * g;
+      if (n < Ci) {
+        f32x4 v = acc[p][c];
+        if (accumulate) v += *reinterpret_cast<const f32x4*>(op + n);
+        *reinterpret_cast<f32x4*>(op + n) = v;
+      }
+    }
+  }
+}
+
+int launch_conv3_bwd_data_s2(const float* gz, int g_ld, const float* w, float* gin, int gin_ld, int H, int W, int OH,
+                             int OW, int Co, int Ci, int N, int accumulate, hipStream_t s, const SlotBatch& sb) {
+  if (Co % 4 || Ci % 4) return -1;
+  const int tiles_x = (OW + C3_TW - 1) / C3_TW, tiles_y = (OH + C3_TH - 1) / C3_TH;
+  dim3 grid(tiles_x * tiles_y * N, (Ci + C3_BN - 1) / C3_BN, 4 * sb.n);
+  const size_t smem = ((size_t)(C3_TH + 1) * (C3_TW + 1) + 4 * C3_BN) * C3_LD * sizeof(float);
+  hipLaunchKernelGGL(conv3_bwd_data_s2_kernel, grid, dim3(256), smem, s, gz, g_ld, w, gin, gin_ld, H, W, OH, OW, Co, Ci,
+                     tiles_x, tiles_y, accumulate, sb.grad);
+  return 0;
+}
+
+// ---- weight gradient of a dense 3x3 layer: dW[tap][o][k] += sum_pixels g_z[p][o] * a[p (+) tap][k] ------------
+// Workgroup = (pixel-tile group, 64 output channels, 32 input channels): per 8 x 16 pixel tile the g_z tile [128][64]
+// and the activated input halo tile [(8S+2)(16S+2)][32] sit in LDS; wave w contracts the 128 pixels for output-channel
+// tile w, 2 input tiles and the 9 taps (18 accumulators), persistent over its tiles; one set of atomics at the end.
+constexpr int CW_BO = 64, CW_BK = 32, CW_LDG = CW_BO + 4, CW_LDX = CW_BK + 4;
+
+template <int S, typename XT>
+__global__ __launch_bounds__(256) void conv3_bwd_weight_kernel(const float* __restrict__ gz, int g_ld,
+                                                               const XT* __restrict__ x, int x_ld, ChanTab it,
+                                                               float* __restrict__ gw, int H, int W, int OH, int OW,
+                                                               int Co, int Ci, int tiles_x, int tiles_y, int n_tiles,
+                                                               SlotBatch sb) {
+  constexpr int IH = C3_TH * S + 2, IW = C3_TW * S + 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Gs = smem;                              // [128][CW_LDG]
+  float* Xs = smem + 128 * CW_LDG;               // [IH*IW][CW_LDX]
+  {
+    const long long sl = blockIdx.z / ((Ci + CW_BK - 1) / CW_BK);
+    gz += sl * sb.grad; x += sl * sb.act;
+    it.sc += sl * sb.tab; it.sh += sl * sb.tab; it.fl += sl * sb.tab;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, g = lane >> 4;
+  const int o0 = blockIdx.y * CW_BO, k0 = (blockIdx.z % ((Ci + CW_BK - 1) / CW_BK)) * CW_BK;
+  f32x4 acc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int tr = tile % (tiles_x * tiles_y), n_img = tile / (tiles_x * tiles_y);
+    const int oy0 = (tr / tiles_x) * C3_TH, ox0 = (tr % tiles_x) * C3_TW;
+    __syncthreads();
+    for (int i = tid; i < 128 * (CW_BO / 4); i += 256) {
+      const int pix = i / (CW_BO / 4), q = i % (CW_BO / 4);
+      const int oy = oy0 + pix / C3_TW, ox = ox0 + pix % C3_TW;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (oy < OH && ox < OW && o0 + 4 * q < Co)
+        v = *reinterpret_cast<const f32x4*>(gz + (((long long)n_img * OH + oy) * OW + ox) * g_ld + o0 + 4 * q);
+      *reinterpret_cast<f32x4*>(Gs + pix * CW_LDG + 4 * q) = v;
+    }
+    for (int i = tid; i < IH * IW * (CW_BK / 4); i += 256) {
+      const int pix = i / (CW_BK / 4), q = i % (CW_BK / 4);
+      const int iy = oy0 * S - 1 + pix / IW, ix = ox0 * S - 1 + pix % IW;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int kk = k0 + 4 * q;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W && kk < Ci)
+        v = tf4_d(ld4(x + (((long long)n_img * H + iy) * W + ix) * x_ld + kk), *reinterpret_cast<const f32x4*>(it.sc + kk),
+                  *reinterpret_cast<const f32x4*>(it.sh + kk), *reinterpret_cast<const f32x4*>(it.fl + kk));
+      *reinterpret_cast<f32x4*>(Xs + pix * CW_LDX + 4 * q) = v;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int st = 0; st < 32; ++st) {              // 4 pixels per k-step: lane group g takes pixel 4 st + g
+      const int pix = 4 * st + g, ty = pix / C3_TW, tx = pix % C3_TW;
+      const float av = Gs[pix * CW_LDG + 16 * wave + lm];            // A[i = cout][k = pixel]
+      const float* xp = Xs + ((ty * S) * IW + tx * S) * CW_LDX + lm;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float* xt = xp + ((t / 3) * IW + (t % 3)) * CW_LDX;
+        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xt[0], acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xt[16], acc[t][1], 0, 0, 0);
+      }
+    }
+  }
+  // D[i = cout 4g + r][j = cin lm]: dW[tap][o][k], k contiguous
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = o0 + 16 * wave + 4 * g + r, k = k0 + 16 * h + lm;
+        if (o < Co && k < Ci) atomicAdd(&gw[((long long)t * Co + o) * Ci + k], acc[t][h][r]);
+      }
+}
+
+int launch_conv3_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, int x_ld, ChanTab it, float* gw, int H,
+                            int W, int OH, int OW, int Co, int Ci, int N, int stride, hipStream_t s, const SlotBatch& sb) {
+  const int tiles_x = (OW + C3_TW - 1) / C3_TW, tiles_y = (OH + C3_TH - 1) / C3_TH, n_tiles = tiles_x * tiles_y * N;
+  const int nbo = (Co + CW_BO - 1) / CW_BO, nbk = (Ci + CW_BK - 1) / CW_BK;
+  long long gx = 2048 / ((long long)nbo * nbk * sb.n);      // persistent workgroups over the pixel tiles
+  if (gx < 1) gx = 1;
+  if (gx > n_tiles) gx = n_tiles;
+  dim3 grid((unsigned)gx, nbo, nbk * sb.n);
+#define JN_CW(S_, T_)                                                                                                 \
+  {                                                                                                                   \
+    const size_t smem = ((size_t)128 * CW_LDG + (size_t)(C3_TH * S_ + 2) * (C3_TW * S_ + 2) * CW_LDX) * sizeof(float); \
+    if (smem > 64 * 1024) {                                                                                           \
+      static bool raised = false;                                                                                     \
+      if (!raised) {                                                                                                  \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bwd_weight_kernel<S_, T_>),                    \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                             \
+        raised = true;                                                                                                \
+      }                                                                                                               \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((conv3_bwd_weight_kernel<S_, T_>), grid, dim3(256), smem, s, gz, g_ld, (const T_*)x, x_ld, it, \
+                       gw, H, W, OH, OW, Co, Ci, tiles_x, tiles_y, n_tiles, sb);                                      \
+  }
+  if (x_dtype == JN_BF16) { if (stride == 1) JN_CW(1, bf16_t) else JN_CW(2, bf16_t) }
+  else { if (stride == 1) JN_CW(1, float) else JN_CW(2, float) }
+#undef JN_CW
   return 0;
 }
 

@@ -109,6 +109,23 @@ def test_nano_backbone_fpn_maps(P, N):
         assert err < TOL_MAP, (i, err)
 
 
+def test_dense_backbone_train_mode_batchnorm():
+    """yolox-s encoder (dense 3x3 convs) in train mode: batch-statistics maps and running-stat updates."""
+    product, oracle = make_pair(3, patch_size=96, block_size=6, with_detector=False, image_processor=None, gpt_backbone="yolox-s")
+    x = torch.rand((3, 3, 96, 96), generator=torch.Generator().manual_seed(5))
+    oracle.gpt_backbone.train()
+    with torch.no_grad():
+        ref = oracle.gpt_backbone(x)
+    got = product.backbone_features(x, train=True)
+    for i in range(3):
+        assert (got[i].cpu() - ref[i]).abs().max().item() < 1e-3, i
+    product.pull_bn_statistics()
+    osd, psd = oracle.state_dict(), product.state_dict()
+    for k in osd:
+        if k.startswith("gpt_backbone") and ("running_mean" in k or "running_var" in k):
+            assert torch.allclose(psd[k], osd[k], atol=1e-5, rtol=1e-4), k
+
+
 @pytest.mark.parametrize("P,N", [(64, 5), (448, 3)])
 def test_nano_backbone_train_mode_batchnorm(P, N):
     """Train-mode BN (batch statistics per pass, src/reinforce.py:304) + running-stat update."""
@@ -137,11 +154,12 @@ def test_nano_backbone_train_mode_batchnorm(P, N):
         assert (got[i].cpu() - ref[i]).abs().max().item() < 1e-3
 
 
-@pytest.mark.parametrize("P,N", [(64, 4), (448, 2)])
-def test_nano_backbone_backward_vs_autograd(P, N):
+@pytest.mark.parametrize("P,N,bb", [(64, 4, "yolox-nano"), (448, 2, "yolox-nano"), (64, 3, "yolox-s"), (160, 2, "yolox-s")])
+def test_nano_backbone_backward_vs_autograd(P, N, bb):
     """Gradients of every conv weight and BN weight/bias of the patch encoder (train-mode BN)
-    for loss = sum_i <fpn_i, R_i>, against torch autograd on the CPU oracle."""
-    product, oracle = make_pair(3, patch_size=P, block_size=6, with_detector=False, image_processor=None)
+    for loss = sum_i <fpn_i, R_i>, against torch autograd on the CPU oracle.  yolox-s = the dense 3x3
+    (non-depthwise) encoder of BASELINE config 5: stride-1 / stride-2 data gradients and the 9-tap weight gradient."""
+    product, oracle = make_pair(3, patch_size=P, block_size=6, with_detector=False, image_processor=None, gpt_backbone=bb)
     g = torch.Generator().manual_seed(17)
     x = torch.rand((N, 3, P, P), generator=g)
     net = oracle.gpt_backbone.train()
@@ -167,8 +185,9 @@ def test_nano_backbone_backward_vs_autograd(P, N):
     product.backbone_features(x, train=True)
     product.backbone_backward(x, R)
     got2 = product.engine_grads("gpt_backbone.")
-    k = "gpt_backbone.backbone.dark3.1.conv3.conv.weight"
-    assert torch.allclose(got2[k], 2 * got[k], rtol=1e-3, atol=1e-3 * got[k].abs().max().item())
+    for k in ("gpt_backbone.backbone.dark3.1.conv3.conv.weight", "gpt_backbone.backbone.dark3.0.conv.weight"):
+        if k in got:
+            assert torch.allclose(got2[k], 2 * got[k], rtol=1e-3, atol=1e-3 * got[k].abs().max().item())
 
 
 def test_backbone_golden_and_patch_embedding(golden):
@@ -207,6 +226,7 @@ def test_gpt_forward_full_and_recurrent_golden(golden):
 
 @pytest.mark.parametrize("kw", [dict(concat_emb=False), dict(decoder_pos_encoding=False, nclasses=8),
                                 dict(use_pos_emb=False), dict(model_type="gpt-mini"),
+                                dict(model_type="gpt-mini", gpt_backbone="yolox-s"),     # BASELINE config 5 topology
                                 dict(gpt_backbone=None, image_processor="yolox-nano")])
 def test_gpt_forward_variants_vs_oracle(kw):
     base = dict(patch_size=64, block_size=5, image_processor="yolox-nano", gpt_backbone="yolox-nano")
@@ -413,15 +433,17 @@ def _oracle_reinforce_grads(oracle, images, bboxes, start, forced, P, Tn, stop, 
     return ro, m
 
 
-@pytest.mark.parametrize("stop,B,P,Tn,grad_slots", [(True, 3, 64, 4, None), (False, 2, 96, 3, None), (True, 3, 64, 4, 3)])
-def test_reinforce_iteration_gradients_vs_oracle(stop, B, P, Tn, grad_slots, monkeypatch):
+@pytest.mark.parametrize("stop,B,P,Tn,grad_slots,arch", [
+    (True, 3, 64, 4, None, {}), (False, 2, 96, 3, None, {}), (True, 3, 64, 4, 3, {}),
+    (True, 3, 96, 3, None, dict(model_type="gpt-mini", gpt_backbone="yolox-s"))])     # BASELINE config 5 topology
+def test_reinforce_iteration_gradients_vs_oracle(stop, B, P, Tn, grad_slots, arch, monkeypatch):
     """loss.backward() of a whole REINFORCE iteration (train-mode BN per glimpse step, T backbone
     passes, causal GPT over the trajectory) against torch autograd on the CPU oracle.  The backward is
     step-batched: all T passes per launch, or chunks of `grad_slots` passes when memory is capped."""
     if grad_slots:
         monkeypatch.setenv("JN_GRAD_SLOTS", str(grad_slots))
     nA = 9 if stop else 8
-    product, oracle = make_pair(5, patch_size=P, block_size=Tn, nclasses=nA, with_detector=False, image_processor=None)
+    product, oracle = make_pair(5, patch_size=P, block_size=Tn, nclasses=nA, with_detector=False, image_processor=None, **arch)
     images, bboxes, start = synth_batch(B, 3, 4, P, seed=41)
     forced = torch.randint(0, 8, (B, Tn), generator=torch.Generator().manual_seed(3))
     ro, m = _oracle_reinforce_grads(oracle, images, bboxes, start, forced, P, Tn, stop, 0.25, 1.5, 0.01)
@@ -448,7 +470,7 @@ def test_reinforce_iteration_gradients_vs_oracle(stop, B, P, Tn, grad_slots, mon
     assert checked > 150
     # running statistics moved Tn times, as in the reference's train-mode rollout
     product.pull_bn_statistics()
-    k = "gpt_backbone.backbone.dark2.0.pconv.bn.running_mean"
+    k = "gpt_backbone.backbone.dark2.0.pconv.bn.running_mean" if not arch else "gpt_backbone.backbone.dark2.0.bn.running_mean"
     assert torch.allclose(product.state_dict()[k], oracle.state_dict()[k], atol=1e-5, rtol=1e-3)
 
 
