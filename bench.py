@@ -34,6 +34,10 @@ sys.path.insert(0, str(ROOT))
 # BN+SiLU fused, concat/upsample/focus free: 17.44 M elements per patch, fp32 storage.
 NANO_448_ELEMS_PER_PATCH = 17.44e6
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+# --config c5 (BASELINE configs[4] topology on one GPU): yolox-s PAFPN @640 = 8.113 GMAC / patch, dense
+# 3x3 convs on fp32 MFMA -> 69 FLOP per fp32 byte, right of the fp32 ridge: priced against the dense fp32 MFMA peak.
+S_640_GMAC_PER_PATCH = 8.113e9
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
 # HBM traffic of ONE forward conv-stack pass at B=64, 448 px from the PMC counters (separate --pmc FETCH_SIZE and
 # --pmc WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM): profiles/r01_c_pmc_conv_stack_traffic.txt
 PMC_TRAFFIC_BYTES_B64_448 = 5.552e9
@@ -105,9 +109,17 @@ def main():
     ap.add_argument("--grid", type=int, default=10, help="image side in patches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["train", "rollout"], default="train")
+    ap.add_argument("--config", choices=["c3", "c5"], default="c3",
+                    help="c3 (default, the headline): gpt-nano + yolox-nano encoder, 448 px, T=20, B=64; "
+                         "c5: gpt-mini + yolox-s encoder, 640 px, T=32, B=16 (BASELINE configs[4] topology, secondary)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="activation storage / MFMA type; bf16 is the inference (rollout) mode only")
     args = ap.parse_args()
+    arch = {}
+    if args.config == "c5":
+        arch = dict(model_type="gpt-mini", gpt_backbone="yolox-s")
+        if args.batch == 64 and args.seq_len == 20 and args.patch_size == 448:
+            args.batch, args.seq_len, args.patch_size = 16, 32, 640
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -135,7 +147,7 @@ def main():
     torch.manual_seed(12345)
     assert not (args.dtype == "bf16" and args.mode == "train"), "bf16 is the inference mode: use --mode rollout"
     model = ja.GPT(model_config(patch_size=P, block_size=T, with_detector=False, image_processor=None,
-                                act_dtype=args.dtype),
+                                act_dtype=args.dtype, **arch),
                    max_batch=B, device=f"cuda:{local_rank}")
     model.sync_weights()
     cfg = ja.CfgNode(max_seq_len=T, entropy_weight=0.01, stop_enabled=True, reward_norm=True, seed=12345 + rank,
@@ -216,7 +228,17 @@ def main():
                          "ms_per_launch": round(conv_ms_per_launch, 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.config == "c5":
+            tflops = 2.0 * S_640_GMAC_PER_PATCH * (P / 640.0) ** 2 * B / (conv_ms_per_launch * 1e-3) / 1e12
+            out["metric"] = f"glimpse-patches/sec ({P}px, seq-len {T}) REINFORCE step, gpt-mini + yolox-s encoder"
+            out["config"]["workload"] = (f"configs[4] topology on {world} GPU: gpt-mini + yolox-s (dense 3x3) encoder, {P}px, "
+                                         f"seq-len {T}, {B} agents/GPU, forced non-STOP actions")
+            out["roofline"] = {"bound": "mfma", "kernel": "yolox-s PAFPN forward conv stack (dense 3x3 + 1x1 on "
+                                                          "v_mfma_f32_16x16x4_f32), one pass over the batch per glimpse step",
+                               "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                               "ms_per_launch": round(conv_ms_per_launch, 4)}
+        elif world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(P, T, 12345, train)
         print(json.dumps(out), flush=True)
     if dist is not None:
