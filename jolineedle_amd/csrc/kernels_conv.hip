@@ -555,10 +555,8 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
   }
 }
 
-template <int CT, bool WT, int WM, typename IT, typename OT, bool BF>
-static void launch_pw_cfg(const ConvArgs& a, long long M, hipStream_t s) {
-  // K chunk: 64 wherever the tiles fit in 64 KB of LDS (fewer load -> LDS -> MFMA round trips)
-  constexpr int KC = BF ? 64 : ((CT > 4 && WM == 4) ? 32 : 64);
+template <int CT, int KC, bool WT, int WM, typename IT, typename OT, bool BF>
+static void launch_pw_kc(const ConvArgs& a, long long M, hipStream_t s) {
   constexpr int BM = 32 * WM;
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.cout + 16 * CT - 1) / (16 * CT)), a.n_slots > 1 ? a.n_slots : 1);
   const size_t smem = (size_t)(BM + 16 * CT) * (KC + (BF ? 8 : 4)) * (BF ? 2 : 4) + WM * 32 * CT * sizeof(float);
@@ -567,21 +565,36 @@ static void launch_pw_cfg(const ConvArgs& a, long long M, hipStream_t s) {
                      a.stats_rep_stride, a.skip_flag, a.skip_when, a.in_slot_stride, a.out_slot_stride, a.tab_slot_stride);
 }
 
+template <int CT, bool WT, int WM, typename IT, typename OT, bool BF>
+static void launch_pw_cfg(const ConvArgs& a, long long M, hipStream_t s) {
+  // K chunk: 64 wherever the tiles fit in 64 KB of LDS (fewer load -> LDS -> MFMA round trips); layers with
+  // K <= 32 / K <= 16 get narrower LDS rows: half / a quarter of the LDS per workgroup = more workgroups per CU
+  constexpr int KC = BF ? 64 : ((CT > 4 && WM == 4) ? 32 : 64);
+  if constexpr (!BF && CT <= 4) {
+    if constexpr (WM >= 2) {
+      if (a.cin <= 16) { launch_pw_kc<CT, 16, WT, WM, IT, OT, BF>(a, M, s); return; }
+    }
+    if (a.cin <= 32) { launch_pw_kc<CT, 32, WT, WM, IT, OT, BF>(a, M, s); return; }
+  }
+  launch_pw_kc<CT, KC, WT, WM, IT, OT, BF>(a, M, s);
+}
+
 template <int CT, typename IT, typename OT, bool BF>
 static void launch_pw_ct(const ConvArgs& a, long long M, hipStream_t s) {
-  // few pixels (14x14 / 28x28 maps): 64-pixel workgroups double the workgroup count
+  // 64-pixel workgroups (two wave pairs split the channel tiles) whenever CT is even: half the LDS per
+  // workgroup -> more workgroups per CU, which is what hides the load -> LDS -> MFMA latency of these short kernels
+  // (measured: 56x56 layers 50 -> 42 us, 112x112 60 -> 55 us against 128-pixel workgroups)
   constexpr bool can_split = (CT % 2 == 0), can_split4 = (CT % 4 == 0);
   const long long Mtot = M * (a.n_slots > 1 ? a.n_slots : 1);
-  const bool small_m = Mtot <= 65536, tiny_m = Mtot <= 16384;     // 28x28 | 14x14 maps at 64 patches
-  if (a.w_transposed) {
-    if (can_split && small_m) launch_pw_cfg<CT, true, can_split ? 2 : 4, IT, OT, BF>(a, M, s);
+  const bool tiny_m = Mtot <= 16384;                  // 14x14 maps at 64 patches
+  if (a.w_transposed) {              // data gradients (step-batched, large): 128-pixel workgroups unless the map is small
+    if (can_split && Mtot <= 65536) launch_pw_cfg<CT, true, can_split ? 2 : 4, IT, OT, BF>(a, M, s);
     else launch_pw_cfg<CT, true, 4, IT, OT, BF>(a, M, s);
   } else {
     // 14x14 maps with K <= 128: 32-pixel workgroups (the four waves split the channel tiles) quadruple the
     // workgroup count; with a longer K the re-staged weight tile costs more than the parallelism gains
     if (can_split4 && tiny_m && a.cin <= 128) launch_pw_cfg<CT, false, can_split4 ? 1 : 4, IT, OT, BF>(a, M, s);
-    else if (can_split && small_m) launch_pw_cfg<CT, false, can_split ? 2 : 4, IT, OT, BF>(a, M, s);
-    else launch_pw_cfg<CT, false, 4, IT, OT, BF>(a, M, s);
+    else launch_pw_cfg<CT, false, can_split ? 2 : 4, IT, OT, BF>(a, M, s);
   }
 }
 
