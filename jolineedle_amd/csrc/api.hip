@@ -789,15 +789,21 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
   auto tab = [&](const View& v) { return view_tab(net, slot, v); };
   auto ld = [&](const View& v) { return net.bufs[v.buf].C; };
   const ChanTab ident{ctx->ident, ctx->ident + 2048, ctx->ident + 4096};
+  std::map<int, std::pair<int, View>> g_alias;      // conv output buffer -> (coff, gradient view to read instead)
   for (auto it = net.ops.rbegin(); it != net.ops.rend(); ++it) {
     const Op& op = *it;
     if (op.wslot >= 0) {
       const ConvW& cw = net.convs[op.wslot];
       JN_CHECK(cw.has_bn, JN_ESTATE, "backward of BN-free conv %s inside a PAFPN", op.name.c_str());
+      // the gradient of a conv that feeds a shortcut add IS the gradient of the sum: read it in place
+      const auto al = g_alias.find(op.out.buf);
+      const View gview = (al != g_alias.end() && al->second.first == op.out.coff) ? al->second.second : op.out;
+      float* const gp_out = gptr(gview);
+      const int gld_out = ld(gview);
       const long long M = (long long)N * op.out.H * op.out.W;
       double* red = net.bred + 2 * cw.stat_off;
       float* consts = net.bconsts + 3 * cw.stat_off;
-      launch_bn_bwd_reduce(gptr(op.out), ld(op.out), ptr(op.out), net.act_dtype, ld(op.out), tab(op.out), save + 2 * cw.stat_off, cw.cout,
+      launch_bn_bwd_reduce(gp_out, gld_out, ptr(op.out), net.act_dtype, ld(op.out), tab(op.out), save + 2 * cw.stat_off, cw.cout,
                            M, red, rep_stride, s, sb);
       launch_bn_bwd_consts(red, rep_stride, (double)M, cw.gamma_dev, save + 2 * cw.stat_off, consts,
                            grad_of(ctx, cw.gamma_dev), grad_of(ctx, cw.beta_dev), cw.cout, s, sb);
@@ -813,7 +819,7 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
           ChanTab ot = tab(op.out);
           ot.sc += c0; ot.sh += c0; ot.fl += c0;
           PwBwdFusedArgs fa{};
-          fa.g = gptr(op.out) + c0; fa.g_ld = ld(op.out); fa.z = (const float*)ptr(op.out) + c0; fa.z_ld = ld(op.out); fa.ot = ot;
+          fa.g = gp_out + c0; fa.g_ld = gld_out; fa.z = (const float*)ptr(op.out) + c0; fa.z_ld = ld(op.out); fa.ot = ot;
           fa.save = save + 2 * (cw.stat_off + c0); fa.consts = consts + 3 * c0;
           fa.x = (const float*)ptr(op.in); fa.x_ld = ld(op.in); fa.it = tab(op.in); fa.w = cw.w_dev + (size_t)c0 * cw.cin;
           fa.gx = gptr(op.in); fa.gx_ld = ld(op.in); fa.accumulate = (op.acc_in || part > 0) ? 1 : 0;
@@ -826,7 +832,7 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
       if (op.kind == OP_DW && net.act_dtype == JN_F32 && !no_fused && !no_fused_dw &&
           dw_bwd_fused_supported(cw.cout, op.in.H, op.in.W, op.out.H, op.out.W, op.stride)) {
         DwBwdFusedArgs fa{};
-        fa.g = gptr(op.out); fa.g_ld = ld(op.out); fa.z = (const float*)ptr(op.out); fa.z_ld = ld(op.out); fa.ot = tab(op.out);
+        fa.g = gp_out; fa.g_ld = gld_out; fa.z = (const float*)ptr(op.out); fa.z_ld = ld(op.out); fa.ot = tab(op.out);
         fa.save = save + 2 * cw.stat_off; fa.consts = consts;
         fa.x = (const float*)ptr(op.in); fa.x_ld = ld(op.in); fa.it = tab(op.in); fa.w = cw.w_dev;
         fa.gin = gptr(op.in); fa.gin_ld = ld(op.in); fa.accumulate = op.acc_in ? 1 : 0; fa.gw = gw; fa.wpart = ctx->wpart;
@@ -838,39 +844,39 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
       if (op.kind == OP_STEM && net.act_dtype == JN_F32 && !no_fused) {
         StemArgs a{ss.src, ss.positions, ss.pos_stride, ss.sample_stride, ss.chan_stride, ss.row_stride, net.P, N, cw.cout,
                    cw.w_dev, nullptr, 0, JN_F32, nullptr, 0, nullptr, 0};
-        launch_stem_bwd_weight(a, gptr(op.out), ld(op.out), gw, ctx->wpart, s, sb, (const float*)ptr(op.out), ld(op.out),
+        launch_stem_bwd_weight(a, gp_out, gld_out, gw, ctx->wpart, s, sb, (const float*)ptr(op.out), ld(op.out),
                                tab(op.out), save + 2 * cw.stat_off, consts);
         continue;
       }
-      launch_bn_bwd_gz(gptr(op.out), ld(op.out), ptr(op.out), net.act_dtype, ld(op.out), tab(op.out), save + 2 * cw.stat_off, consts,
+      launch_bn_bwd_gz(gp_out, gld_out, ptr(op.out), net.act_dtype, ld(op.out), tab(op.out), save + 2 * cw.stat_off, consts,
                        cw.cout, M, s, sb);
       if (op.kind == OP_PW) {
         ConvArgs a{};
-        a.in = gptr(op.out); a.in_ld = ld(op.out); a.in_dtype = JN_F32; a.itab = ident; a.w = cw.w_dev; a.bias = nullptr;
+        a.in = gp_out; a.in_ld = gld_out; a.in_dtype = JN_F32; a.itab = ident; a.w = cw.w_dev; a.bias = nullptr;
         a.out = gptr(op.in); a.out_ld = ld(op.in); a.out_dtype = JN_F32; a.bf16_mfma = net.act_dtype == JN_BF16;
         a.N = N; a.H = op.out.H; a.W = op.out.W; a.OH = op.out.H; a.OW = op.out.W;
         a.cin = cw.cout; a.cout = cw.cin; a.stride = 1; a.act = ACT_NONE;
         a.accumulate = op.acc_in ? 1 : 0; a.w_transposed = 1;
         a.n_slots = nsl; a.in_slot_stride = sb.grad; a.out_slot_stride = sb.grad; a.tab_slot_stride = 0;
         launch_pw(a, s);
-        launch_pw_bwd_weight(gptr(op.out), ld(op.out), ptr(op.in), net.act_dtype, ld(op.in), tab(op.in), gw, ctx->wpart, M, cw.cout,
+        launch_pw_bwd_weight(gp_out, gld_out, ptr(op.in), net.act_dtype, ld(op.in), tab(op.in), gw, ctx->wpart, M, cw.cout,
                              cw.cin, s, sb);
       } else if (op.kind == OP_DW) {
-        launch_dw_bwd_data(gptr(op.out), ld(op.out), cw.w_dev, gptr(op.in), ld(op.in), cw.cout, op.in.H, op.in.W, op.out.H,
+        launch_dw_bwd_data(gp_out, gld_out, cw.w_dev, gptr(op.in), ld(op.in), cw.cout, op.in.H, op.in.W, op.out.H,
                            op.out.W, N, op.stride, op.acc_in ? 1 : 0, s, sb);
-        launch_dw_bwd_weight(gptr(op.out), ld(op.out), ptr(op.in), net.act_dtype, ld(op.in), tab(op.in), gw, ctx->wpart, cw.cout, op.in.H,
+        launch_dw_bwd_weight(gp_out, gld_out, ptr(op.in), net.act_dtype, ld(op.in), tab(op.in), gw, ctx->wpart, cw.cout, op.in.H,
                              op.in.W, op.out.H, op.out.W, N, op.stride, s, sb);
       } else if (op.kind == OP_STEM) {
         StemArgs a{ss.src, ss.positions, ss.pos_stride, ss.sample_stride, ss.chan_stride, ss.row_stride, net.P, N, cw.cout,
                    cw.w_dev, nullptr, 0, JN_F32, nullptr, 0, nullptr, 0};
-        launch_stem_bwd_weight(a, gptr(op.out), ld(op.out), gw, ctx->wpart, s, sb);
+        launch_stem_bwd_weight(a, gp_out, gld_out, gw, ctx->wpart, s, sb);
       } else if (op.kind == OP_CONV3) {
         // dense 3x3 (non-depthwise patch encoders, e.g. yolox-s): stride 1 = the forward kernel over g_z with
         // mirrored taps and the transposed weight; stride 2 = one MFMA tile loop per input-pixel parity class
         int rc3 = 0;
         if (op.stride == 1) {
           ConvArgs a{};
-          a.in = gptr(op.out); a.in_ld = ld(op.out); a.in_dtype = JN_F32; a.itab = ident; a.w = cw.w_dev; a.bias = nullptr;
+          a.in = gp_out; a.in_ld = gld_out; a.in_dtype = JN_F32; a.itab = ident; a.w = cw.w_dev; a.bias = nullptr;
           a.out = gptr(op.in); a.out_ld = ld(op.in); a.out_dtype = JN_F32;
           a.N = N; a.H = op.out.H; a.W = op.out.W; a.OH = op.in.H; a.OW = op.in.W;
           a.cin = cw.cout; a.cout = cw.cin; a.stride = 1; a.act = ACT_NONE;
@@ -878,11 +884,11 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
           a.n_slots = nsl; a.in_slot_stride = sb.grad; a.out_slot_stride = sb.grad;
           rc3 = launch_conv3(a, s);
         } else {
-          rc3 = launch_conv3_bwd_data_s2(gptr(op.out), ld(op.out), cw.w_dev, gptr(op.in), ld(op.in), op.in.H, op.in.W, op.out.H,
+          rc3 = launch_conv3_bwd_data_s2(gp_out, gld_out, cw.w_dev, gptr(op.in), ld(op.in), op.in.H, op.in.W, op.out.H,
                                          op.out.W, cw.cout, cw.cin, N, op.acc_in ? 1 : 0, s, sb);
         }
         JN_CHECK(rc3 == 0, JN_ESTATE, "backward of dense 3x3 conv %s: unsupported shape", op.name.c_str());
-        launch_conv3_bwd_weight(gptr(op.out), ld(op.out), ptr(op.in), net.act_dtype, ld(op.in), tab(op.in), gw, op.in.H, op.in.W,
+        launch_conv3_bwd_weight(gp_out, gld_out, ptr(op.in), net.act_dtype, ld(op.in), tab(op.in), gw, op.in.H, op.in.W,
                                 op.out.H, op.out.W, cw.cout, cw.cin, N, op.stride, s, sb);
       } else {
         set_error("backward of op %s is not implemented", op.name.c_str());
@@ -893,7 +899,8 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
     switch (op.kind) {
       case OP_ADDACT: {
         const long long M = (long long)N * op.out.H * op.out.W;
-        launch_grad_copy(gptr(op.out), ld(op.out), gptr(op.in), ld(op.in), op.out.C, M, op.acc_in ? 1 : 0, s, sb);
+        if (op.acc_in) launch_grad_copy(gptr(op.out), ld(op.out), gptr(op.in), ld(op.in), op.out.C, M, 1, s, sb);
+        else g_alias[op.in.buf] = std::make_pair(op.in.coff, op.out);       // sole consumer: no copy, see above
         launch_grad_copy(gptr(op.out), ld(op.out), gptr(op.res), ld(op.res), op.out.C, M, op.acc_res ? 1 : 0, s, sb);
         break;
       }

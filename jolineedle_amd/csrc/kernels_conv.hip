@@ -250,9 +250,9 @@ __global__ __launch_bounds__(256) void dw3x3_kernel(
 // (halo included) of CB channels once, so silu(bn(z)) is evaluated ~1.3x per input element instead of once per
 // tap (4.5x - 6.75x in the strip kernel above, which made the layer ALU-bound); taps then come from LDS.
 // Tile = 8 x 16 output pixels; thread = (channel quad, column, row group), sliding down its rows.
-constexpr int DW_TH = 8, DW_TW = 16;
+constexpr int DW_TW = 16;
 
-template <int S, int CB, typename AT>
+template <int S, int CB, int DW_TH, typename AT>
 __global__ __launch_bounds__(256) void dw3x3_lds_kernel(
     const AT* __restrict__ in, int in_ld, ChanTab it, const float* __restrict__ w, AT* __restrict__ out,
     int out_ld, int C, int H, int W, int OH, int OW, int tiles_x, int tiles_y, double* __restrict__ stats,
@@ -347,13 +347,13 @@ __global__ __launch_bounds__(256) void dw3x3_lds_kernel(
   }
 }
 
-template <int S, int CB, typename AT>
+template <int S, int CB, int DW_TH, typename AT>
 static void launch_dw_lds(const ConvArgs& a, hipStream_t s) {
   constexpr int IH = S * (DW_TH - 1) + 3, IW = S * (DW_TW - 1) + 3;
   const int tiles_x = (a.OW + DW_TW - 1) / DW_TW, tiles_y = (a.OH + DW_TH - 1) / DW_TH;
   const size_t smem = ((size_t)IH * IW * (S == 1 ? CB : CB + 4) + 16 * 2 * CB) * sizeof(float);
   dim3 grid((unsigned)(tiles_x * tiles_y * (a.cin / CB)), (unsigned)a.N);
-  hipLaunchKernelGGL((dw3x3_lds_kernel<S, CB, AT>), grid, dim3(256), smem, s, (const AT*)a.in, a.in_ld, a.itab, a.w,
+  hipLaunchKernelGGL((dw3x3_lds_kernel<S, CB, DW_TH, AT>), grid, dim3(256), smem, s, (const AT*)a.in, a.in_ld, a.itab, a.w,
                      (AT*)a.out, a.out_ld, a.cin, a.H, a.W, a.OH, a.OW, tiles_x, tiles_y, a.stats, a.stats_rep_stride,
                      a.skip_flag, a.skip_when);
 }
@@ -362,10 +362,11 @@ int launch_dw(const ConvArgs& a, hipStream_t s) {
   if (a.cin % 16 == 0 && a.N <= 65535) {
     const bool bf = a.in_dtype == JN_BF16;
     if (a.stride == 1) {
-      if (a.cin % 32 == 0) { if (bf) launch_dw_lds<1, 32, bf16_t>(a, s); else launch_dw_lds<1, 32, float>(a, s); }
-      else { if (bf) launch_dw_lds<1, 16, bf16_t>(a, s); else launch_dw_lds<1, 16, float>(a, s); }
+      if (a.cin % 32 == 0) { if (bf) launch_dw_lds<1, 32, 8, bf16_t>(a, s); else launch_dw_lds<1, 32, 8, float>(a, s); }
+      else { if (bf) launch_dw_lds<1, 16, 8, bf16_t>(a, s); else launch_dw_lds<1, 16, 8, float>(a, s); }
     } else {
-      if (bf) launch_dw_lds<2, 16, bf16_t>(a, s); else launch_dw_lds<2, 16, float>(a, s);
+      // stride 2: 4-row tiles halve the LDS halo tile (9 x 33 pixels): twice the workgroups per CU
+      if (bf) launch_dw_lds<2, 16, 4, bf16_t>(a, s); else launch_dw_lds<2, 16, 4, float>(a, s);
     }
     return 0;
   }
