@@ -344,6 +344,8 @@ int jn_create(const jn_config* cfg, jn_ctx** out) {
   if (!cfg->no_patch_emb) {
     const Net& enc = ctx->nets[ctx->enc_net];
     ctx->efpn_cin = enc.fpn[2].C; ctx->efpn_h = enc.fpn[2].H; ctx->efpn_w = enc.fpn[2].W;
+    // split-K slices of embed_fpn.3: ~192 inputs each, 8..64 slices (their partials are summed by the consumer)
+    ctx->KS = std::max(8, std::min(64, (ctx->efpn_h * ctx->efpn_w * C + 191) / 192));
     add_param(P, "embed_fpn.0.weight", {C, ctx->efpn_cin, 1, 1}, 0, false, true);
     add_param(P, "embed_fpn.3.weight", {C, (int64_t)ctx->efpn_h * ctx->efpn_w * C}, 0, false, true);
     add_param(P, "embed_fpn.3.bias", {C}, 0, false, true);
