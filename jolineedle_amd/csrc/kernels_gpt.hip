@@ -26,15 +26,52 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// y[n] = b[n] + sum_k x[k] * wt[k*N + n]   (x in LDS, wt transposed in global/L2)
+// y[n] = b[n] + sum_k x[k] * wt[k*N + n]   (x in LDS, wt transposed in global/L2).
+// All 256 threads work whatever N is: thread = (column quad, K slice); each slice walks K with stride `slices`
+// (independent dwordx4 loads), partials meet in LDS scratch `part` (>= 1024 floats).  With one thread per column a
+// 192 -> 48 layer was 192 dependent loads on 48 threads: the whole step was a chain of L2 latencies.
 __device__ __forceinline__ void linear_t(float* y, const float* x, const float* __restrict__ wt,
-                                         const float* __restrict__ b, int K, int N) {
-  for (int n = threadIdx.x; n < N; n += GPT_THREADS) {
-    float acc = b ? b[n] : 0.0f;
-    const float* wp = wt + n;
+                                         const float* __restrict__ b, int K, int N, float* part) {
+  using f4 = __attribute__((ext_vector_type(4))) float;
+  const int tid = threadIdx.x;
+  if ((N & 3) == 0 && N <= 4 * GPT_THREADS) {
+    const int nq = N >> 2, slices = GPT_THREADS / nq;
+    const int q = tid % nq, sl = tid / nq;
+    if (sl < slices) {
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* wp = wt + 4 * q;
 #pragma unroll 4
-    for (int k = 0; k < K; ++k) acc = fmaf(x[k], wp[(long long)k * N], acc);
-    y[n] = acc;
+      for (int k = sl; k < K; k += slices) acc += x[k] * *reinterpret_cast<const f4*>(wp + (long long)k * N);
+      *reinterpret_cast<f4*>(part + sl * N + 4 * q) = acc;
+    }
+    __syncthreads();
+    for (int n = tid; n < N; n += GPT_THREADS) {
+      float acc = b ? b[n] : 0.0f;
+      for (int i = 0; i < slices; ++i) acc += part[i * N + n];
+      y[n] = acc;
+    }
+  } else if (N <= GPT_THREADS) {
+    const int slices = GPT_THREADS / N;
+    const int n = tid % N, sl = tid / N;
+    if (sl < slices) {
+      float acc = 0.0f;
+      for (int k = sl; k < K; k += slices) acc = fmaf(x[k], wt[(long long)k * N + n], acc);
+      part[sl * N + n] = acc;
+    }
+    __syncthreads();
+    if (tid < N) {
+      float acc = b ? b[tid] : 0.0f;
+      for (int i = 0; i < slices; ++i) acc += part[i * N + tid];
+      y[tid] = acc;
+    }
+  } else {
+    for (int n = tid; n < N; n += GPT_THREADS) {
+      float acc = b ? b[n] : 0.0f;
+      const float* wp = wt + n;
+#pragma unroll 4
+      for (int k = 0; k < K; ++k) acc = fmaf(x[k], wp[(long long)k * N], acc);
+      y[n] = acc;
+    }
   }
 }
 
@@ -62,7 +99,7 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
     if (blockIdx.x == 0 && threadIdx.x == 0) a.n_done[a.step + 1] = a.skip_when;
     return;
   }
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int C = a.C, tid = threadIdx.x, b = blockIdx.x;
   float* x = sm;                 // [C]   residual stream
   float* h = x + C;              // [C]   LN output / attention output
@@ -71,6 +108,7 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
   float* att = mlp + 4 * C;      // [n_head * Tmax]
   float* red = att + a.n_head * a.Tmax;   // [4]
   float* lg = red + 4;           // [16]  logits
+  float* part = sm + ((9 * C + a.n_head * a.Tmax + 4 + 16 + 3) & ~3);   // [1024] split-K partials of linear_t (16-B aligned)
 
   const int t = a.step;
   const int hs = C / a.n_head;
@@ -127,7 +165,7 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
       }
       __syncthreads();
       if (a.concat_emb) {
-        linear_t(x, parts, a.proj_wt, a.proj_b, p * C, C);
+        linear_t(x, parts, a.proj_wt, a.proj_b, p * C, C, part);
       } else {
         for (int i = tid; i < C; i += GPT_THREADS) {
           float s = 0.0f;
@@ -147,7 +185,7 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
       float* kc = a.kcache + (((long long)l * a.B + b) * a.Tmax) * C;
       float* vc = a.vcache + (((long long)l * a.B + b) * a.Tmax) * C;
       layer_norm(h, x, L.ln1_w, L.ln1_b, C, red);
-      linear_t(qkv, h, L.qkv_wt, L.qkv_b, C, 3 * C);
+      linear_t(qkv, h, L.qkv_wt, L.qkv_b, C, 3 * C, part);
       __syncthreads();
       for (int i = tid; i < C; i += GPT_THREADS) { kc[len * C + i] = qkv[C + i]; vc[len * C + i] = qkv[2 * C + i]; }
       __syncthreads();   // own-block global writes are visible to the block after the barrier
@@ -181,16 +219,16 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
         h[i] = acc;
       }
       __syncthreads();
-      linear_t(qkv, h, L.proj_wt, L.proj_b, C, C);      // qkv[0:C] reused as scratch
+      linear_t(qkv, h, L.proj_wt, L.proj_b, C, C, part);      // qkv[0:C] reused as scratch
       __syncthreads();
       for (int i = tid; i < C; i += GPT_THREADS) x[i] += qkv[i];
       __syncthreads();
       layer_norm(h, x, L.ln2_w, L.ln2_b, C, red);
-      linear_t(mlp, h, L.fc_wt, L.fc_b, C, 4 * C);
+      linear_t(mlp, h, L.fc_wt, L.fc_b, C, 4 * C, part);
       __syncthreads();
       for (int i = tid; i < 4 * C; i += GPT_THREADS) mlp[i] = gelu_tanh(mlp[i]);
       __syncthreads();
-      linear_t(qkv, mlp, L.fc2_wt, L.fc2_b, 4 * C, C);
+      linear_t(qkv, mlp, L.fc2_wt, L.fc2_b, 4 * C, C, part);
       __syncthreads();
       for (int i = tid; i < C; i += GPT_THREADS) x[i] += qkv[i];
       __syncthreads();
@@ -204,7 +242,7 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
   }
   // ---------------- head on the newest token ----------------
   layer_norm(h, x, a.lnf_w, a.lnf_b, C, red);
-  linear_t(lg, h, a.head_wt, nullptr, C, a.nA);
+  linear_t(lg, h, a.head_wt, nullptr, C, a.nA, part);
   __syncthreads();
 
   if (a.src_mode != GPT_SRC_ENV) {
@@ -258,7 +296,7 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
 }
 
 int launch_gpt_step(const GptStepArgs& a, hipStream_t s) {
-  const size_t smem = (size_t)(9 * a.C + a.n_head * a.Tmax + 4 + 16) * sizeof(float);
+  const size_t smem = (size_t)(9 * a.C + a.n_head * a.Tmax + 4 + 16 + 4 + 1024) * sizeof(float);
   hipLaunchKernelGGL(gpt_step_kernel, dim3(a.B), dim3(GPT_THREADS), smem, s, a);
   return 0;
 }
