@@ -884,39 +884,65 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
   f32x4 acc[7];
 #pragma unroll
   for (int t = 0; t < 7; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // persistent over (image, tile): the partial dW stays in registers, ONE set of atomics per workgroup
-  for (int tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+  // persistent over (image, tile): the partial dW stays in registers, ONE set of atomics per workgroup; the next
+  // tile's image values and gradients are fetched into registers while the MFMAs of the current one run
+  constexpr int NI = (3 * SB_IH * SB_IW + 255) / 256, NG = SB_TY * SB_TX * 4 / 256;
+  float pim[NI];
+  f32x4 pg[NG], pz[NG];
+  auto fetch = [&](int tl) {
     const int n = tl / (tiles_x * tiles_y), tr = tl % (tiles_x * tiles_y);
     const int oy0 = (tr / tiles_x) * SB_TY, ox0 = (tr % tiles_x) * SB_TX;
     const float* base = src + (long long)n * sample_stride;
     if (pos) base += pos[(long long)pos_stride * n] * (long long)P * row_stride + pos[(long long)pos_stride * n + 1] * (long long)P;
-    __syncthreads();
-    for (int i = tid; i < 3 * SB_IH * SB_IW; i += 256) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int i = tid + 256 * j;
       const int c = i / (SB_IH * SB_IW), r = (i / SB_IW) % SB_IH, q = i % SB_IW;
       const int iy = 2 * oy0 - 2 + r, ix = 2 * ox0 - 2 + q;
       float v = 0.0f;
-      if (iy >= 0 && iy < P && ix >= 0 && ix < P) v = base[c * chan_stride + (long long)iy * row_stride + ix];
-      tile[i] = v;
+      if (i < 3 * SB_IH * SB_IW && iy >= 0 && iy < P && ix >= 0 && ix < P) v = base[c * chan_stride + (long long)iy * row_stride + ix];
+      pim[j] = v;
     }
-    for (int i = tid; i < SB_TY * SB_TX * 4; i += 256) {
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int i = tid + 256 * j;
       const int p = i >> 2, q = i & 3, ty = p / SB_TX, tx = p % SB_TX;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      pg[j] = f32x4{0.f, 0.f, 0.f, 0.f}; pz[j] = pg[j];
       if (oy0 + ty < OH && ox0 + tx < OH) {
         const long long pix = ((long long)n * OH + oy0 + ty) * OH + ox0 + tx;
-        v = *reinterpret_cast<const f32x4*>(gz + pix * g_ld + og * 16 + 4 * q);
-        if (z) {
-          const f32x4 zv = *reinterpret_cast<const f32x4*>(z + pix * z_ld + og * 16 + 4 * q);
+        pg[j] = *reinterpret_cast<const f32x4*>(gz + pix * g_ld + og * 16 + 4 * q);
+        if (z) pz[j] = *reinterpret_cast<const f32x4*>(z + pix * z_ld + og * 16 + 4 * q);
+      }
+    }
+  };
+  int tl = blockIdx.x;
+  if (tl < n_tiles) fetch(tl);
+  for (; tl < n_tiles; tl += gridDim.x) {
+    __syncthreads();
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float zh = (zv[k] - o_mean[k]) * o_istd[k];
-            const float gy = v[k] * dsilu_(fmaf(zv[k], o_sc[k], o_sh[k]));
-            v[k] = o_k[k] * (gy - o_c1[k] - zh * o_c2[k]);
-          }
+    for (int j = 0; j < NI; ++j) {
+      const int i = tid + 256 * j;
+      if (i < 3 * SB_IH * SB_IW) tile[i] = pim[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int i = tid + 256 * j;
+      f32x4 v = pg[j];
+      if (z) {                                   // pixels outside the map carry g = 0 -> gy = 0, but c1 must not leak in
+        const int p = i >> 2, ty = p / SB_TX, tx = p % SB_TX;
+        const int tr = tl % (tiles_x * tiles_y);
+        const bool inside = (tr / tiles_x) * SB_TY + ty < OH && (tr % tiles_x) * SB_TX + tx < OH;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float zh = (pz[j][k] - o_mean[k]) * o_istd[k];
+          const float gy = v[k] * dsilu_(fmaf(pz[j][k], o_sc[k], o_sh[k]));
+          v[k] = inside ? o_k[k] * (gy - o_c1[k] - zh * o_c2[k]) : 0.0f;
         }
       }
-      *reinterpret_cast<f32x4*>(&Gz[p * 16 + 4 * q]) = v;
+      *reinterpret_cast<f32x4*>(&Gz[i * 4]) = v;
     }
     __syncthreads();
+    if (tl + (int)gridDim.x < n_tiles) fetch(tl + gridDim.x);
     for (int st = 0; st < SB_TY * SB_TX / 16; ++st) {
       const int p = wave * (SB_TY * SB_TX / 4) + 4 * st + g;   // pixel of this k-step for this lane group
       const int ty = p / SB_TX, tx = p % SB_TX;
