@@ -294,10 +294,111 @@ static void launch_pw_bw_t(const float* gz, int g_ld, const void* x, int x_dtype
                        it, gw, rep, M, N, K, rows_per_block, chunks_per_slot, gz_slot, x_slot, tab_slot);
 }
 
+// Wide layers (N, K >= 128): workgroup tile = 128 x 128 outputs, wave w owns the 64 x 64 quadrant (w & 1, w >> 1) and
+// contracts ALL 64 rows of a stage itself (no cross-wave sum).  Against the 64 x 64 tiles above every input row is
+// re-read half as often: (N/128 + K/128) instead of (N/64 + K/64) passes over g_z / x.
+template <typename XT>
+__global__ __launch_bounds__(256) void pw_bwd_weight_wide_kernel(const float* __restrict__ gz, int g_ld,
+                                                                 const XT* __restrict__ x, int x_ld, ChanTab it,
+                                                                 float* __restrict__ gw, long long M, int N, int K,
+                                                                 int rows_per_block, int chunks_per_slot,
+                                                                 long long gz_slot, long long x_slot, long long tab_slot) {
+  constexpr int LD = 128 + 4;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Gs = sm;                 // [64][LD]
+  float* As = sm + 64 * LD;       // [64][LD]
+  const int slot = blockIdx.x / chunks_per_slot, chunk = blockIdx.x - slot * chunks_per_slot;
+  gz += slot * gz_slot; x += slot * x_slot;
+  it.sc += slot * tab_slot; it.sh += slot * tab_slot; it.fl += slot * tab_slot;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.y * 128, k0 = blockIdx.z * 128;
+  const int wn = (wave & 1) * 64, wk = (wave >> 1) * 64;
+  const long long r0 = (long long)chunk * rows_per_block;
+  const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the channel quad of a thread is fixed (256 % 32 == 0)
+  const int q = tid & 31;
+  f32x4 i_sc = {1.f, 1.f, 1.f, 1.f}, i_sh = {0.f, 0.f, 0.f, 0.f}, i_fl = {0.f, 0.f, 0.f, 0.f};
+  if (k0 + 4 * q < K) {
+    i_sc = *reinterpret_cast<const f32x4*>(it.sc + k0 + 4 * q); i_sh = *reinterpret_cast<const f32x4*>(it.sh + k0 + 4 * q);
+    i_fl = *reinterpret_cast<const f32x4*>(it.fl + k0 + 4 * q);
+  }
+  for (long long rb = r0; rb < r1; rb += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = (tid >> 5) + 8 * j;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f}, u = {0.f, 0.f, 0.f, 0.f};
+      if (rb + r < r1) {
+        if (n0 + 4 * q < N) v = *reinterpret_cast<const f32x4*>(gz + (rb + r) * g_ld + n0 + 4 * q);
+        if (k0 + 4 * q < K) u = tf4_(ld4(x + (rb + r) * x_ld + k0 + 4 * q), i_sc, i_sh, i_fl);
+      }
+      *reinterpret_cast<f32x4*>(Gs + r * LD + 4 * q) = v;
+      *reinterpret_cast<f32x4*>(As + r * LD + 4 * q) = u;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int st = 0; st < 16; ++st) {
+      const int row = 4 * st + g;
+      float av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) av[a] = Gs[row * LD + wn + 16 * a + lm];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bv[b] = As[row * LD + wk + 16 * b + lm];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn + 16 * a + 4 * g + r, k = k0 + wk + 16 * b + lm;
+        if (n < N && k < K) atomicAdd(&gw[(long long)n * K + k], acc[a][b][r]);
+      }
+}
+
+static void launch_pw_bwd_weight_wide(const float* gz, int g_ld, const void* x, int x_dtype, int x_ld, ChanTab it, float* gw,
+                                      long long M, int N, int K, hipStream_t s, const SlotBatch& sb, long long gz_slot) {
+  const long long tiles = (long long)((N + 127) / 128) * ((K + 127) / 128);
+  long long rpb = (M * sb.n * tiles / 1024 + 63) / 64 * 64;     // ~1024 workgroups (2 fit per CU)
+  if (rpb < 256) rpb = 256;
+  if (rpb > 8192) rpb = 8192;
+  const int chunks_per_slot = (int)((M + rpb - 1) / rpb);
+  dim3 grid((unsigned)(chunks_per_slot * sb.n), (N + 127) / 128, (K + 127) / 128);
+  const size_t smem = (size_t)2 * 64 * (128 + 4) * sizeof(float);
+#define JN_WW(T_)                                                                                                     \
+  {                                                                                                                   \
+    static bool raised = false;                                                                                       \
+    if (!raised) {                                                                                                    \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_weight_wide_kernel<T_>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                               \
+      raised = true;                                                                                                  \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((pw_bwd_weight_wide_kernel<T_>), grid, dim3(256), smem, s, gz, g_ld, (const T_*)x, x_ld, it, gw, M, N, \
+                       K, (int)rpb, chunks_per_slot, gz_slot, sb.act, sb.tab);                                        \
+  }
+  if (x_dtype == JN_BF16) JN_WW(bf16_t) else JN_WW(float)
+#undef JN_WW
+}
+
 int launch_pw_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, int x_ld, ChanTab it, float* gw_final,
                          float* wpart, long long M, int N, int K, hipStream_t s, const SlotBatch& sb,
                          long long gz_slot_stride) {
   const long long gz_slot = gz_slot_stride >= 0 ? gz_slot_stride : sb.grad;
+  if (N >= 128 && K >= 128 && N % 4 == 0 && K % 4 == 0) {
+    launch_pw_bwd_weight_wide(gz, g_ld, x, x_dtype, x_ld, it, gw_final, M, N, K, s, sb, gz_slot);
+    return 0;
+  }
   const int rep = (wpart && N * K <= JN_WPART_MAX) ? 1 : 0;
   float* gw = rep ? wpart : gw_final;
   const int tn = (N + 15) / 16, tk = (K + 15) / 16;
