@@ -39,8 +39,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s mea
 S_640_GMAC_PER_PATCH = 8.113e9
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
 # HBM traffic of ONE forward conv-stack pass at B=64, 448 px from the PMC counters (separate --pmc FETCH_SIZE and
-# --pmc WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM): profiles/r01_c_pmc_conv_stack_traffic.txt
-PMC_TRAFFIC_BYTES_B64_448 = 5.552e9
+# --pmc WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM): profiles/r01_e_pmc_conv_stack_traffic.txt
+PMC_TRAFFIC_BYTES_B64_448 = 5.577e9
 
 
 def synth_inputs(B, G, P, seed, device):
