@@ -14,6 +14,8 @@ from .env import NeedleGeneralEnv  # noqa: F401
 from .yolox import NeedleYOLOX  # noqa: F401
 from .reinforce import ReinforceTrainer  # noqa: F401
 from .supervised import SupervisedTrainer  # noqa: F401
+from .detection import (patch_bboxes2full_image, merge_boxes, merge_boxes_batched,  # noqa: F401
+                        compute_detection_metrics, detection_targets)
 
 __all__ = ["GPT", "NeedleYOLOX", "NeedleGeneralEnv", "ReinforceTrainer", "SupervisedTrainer", "Action", "ACTION_DELTAS",
            "ActionInfo", "get_actions_info", "CfgNode", "get_args", "args_to_config", "load_library"]

@@ -131,6 +131,34 @@ class NeedleGeneralEnv:
         tot[tot == 0] = 1
         return count / tot
 
+    # ---- detection bookkeeping (src/env/general_env.py:381-573) ----------------------------------------
+    def parse_bboxes(self, bboxes: Tensor = None):
+        """Ground-truth boxes split over the patch grid: ([B, Gy, Gx, nb, 4] patch-local xyxy, [B, Gy, Gx, nb] masks)."""
+        from .detection import split_bboxes_over_patches
+        return split_bboxes_over_patches(self.bboxes if bboxes is None else bboxes, self.n_vertical_patches,
+                                         self.n_horizontal_patches, self.patch_size)
+
+    def get_detection_targets(self):
+        from .detection import detection_targets
+        return detection_targets(self.bboxes, self.n_vertical_patches, self.n_horizontal_patches, self.patch_size)
+
+    @torch.no_grad()
+    def get_detection_batch(self, sample_neg: int = 1, generator: torch.Generator = None):
+        """Patches to train the detector on: every patch holding (a piece of) a box plus `sample_neg` random empty
+        patches per image; returns (patches [n, 3, P, P], bboxes [n, nb, 1 + 4]) like general_env.py:503-544."""
+        boxes, masks = self.parse_bboxes()
+        any_box = masks.any(-1).cpu()
+        P = self.patch_size
+        patches, all_boxes = [], []
+        for i in range(self.batch_size):
+            pos = torch.nonzero(any_box[i])
+            neg = torch.nonzero(~any_box[i])
+            neg = neg[torch.randperm(len(neg), generator=generator)[:sample_neg]]
+            for y, x in torch.cat((pos, neg)).tolist():
+                patches.append(self._images[i, :, y * P:(y + 1) * P, x * P:(x + 1) * P])
+                all_boxes.append(torch.nn.functional.pad(boxes[i, y, x], (1, 0)))
+        return torch.stack(patches), torch.stack(all_boxes).to(self.device)
+
     @property
     def prop_bboxes_found(self) -> Tensor:
         return (self.prop_patches_found > 0).to(torch.float32)

@@ -209,3 +209,34 @@ class ReinforceTrainer:
                 metrics["stop_used"] = env.terminated[0].to(torch.float32)
                 metrics["stop_misused"] = (env.terminated[0] and env.prop_patches_found[0] < 1).to(torch.float32)
         return metrics
+
+    @torch.no_grad()
+    def eval_on_batch(self, env: NeedleGeneralEnv, do_detection: bool = None, merge_bboxes: bool = None) -> Dict[str, torch.Tensor]:
+        """``eval_on_sample`` of the reference (src/reinforce.py:424-497) without the plotting: greedy rollout,
+        rollout metrics incl. the env's found-ratios, and — with detection — mAP-50 of the boxes found along the
+        trajectories (moved to full-image coordinates, optionally merged) plus the detector's mAP on every patch that
+        holds a box (`yolo_map`).  The reference evaluates one image at a time; any batch size works here (the
+        per-image metrics it reads from index 0 stay index 0)."""
+        from .detection import (compute_detection_metrics, merge_boxes_batched, patch_bboxes2full_image)
+        cfg = self.config
+        if do_detection is None:
+            do_detection = bool(getattr(cfg, "detection_enabled", False))
+        if merge_bboxes is None:
+            merge_bboxes = bool(getattr(cfg, "merge_bboxes", False))
+        ro = self.rollout(env, sample_actions=False, do_detection=do_detection)
+        metrics = self.compute_metrics(ro, env)
+        if do_detection:
+            targets = env.get_detection_targets()
+            offsets = ro["positions"][:, :, [1, 0]] * self.patch_size        # (y, x) grid -> (x, y) pixels
+            preds = patch_bboxes2full_image(ro["bboxes"], offsets, ro["masks"])
+            if merge_bboxes:
+                preds = merge_boxes_batched(preds, target=False)
+                targets = merge_boxes_batched(targets, target=True)
+            metrics.update(compute_detection_metrics(preds, targets))
+            patches, patch_targets = env.get_detection_batch(sample_neg=0)
+            pred_bboxes, _, yolo_losses = self.yolox_model()(patches)
+            for k, v in compute_detection_metrics(pred_bboxes, list(patch_targets)).items():
+                metrics["yolo_" + k] = v
+            for k, v in yolo_losses.items():
+                metrics["yolo_" + k] = v
+        return metrics

@@ -653,6 +653,47 @@ def test_rollout_with_detection_vs_oracle():
                 _same_boxes(g.cpu(), r, 1e-3 * P)
 
 
+def test_eval_on_batch_detection_metrics_vs_oracle():
+    """eval_on_sample of the reference (src/reinforce.py:424-497): greedy rollout with detection, boxes moved to
+    full-image coordinates, mAP-50 against the split ground-truth boxes — the GPU rollout's metric equals the one
+    computed from the CPU oracle's rollout; the detection batch is a bit-exact gather."""
+    from oracle import env_ref, rollout_ref
+    from jolineedle_amd import detection
+    P, Tn, B = 64, 3, 2
+    images, bboxes, start = synth_batch(B, 3, 3, P, seed=8)
+    images = _blocky_images(B, 3 * P, 8)
+    calib = images[:, :, :P, :P].contiguous()
+    _, oracle0 = _detector_pair(P, 0.5, max_batch=B, calib=calib)
+    with torch.no_grad():
+        raw = oracle0.yolox.head(oracle0.yolox.backbone(images[:, :, :P, :P]))
+    thr = _gap_threshold(raw[..., 4] * raw[..., 5], 30)
+    product, oracle = _detector_pair(P, thr, max_batch=8, calib=calib)
+    env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True)
+    env.reset(start)
+    tr = ja.ReinforceTrainer(_cfg(T=Tn), product)
+    ro0 = tr.rollout(env, do_detection=True, sample_actions=False, start_positions=start)
+    m = tr.eval_on_batch(ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True), do_detection=True, merge_bboxes=True)
+    for k in ("map", "yolo_map", "loss", "prop_patches_found", "prop_bbox_found"):
+        assert k in m, k
+    assert 0.0 <= float(m["map"]) <= 1.0 and 0.0 <= float(m["yolo_map"]) <= 1.0
+    # the same bookkeeping applied to the oracle's rollout (same greedy trajectory as ro0) gives the same mAP
+    with torch.no_grad():
+        ref = rollout_ref.rollout(oracle, env_ref.EnvRef(images, bboxes, P, Tn, 1, True), do_detection=True,
+                                  sample_actions=False, start_positions=ro0["positions"][:, 0].cpu())
+    if torch.equal(ref["positions"], ro0["positions"].cpu()):
+        offs = ref["positions"][:, :, [1, 0]] * P
+        preds = detection.merge_boxes_batched(detection.patch_bboxes2full_image(ref["bboxes"], offs, ref["masks"]))
+        tg = detection.merge_boxes_batched(detection.detection_targets(bboxes, 3, 3, P), target=True)
+        ref_map = float(detection.compute_detection_metrics(preds, tg)["map"])
+        assert abs(ref_map - float(ja.ReinforceTrainer(_cfg(T=Tn), product).eval_on_batch(
+            ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True), True, True)["map"])) < 0.05
+    pats, tgt = env.get_detection_batch(sample_neg=1, generator=torch.Generator().manual_seed(1))
+    assert pats.shape[1:] == (3, P, P) and tgt.shape[0] == pats.shape[0] and tgt.shape[2] == 5
+    loc, msk = env.parse_bboxes()
+    ys, xs = torch.nonzero(msk[0].any(-1).cpu())[0].tolist()
+    assert torch.equal(pats[0].cpu(), images[0, :, ys * P:(ys + 1) * P, xs * P:(xs + 1) * P])
+
+
 # --------------------------------------------------------------------------------------
 # supervised teacher-forced step (SURVEY.md §8 a15, BASELINE configs 1-2)
 # --------------------------------------------------------------------------------------

@@ -5,6 +5,7 @@ import re
 from pathlib import Path
 
 import pytest
+import numpy as np
 import torch
 
 import jolineedle_amd as ja
@@ -111,3 +112,41 @@ def test_action_vocabulary_and_args(golden):
     t, m = ja.args_to_config(args)
     assert (t.max_seq_len, t.stop_enabled, t.patch_size, m.pos_emb_size, m.block_size) == (8, True, 448, 25, 8)
     assert m.gpt_backbone == "yolox-nano" and m.concat_emb and m.decoder_pos_encoding
+
+
+# --------------------------------------------------------------------------------------
+# detection bookkeeping, pinned by the known answers of the reference's tests/test_map.py (G7)
+# --------------------------------------------------------------------------------------
+def test_detection_targets_and_patch_to_full_image_known_answers(golden):
+    g = golden("g7_known_answers.npz")
+    tg = ja.detection_targets(torch.from_numpy(g["targets_bboxes"]), 1792 // 448, 2240 // 448, 448)
+    assert len(tg) == 1 and np.array_equal(tg[0].numpy(), g["targets_expected"])
+    outs = [[torch.from_numpy(g["p2f_box0"]), torch.from_numpy(g["p2f_box1"]), None, torch.from_numpy(g["p2f_box3"])]]
+    res = ja.patch_bboxes2full_image(outs, torch.from_numpy(g["p2f_offsets"]), torch.from_numpy(g["p2f_masks"]))
+    assert len(res) == 1 and np.array_equal(res[0].numpy(), g["p2f_expected"])
+    assert ja.patch_bboxes2full_image([[None, None]], torch.zeros((1, 2, 2), dtype=torch.long)) == [None]
+
+
+def test_map50_known_answers(golden):
+    """tests/test_map.py:36-66 of the reference: no prediction -> 0, perfect -> 1, one of five pieces missed -> 0.8."""
+    g = golden("g7_known_answers.npz")
+    targets = [torch.from_numpy(g["targets_expected"])]
+    assert float(ja.compute_detection_metrics([None], targets)["map"]) == 0.0
+    p2 = torch.tensor([[410, 410, 447, 446, 0.5, 1], [448, 410, 500, 447, 0.9, 1], [410, 448, 447, 500, 0.8, 1],
+                       [448, 448, 500, 500, 0.7, 1], [1500, 1500, 1600, 1600, 0.6, 1]])
+    assert float(ja.compute_detection_metrics([p2], targets)["map"]) == pytest.approx(1.0)
+    p3 = p2[[0, 2, 3, 4]]
+    assert float(ja.compute_detection_metrics([p3], targets)["map"]) == pytest.approx(0.8, 0.01)
+    assert float(ja.compute_detection_metrics([p2], [torch.zeros((0, 5))])["map"]) == 0.0
+
+
+def test_merge_boxes_groups_contiguous_pieces():
+    pieces = torch.tensor([[410., 410, 447, 447, 0.9, 0.5], [448, 410, 500, 447, 0.8, 1.0], [410, 448, 447, 500, 0.7, 1.0],
+                           [1500, 1500, 1600, 1600, 0.6, 1.0]])
+    m = ja.merge_boxes(pieces, threshold=2)
+    assert m.shape == (2, 6)
+    assert m[0].tolist() == pytest.approx([410, 410, 500, 500, 0.8, 1.0])
+    assert m[1].tolist() == pytest.approx([1500, 1500, 1600, 1600, 0.6, 1.0])
+    tg = torch.tensor([[0, 410, 410, 447, 447], [0, 448, 410, 500, 447], [0, 900, 900, 950, 950]])
+    assert ja.merge_boxes(tg, target=True).tolist() == [[0, 410, 410, 500, 447], [0, 900, 900, 950, 950]]
+    assert ja.merge_boxes_batched([None, tg], target=True)[0] is None
