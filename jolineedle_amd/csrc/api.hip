@@ -674,6 +674,24 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
       case OP_CONV3:
       case OP_DW: {
         const ConvW& cw = net.convs[op.wslot];
+        static const bool no_fused_eval = std::getenv("JN_NO_FUSED_EVAL") != nullptr;
+        if (!train && !no_fused_eval && net.act_dtype == JN_F32 && op.kind == OP_DW && oi + 1 < n_ops) {
+          // eval: DWConv = depthwise + pointwise in one kernel, the depthwise output stays on chip
+          const Op& nx = net.ops[oi + 1];
+          if (nx.kind == OP_PW && nx.in.buf == op.out.buf && nx.in.coff == op.out.coff && nx.in.C == op.out.C &&
+              dwpw_supported(op.out.C, nx.out.C, op.stride)) {
+            const ConvW& pw = net.convs[nx.wslot];
+            DwPwArgs f{};
+            f.in = ptr(op.in); f.in_ld = ld(op.in); f.itab = tab(op.in); f.w_dw = cw.w_dev; f.mtab = tab(op.out);
+            f.w_pw = pw.w_dev; f.out = ptr(nx.out); f.out_ld = ld(nx.out); f.dtype = net.act_dtype;
+            f.C = op.out.C; f.cout = nx.out.C; f.N = N; f.H = op.in.H; f.W = op.in.W; f.OH = op.out.H; f.OW = op.out.W;
+            f.stride = op.stride; f.skip_flag = skip_flag; f.skip_when = skip_when;
+            launch_dwpw(f, s);
+            if (layer_profile) { hipEventRecord(lev[oi + 1], s); hipEventRecord(lev[oi + 2], s); }
+            ++oi;
+            continue;
+          }
+        }
         ConvArgs a{};
         a.in = ptr(op.in); a.in_ld = ld(op.in); a.in_dtype = net.act_dtype; a.itab = tab(op.in); a.w = cw.w_dev;
         a.bias = cw.b_dev; a.out = ptr(op.out); a.out_ld = ld(op.out); a.out_dtype = net.act_dtype;

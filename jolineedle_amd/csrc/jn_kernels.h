@@ -63,6 +63,14 @@ struct ConvArgs {
   long long in_slot_stride, out_slot_stride, tab_slot_stride;
 };
 
+// eval-mode DWConv (depthwise 3x3 -> BN + SiLU -> pointwise 1x1) in one kernel; mtab = table of the depthwise output
+struct DwPwArgs {
+  const void* in; int in_ld; ChanTab itab; const float* w_dw; ChanTab mtab; const float* w_pw;
+  void* out; int out_ld; int dtype; int C, cout, N, H, W, OH, OW, stride;
+  const int* skip_flag; int skip_when;
+};
+bool dwpw_supported(int C, int cout, int stride);
+int launch_dwpw(const DwPwArgs& a, hipStream_t s);
 int launch_stem(const StemArgs& a, hipStream_t s);
 int launch_dw(const ConvArgs& a, hipStream_t s);
 int launch_pw(const ConvArgs& a, hipStream_t s);

@@ -358,6 +358,173 @@ static void launch_dw_lds(const ConvArgs& a, hipStream_t s) {
                      a.skip_flag, a.skip_when);
 }
 
+// ------------------------------------------------------------------------------------
+// Eval-mode DWConv in ONE kernel: depthwise 3x3 (stride S) -> BN + SiLU (fixed affine from the running statistics)
+// -> pointwise 1x1.  The depthwise output never goes to HBM: per 16-channel chunk the workgroup stages the activated
+// input tile (+halo) in LDS, forms the depthwise outputs of its TH x 16 pixels, activates them into the MFMA operand
+// tile and accumulates W_pw[:, chunk] . X.  (Train mode cannot do this: the BN between the two convs needs the
+// statistics of the whole batch first.)  WM = waves along the pixels: 4 -> 128 pixels (S = 1, TH = 8), 2 -> 64 pixels
+// (S = 2, TH = 4; the wave pairs split the channel tiles).
+// ------------------------------------------------------------------------------------
+template <int S, int WM, int CT, typename AT>
+__global__ __launch_bounds__(256) void dwpw_eval_kernel(
+    const AT* __restrict__ in, int in_ld, ChanTab it, const float* __restrict__ w_dw, ChanTab mt,
+    const float* __restrict__ w_pw, AT* __restrict__ out, int out_ld, int C, int Nc, int H, int W, int OH, int OW,
+    int tiles_x, int tiles_y, const int* __restrict__ skip_flag, int skip_when) {
+  if (skip_flag && *skip_flag >= skip_when) return;
+  constexpr int CB = 16, Q = 4, TW = 16, TH = 2 * WM, BM = TH * TW;
+  constexpr int IH = S * (TH - 1) + 3, IW = S * (TW - 1) + 3;
+  constexpr int PS = S == 1 ? CB : CB + 4;            // input tile pixel stride (see dw3x3_lds_kernel)
+  constexpr int LDX = CB + 4;                         // MFMA operand rows: 16-B aligned, banks spread
+  constexpr int RPG = TH / 4;                         // output rows per thread in the depthwise phase
+  constexpr int CTW = CT * WM / 4;                    // channel tiles per wave
+  constexpr int NT = (IH * IW * Q + 255) / 256, NW = (16 * CT * Q + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Ti = sm;                                     // [IH*IW][PS]  activated input chunk
+  float* Xs = Ti + IH * IW * PS;                      // [BM][LDX]    activated depthwise outputs
+  float* Ws = Xs + BM * LDX;                          // [16*CT][LDX] pointwise weight chunk
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, g = lane >> 4;
+  const int wm = wave % WM, wn = wave / WM;
+  const int tile = blockIdx.x % (tiles_x * tiles_y), n = blockIdx.x / (tiles_x * tiles_y);
+  const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
+  const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+  const int q = tid & 3;
+  const AT* inb = in + (long long)n * H * W * in_ld;
+  f32x4 acc[2][CTW];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 rt[NT], rw[NW];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int i = tid + 256 * j, p = i >> 2, r = p / IW, cx = p - r * IW;
+      const int iy = iy0 + r, ix = ix0 + cx;
+      rt[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < IH * IW * Q && iy >= 0 && iy < H && ix >= 0 && ix < W) rt[j] = ld4(inb + ((long long)iy * W + ix) * in_ld + k0 + 4 * q);
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int i = tid + 256 * j, r = i >> 2;
+      rw[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < 16 * CT * Q && r < Nc) rw[j] = *reinterpret_cast<const f32x4*>(w_pw + (long long)r * C + k0 + 4 * q);
+    }
+  };
+  fetch(0);
+  const int x = (tid >> 2) & 15, j0 = (tid >> 6) * RPG;       // depthwise phase: column, first row of this thread
+  for (int k0 = 0; k0 < C; k0 += CB) {
+    const int c = k0 + 4 * q;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(it.sc + c), sh = *reinterpret_cast<const f32x4*>(it.sh + c),
+                fl = *reinterpret_cast<const f32x4*>(it.fl + c);
+    if (k0) __syncthreads();                          // the previous chunk's MFMAs have read Xs / Ws
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int i = tid + 256 * j, p = i >> 2, r = p / IW, cx = p - r * IW;
+      const int iy = iy0 + r, ix = ix0 + cx;
+      if (i < IH * IW * Q) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = tf4(rt[j], sc, sh, fl);
+        *reinterpret_cast<f32x4*>(Ti + p * PS + 4 * q) = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int i = tid + 256 * j;
+      if (i < 16 * CT * Q) *reinterpret_cast<f32x4*>(Ws + (i >> 2) * LDX + 4 * q) = rw[j];
+    }
+    __syncthreads();
+    if (k0 + CB < C) fetch(k0 + CB);
+    {   // depthwise 3x3 on the chunk, then the dconv layer's BN + SiLU -> MFMA operand tile
+      f32x4 wv[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(w_dw + t * C + c);
+      const f32x4 msc = *reinterpret_cast<const f32x4*>(mt.sc + c), msh = *reinterpret_cast<const f32x4*>(mt.sh + c);
+      f32x4 d[RPG];
+#pragma unroll
+      for (int j = 0; j < RPG; ++j) d[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      constexpr int R = S * (RPG - 1) + 3;
+      const float* sp = Ti + ((j0 * S) * IW + x * S) * PS + 4 * q;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(sp + (r * IW + kx) * PS);
+#pragma unroll
+          for (int j = 0; j < RPG; ++j) {
+            const int ky = r - j * S;
+            if (ky >= 0 && ky < 3) d[j] += v * wv[ky * 3 + kx];
+          }
+        }
+#pragma unroll
+      for (int j = 0; j < RPG; ++j) {
+        f32x4 a;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = silu(fmaf(d[j][k], msc[k], msh[k]));
+        *reinterpret_cast<f32x4*>(Xs + ((j0 + j) * TW + x) * LDX + 4 * q) = a;
+      }
+    }
+    __syncthreads();
+    {
+      const f32x4 xb0 = *reinterpret_cast<const f32x4*>(Xs + (wm * 32 + lm) * LDX + 4 * g);
+      const f32x4 xb1 = *reinterpret_cast<const f32x4*>(Xs + (wm * 32 + 16 + lm) * LDX + 4 * g);
+#pragma unroll
+      for (int cc = 0; cc < CTW; ++cc) {
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(Ws + ((wn * CTW + cc) * 16 + lm) * LDX + 4 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[0][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], xb0[j], acc[0][cc], 0, 0, 0);
+          acc[1][cc] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], xb1[j], acc[1][cc], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int pix = wm * 32 + 16 * p + lm;
+    const int oy = oy0 + pix / TW, ox = ox0 + pix % TW;
+    if (oy >= OH || ox >= OW) continue;
+    AT* op = out + (((long long)n * OH + oy) * OW + ox) * out_ld;
+#pragma unroll
+    for (int cc = 0; cc < CTW; ++cc) {
+      const int nn = (wn * CTW + cc) * 16 + 4 * g;
+      if (nn < Nc) st4(op + nn, acc[p][cc]);
+    }
+  }
+}
+
+template <int S, int WM, int CT, typename AT>
+static void launch_dwpw_t(const DwPwArgs& a, hipStream_t s) {
+  constexpr int TH = 2 * WM, IH = S * (TH - 1) + 3, IW = S * 15 + 3, PS = S == 1 ? 16 : 20;
+  const int tiles_x = (a.OW + 15) / 16, tiles_y = (a.OH + TH - 1) / TH;
+  const size_t smem = ((size_t)IH * IW * PS + (size_t)TH * 16 * 20 + (size_t)16 * CT * 20) * sizeof(float);
+  hipLaunchKernelGGL((dwpw_eval_kernel<S, WM, CT, AT>), dim3(tiles_x * tiles_y * a.N), dim3(256), smem, s, (const AT*)a.in,
+                     a.in_ld, a.itab, a.w_dw, a.mtab, a.w_pw, (AT*)a.out, a.out_ld, a.C, a.cout, a.H, a.W, a.OH, a.OW, tiles_x,
+                     tiles_y, a.skip_flag, a.skip_when);
+}
+
+bool dwpw_supported(int C, int cout, int stride) {
+  // measured at B = 64: a win up to 64 depthwise channels (<= 4 chunks); at 128 channels (14x14 maps) the serial
+  // chunk loop of the few workgroups is slower than the two separate kernels
+  if (C % 16 || cout % 16 || cout > 128 || C > 64) return false;
+  if (stride == 2 && (cout / 16) % 2) return false;         // the wave pairs split the channel tiles
+  const int ct = cout / 16;
+  return ct == 1 || ct == 2 || ct == 4 || ct == 8;
+}
+
+int launch_dwpw(const DwPwArgs& a, hipStream_t s) {
+  const int ct = a.cout / 16;
+#define JN_DP(S_, WM_, CT_) { if (a.dtype == JN_BF16) launch_dwpw_t<S_, WM_, CT_, bf16_t>(a, s); else launch_dwpw_t<S_, WM_, CT_, float>(a, s); return 0; }
+  if (a.stride == 1) {
+    if (ct == 1) JN_DP(1, 4, 1) if (ct == 2) JN_DP(1, 4, 2) if (ct == 4) JN_DP(1, 4, 4) if (ct == 8) JN_DP(1, 4, 8)
+  } else {
+    if (ct == 2) JN_DP(2, 2, 2) if (ct == 4) JN_DP(2, 2, 4) if (ct == 8) JN_DP(2, 2, 8)
+  }
+#undef JN_DP
+  return -1;
+}
+
 int launch_dw(const ConvArgs& a, hipStream_t s) {
   if (a.cin % 16 == 0 && a.N <= 65535) {
     const bool bf = a.in_dtype == JN_BF16;
