@@ -190,7 +190,9 @@ class YOLOPAFPN(nn.Module):
 
 
 class YOLOXHead(nn.Module):
-    """Inference branch only: raw maps -> [B, A, 5+nc] decoded to pixels."""
+    """Inference branch (raw maps -> [B, A, 5+nc] decoded to pixels) and the training branch
+    (`losses`: SimOTA assignment + IoU / objectness / class / L1 losses, restated from the published YOLOX v0.3.0
+    yolo_head.py — the fork the reference installs is not vendored and pins no commit: PARITY UNPINNED)."""
 
     def __init__(self, num_classes, width=1.0, strides=(8, 16, 32),
                  in_channels=(256, 512, 1024), depthwise=False):
@@ -230,6 +232,137 @@ class YOLOXHead(nn.Module):
         hw = [o.shape[-2:] for o in outs]
         out = torch.cat([o.flatten(start_dim=2) for o in outs], dim=2).permute(0, 2, 1)
         return decode_outputs(out, hw, self.strides)
+
+    # ---- training branch (YOLOXHead.forward(xin, labels, imgs) in train mode -> get_losses) -----------------
+    def raw_logits(self, feats):
+        """[B, A, 6] raw predictor outputs (reg 4, obj logit, cls logit), anchors ordered level by level, row-major."""
+        outs = []
+        for k, x in enumerate(feats):
+            x = self.stems[k](x)
+            cls_feat = self.cls_convs[k](x)
+            reg_feat = self.reg_convs[k](x)
+            o = torch.cat([self.reg_preds[k](reg_feat), self.obj_preds[k](reg_feat), self.cls_preds[k](cls_feat)], 1)
+            outs.append(o.flatten(start_dim=2).permute(0, 2, 1))
+        hw = [(f.shape[-2], f.shape[-1]) for f in feats]
+        return torch.cat(outs, 1), hw
+
+    def losses(self, feats, labels: torch.Tensor, use_l1: bool = True):
+        """labels [B, nb, 5] = (class, cx, cy, w, h), zero rows = padding.  Returns the reference's tuple
+        (loss, 5 * iou_loss, obj_loss, cls_loss, l1_loss, num_fg / max(num_gts, 1))."""
+        assert self.num_classes == 1
+        raw, hw = self.raw_logits(feats)
+        B, A, _ = raw.shape
+        grids, svec = [], []
+        for (h, w), s in zip(hw, self.strides):
+            yv, xv = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+            grids.append(torch.stack((xv, yv), 2).view(-1, 2))
+            svec.append(torch.full((h * w,), float(s)))
+        grid = torch.cat(grids, 0).to(raw.dtype)
+        stride = torch.cat(svec, 0).to(raw.dtype)
+        xy = (raw[..., 0:2] + grid) * stride[:, None]
+        wh = torch.exp(raw[..., 2:4]) * stride[:, None]
+        boxes = torch.cat([xy, wh], -1)                       # decoded cxcywh predictions (with grad)
+        obj, cls = raw[..., 4], raw[..., 5]
+        nlabel = (labels.sum(dim=2) > 0).sum(dim=1)            # rows with a positive sum count as objects
+        loss_iou = raw.new_zeros(())
+        loss_cls = raw.new_zeros(())
+        loss_l1 = raw.new_zeros(())
+        obj_target = torch.zeros((B, A), dtype=raw.dtype)
+        num_fg, num_gts = 0.0, 0.0
+        assign = []
+        for b in range(B):
+            ng = int(nlabel[b])
+            num_gts += ng
+            if ng == 0:
+                assign.append(None)
+                continue
+            gt = labels[b, :ng, 1:5].to(raw.dtype)            # the FIRST ng rows (as published, even if a zero row precedes)
+            with torch.no_grad():
+                fg, matched, ious = simota_assign(gt, boxes[b].detach(), obj[b].detach(), cls[b].detach(), grid, stride)
+            assign.append((fg, matched, ious))
+            nf = int(fg.sum())
+            num_fg += nf
+            if nf == 0:
+                continue
+            obj_target[b, fg] = 1.0
+            tgt = gt[matched]
+            pb = boxes[b][fg]
+            loss_iou = loss_iou + iou_loss(pb, tgt).sum()
+            loss_cls = loss_cls + F.binary_cross_entropy_with_logits(cls[b][fg], ious, reduction="sum")
+            if use_l1:
+                l1t = torch.stack([tgt[:, 0] / stride[fg] - grid[fg, 0], tgt[:, 1] / stride[fg] - grid[fg, 1],
+                                   torch.log(tgt[:, 2] / stride[fg] + 1e-8), torch.log(tgt[:, 3] / stride[fg] + 1e-8)], 1)
+                loss_l1 = loss_l1 + (raw[b][fg][:, :4] - l1t).abs().sum()
+        den = max(num_fg, 1.0)
+        loss_obj = F.binary_cross_entropy_with_logits(obj, obj_target, reduction="sum") / den
+        loss_iou, loss_cls, loss_l1 = loss_iou / den, loss_cls / den, loss_l1 / den
+        total = 5.0 * loss_iou + loss_obj + loss_cls + loss_l1
+        self.last_assignment = assign
+        return total, 5.0 * loss_iou, loss_obj, loss_cls, loss_l1, num_fg / max(num_gts, 1.0)
+
+
+def pairwise_iou_cxcywh(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """bboxes_iou(a, b, xyxy=False) of YOLOX: [len(a), len(b)]."""
+    tl = torch.max(a[:, None, :2] - a[:, None, 2:] / 2, b[None, :, :2] - b[None, :, 2:] / 2)
+    br = torch.min(a[:, None, :2] + a[:, None, 2:] / 2, b[None, :, :2] + b[None, :, 2:] / 2)
+    area_a = a[:, 2] * a[:, 3]
+    area_b = b[:, 2] * b[:, 3]
+    en = (tl < br).to(a.dtype).prod(dim=2)
+    inter = (br - tl).prod(dim=2) * en
+    return inter / (area_a[:, None] + area_b[None, :] - inter)
+
+
+def iou_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """IOUloss(reduction="none", loss_type="iou"): 1 - iou^2 on cxcywh rows."""
+    tl = torch.max(pred[:, :2] - pred[:, 2:] / 2, target[:, :2] - target[:, 2:] / 2)
+    br = torch.min(pred[:, :2] + pred[:, 2:] / 2, target[:, :2] + target[:, 2:] / 2)
+    area_p = pred[:, 2] * pred[:, 3]
+    area_g = target[:, 2] * target[:, 3]
+    en = (tl < br).to(pred.dtype).prod(dim=1)
+    inter = (br - tl).prod(dim=1) * en
+    iou = inter / (area_p + area_g - inter + 1e-16)
+    return 1.0 - iou ** 2
+
+
+def simota_assign(gt: torch.Tensor, boxes: torch.Tensor, obj: torch.Tensor, cls: torch.Tensor,
+                  grid: torch.Tensor, stride: torch.Tensor):
+    """get_assignments + get_geometry_constraint + simota_matching for one image (num_classes = 1).
+    Returns (fg mask [A], matched gt index per fg anchor, IoU of each fg anchor with its gt)."""
+    A, ng = boxes.shape[0], gt.shape[0]
+    xc = (grid[:, 0] + 0.5) * stride
+    yc = (grid[:, 1] + 0.5) * stride
+    r = 1.5 * stride
+    deltas = torch.stack([xc[None] - (gt[:, 0:1] - r[None]), yc[None] - (gt[:, 1:2] - r[None]),
+                          (gt[:, 0:1] + r[None]) - xc[None], (gt[:, 1:2] + r[None]) - yc[None]], 2)
+    in_centers = deltas.min(dim=-1).values > 0.0                # [ng, A]
+    cand = in_centers.sum(0) > 0                                # anchor_filter
+    fg = torch.zeros(A, dtype=torch.bool)
+    if int(cand.sum()) == 0:
+        return fg, torch.zeros((0,), dtype=torch.long), boxes.new_zeros((0,))
+    geo = in_centers[:, cand]
+    ious = pairwise_iou_cxcywh(gt, boxes[cand])                 # [ng, nc]
+    iou_cost = -torch.log(ious + 1e-8)
+    p = (cls[cand].sigmoid() * obj[cand].sigmoid()).sqrt()
+    cls_cost = F.binary_cross_entropy(p[None, :].expand(ng, -1), torch.ones((ng, p.shape[0]), dtype=p.dtype),
+                                      reduction="none")        # one class: the one-hot target is 1
+    cost = cls_cost + 3.0 * iou_cost + 1e6 * (~geo).to(ious.dtype)
+    match = torch.zeros_like(cost, dtype=torch.uint8)
+    k10 = min(10, ious.shape[1])
+    dyn_k = torch.clamp(torch.topk(ious, k10, dim=1).values.sum(1).int(), min=1)
+    for g in range(ng):
+        idx = torch.topk(cost[g], k=int(dyn_k[g]), largest=False).indices
+        match[g, idx] = 1
+    per_anchor = match.sum(0)
+    if int(per_anchor.max()) > 1:
+        multi = per_anchor > 1
+        amin = torch.min(cost[:, multi], dim=0).indices
+        match[:, multi] = 0
+        match[amin, multi] = 1
+    sel = per_anchor > 0
+    fg[cand.nonzero().squeeze(1)[sel]] = True
+    matched = match[:, sel].argmax(0)
+    pred_ious = (match.to(ious.dtype) * ious).sum(0)[sel]
+    return fg, matched, pred_ious
 
 
 def decode_outputs(out: torch.Tensor, hw, strides) -> torch.Tensor:
@@ -325,16 +458,25 @@ def build_yolox(name: str, num_classes: int) -> YOLOX:
 
 
 class NeedleYOLOXRef(YOLOX):
-    """Inference branch of NeedleYOLOX.forward (src/models/yolox.py:24-57, 74-113)."""
+    """NeedleYOLOX.forward (src/models/yolox.py:24-113): inference branch, and with `targets` the loss branch
+    (yolox.py:58-73: xyxy -> cxcywh, head in train mode, use_l1 = True)."""
 
     def __init__(self, backbone, head, conf_threshold: float):
         super().__init__(backbone, head)
         self.conf_threshold = conf_threshold
 
     def forward(self, patches: torch.Tensor, targets=None):
-        assert targets is None, "oracle restates the inference branch only"
         mode = self.training
         fpn_outs = self.backbone(patches)          # current mode (yolox.py:54-55)
+        losses = {}
+        if targets is not None:
+            t = targets.clone().to(patches.dtype)
+            x1, y1, x2, y2 = t[..., 1].clone(), t[..., 2].clone(), t[..., 3].clone(), t[..., 4].clone()
+            t[..., 1], t[..., 2], t[..., 3], t[..., 4] = (x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1
+            self.train()                           # yolox.py:62
+            loss, iou_l, conf_l, cls_l, l1_l, num_fg = self.head.losses(fpn_outs, t, use_l1=True)
+            losses = {"total_loss": loss, "iou_loss": iou_l, "l1_loss": l1_l, "conf_loss": conf_l, "cls_loss": cls_l,
+                      "num_fg": num_fg}
         self.eval()                                # yolox.py:77
         outputs = self.head(fpn_outs)
         outputs = postprocess(outputs, num_classes=1, class_agnostic=True,
@@ -343,4 +485,4 @@ class NeedleYOLOXRef(YOLOX):
             if b is not None:
                 b[:, :4].clamp_(min=0, max=patches.shape[-1] - 1)
         self.train(mode)
-        return outputs, fpn_outs, {}
+        return outputs, fpn_outs, losses

@@ -1,6 +1,7 @@
 """Pins the CPU oracle against the golden vectors produced by the reference's own
 code (tests/golden/make_golden.py).  CPU only."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import env_ref, rollout_ref, yolox_ref
@@ -168,3 +169,28 @@ def test_nms_and_postprocess_known_answers():
     out = yolox_ref.postprocess(pred, 1, conf_thre=0.5, class_agnostic=True)
     assert out[0].shape == (1, 7) and out[0][0, :4].tolist() == [0, 0, 10, 10]
     assert yolox_ref.postprocess(pred * 0, 1, conf_thre=0.5, class_agnostic=True) == [None]
+
+
+def test_simota_known_answers():
+    """Hand-computable cases of the restated SimOTA assignment (the YOLOX package is absent from the reference tree:
+    parity unpinned, the oracle is checked against the published algorithm's invariants)."""
+    from oracle.yolox_ref import simota_assign, iou_loss, pairwise_iou_cxcywh
+    yv, xv = torch.meshgrid(torch.arange(4), torch.arange(4), indexing="ij")
+    grid = torch.stack((xv, yv), 2).view(-1, 2).float()
+    stride = torch.full((16,), 8.0)
+    gt = torch.tensor([[12.0, 12.0, 8.0, 8.0]])
+    boxes = gt.expand(16, 4).clone()                      # every anchor predicts the gt exactly: IoU 1
+    fg, matched, ious = simota_assign(gt, boxes, torch.zeros(16), torch.zeros(16), grid, stride)
+    # centre radius 1.5 * stride = 12 px around (12, 12): anchor centres 4, 12, 20 qualify -> 3 x 3 candidates;
+    # dynamic k = int(sum of the top-10 IoUs) = 9 -> all of them are foreground
+    assert int(fg.sum()) == 9 and fg.view(4, 4)[:3, :3].all() and matched.tolist() == [0] * 9
+    assert torch.allclose(ious, torch.ones(9))
+    boxes2 = boxes.clone()
+    boxes2[:, 2:] = 4.0                                   # quarter-area predictions: IoU 0.25 -> k = int(2.25) = 2
+    fg2, _, ious2 = simota_assign(gt, boxes2, torch.zeros(16), torch.zeros(16), grid, stride)
+    assert int(fg2.sum()) == 2 and torch.allclose(ious2, torch.full((2,), 0.25))
+    # two gts competing for the same anchors: every foreground anchor ends with exactly one gt (lowest cost)
+    gt2 = torch.tensor([[12.0, 12.0, 8.0, 8.0], [14.0, 12.0, 8.0, 8.0]])
+    fg3, matched3, _ = simota_assign(gt2, boxes, torch.zeros(16), torch.zeros(16), grid, stride)
+    assert len(matched3) == int(fg3.sum()) and set(matched3.tolist()) <= {0, 1}
+    assert torch.allclose(iou_loss(gt, gt), torch.zeros(1)) and float(pairwise_iou_cxcywh(gt, gt2)[0, 1]) == pytest.approx(0.6)
