@@ -227,6 +227,21 @@ int jn_gpt_forward(jn_ctx* ctx, const float* patches_dev, const int64_t* actions
 int jn_detect(jn_ctx* ctx, const float* patches_dev, int N, float* boxes_dev,
               int32_t* counts_dev, float* raw_dev, void* stream);
 
+/* One training step of the detector minus the optimiser: NeedleYOLOX.forward(patches, targets) loss branch
+ * (src/models/yolox.py:58-73) + loss.backward() (src/reinforce.py:336-341).  PAFPN + head forward with
+ * batch-statistics BatchNorm on N patches, SimOTA assignment + IoU / objectness / class / L1 losses (YOLOX head,
+ * use_l1 = True), backward; gradients are ACCUMULATED into the gradient arena (yolox.* parameters).
+ * targets_dev: [N, nb, 5] float32 = (class id, x1, y1, x2, y2) in patch pixels, zero rows = padding
+ * (NeedleGeneralEnv.get_detection_batch layout).  loss_scale multiplies the loss before backward
+ * (1 / gradient_accumulation).  metrics_dev: float32[8] = total_loss, iou_loss (x5), conf_loss, cls_loss, l1_loss,
+ * num_fg (foreground anchors per ground-truth box). */
+int jn_detector_step(jn_ctx* ctx, const float* patches_dev, int N, const float* targets_dev, int nb,
+                     float loss_scale, float* metrics_dev, void* stream);
+/* AdamW + clip on one parameter group of the arena: group 0 = optim_gpt (everything but yolox.*,
+ * src/models/gpt.py:552-557), group 1 = optim_yolox (yolox.*).  jn_optimizer_step == group 0. */
+int jn_optimizer_step_group(jn_ctx* ctx, int group, float lr, float weight_decay, float clip_value,
+                            float grad_scale, void* stream);
+
 /* ---- the hot loop ----------------------------------------------------------------- */
 /* ReinforceTrainer.rollout (src/reinforce.py:108-215) for the env set by jn_env_init:
  * reset (positions NULL = random from seed), then up to T steps of

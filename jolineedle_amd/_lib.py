@@ -98,6 +98,8 @@ SIGNATURES = {
     "jn_rollout_steps": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_void_p]),
     "jn_last_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "jn_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "jn_detector_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "jn_optimizer_step_group": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
 }
 
 

@@ -523,15 +523,21 @@ int jn_load_weights(jn_ctx* ctx, const jn_tensor* tensors, size_t n) {
       const float* cw = tm.f32(hp + "cls_preds." + k + ".weight", hid);
       const float* cb = tm.f32(hp + "cls_preds." + k + ".bias", 1);
       if (!rw || !rb || !ow || !ob || !cw || !cb) return JN_ENOTFOUND;
-      std::vector<float> w6((size_t)6 * hid), b6(6);
-      std::copy(rw, rw + 4 * hid, w6.begin());
-      std::copy(ow, ow + hid, w6.begin() + 4 * hid);
-      std::copy(cw, cw + hid, w6.begin() + 5 * hid);
-      for (int i = 0; i < 4; ++i) b6[i] = rb[i];
-      b6[4] = ob[0]; b6[5] = cb[0];
+      // arena-resident (trainable): reg (4 x hid) | obj (hid) | cls (hid) rows back to back = one [6][hid] matrix;
+      // biases reg (4) | obj (1, padded to 4) | cls (1, padded to 4): entries 0..3, 4 and 8 of `pred_b`
+      (void)rw; (void)rb; (void)ow; (void)ob; (void)cw; (void)cb;
       int r;
-      if ((r = dev_upload(ctx, &net.pred_w[op.level], w6))) return r;
-      if ((r = dev_upload(ctx, &net.pred_b[op.level], b6))) return r;
+      float *w_reg = nullptr, *w_obj = nullptr, *w_cls = nullptr, *b_reg = nullptr, *b_obj = nullptr, *b_cls = nullptr;
+      if ((r = upload_raw(ctx, tm, hp + "reg_preds." + k + ".weight", (size_t)4 * hid, &w_reg))) return r;
+      if ((r = upload_raw(ctx, tm, hp + "obj_preds." + k + ".weight", hid, &w_obj))) return r;
+      if ((r = upload_raw(ctx, tm, hp + "cls_preds." + k + ".weight", hid, &w_cls))) return r;
+      if ((r = upload_raw(ctx, tm, hp + "reg_preds." + k + ".bias", 4, &b_reg))) return r;
+      if ((r = upload_raw(ctx, tm, hp + "obj_preds." + k + ".bias", 1, &b_obj))) return r;
+      if ((r = upload_raw(ctx, tm, hp + "cls_preds." + k + ".bias", 1, &b_cls))) return r;
+      JN_CHECK(w_obj == w_reg + 4 * hid && w_cls == w_obj + hid && b_obj == b_reg + 4 && b_cls == b_reg + 8, JN_ESTATE,
+               "predictor tensors of level %d are not contiguous in the arena", op.level);
+      net.pred_w[op.level] = w_reg;
+      net.pred_b[op.level] = b_reg;
     }
     return JN_OK;
   };
@@ -719,8 +725,8 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
         break;
       case OP_PRED:
         launch_head_pred(ptr(op.in), ld(op.in), tab(op.in), ptr(op.res), ld(op.res), tab(op.res), net.act_dtype, net.pred_w[op.level],
-                         net.pred_b[op.level], ctx->det_raw, net.head_hid, op.in.H, op.in.W, op.stride, net.n_anchors,
-                         op.anchor0, N, s);
+                         net.pred_b[op.level], train ? ctx->det_logits : ctx->det_raw, net.head_hid, op.in.H, op.in.W, op.stride,
+                         net.n_anchors, op.anchor0, N, s, train ? 1 : 0);
         break;
     }
     if (layer_profile) hipEventRecord(lev[oi + 1], s);
@@ -790,7 +796,7 @@ static inline float* grad_of(const jn_ctx* ctx, const float* param) { return ctx
 // costs the launches of one pass.  g[fpn views] must hold the incoming gradients; parameter gradients are
 // accumulated into ctx->grads.  ss.positions belongs to the first pass, pos_slot_stride int64s separate passes.
 static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, hipStream_t s, int nsl = 1,
-                            long long pos_slot_stride = 0) {
+                            long long pos_slot_stride = 0, bool with_head = false) {
   Net& net = ctx->nets[ni];
   const int MB = ctx->cfg.max_batch;
   JN_CHECK(nsl >= 1 && nsl <= net.g_slots && slot + nsl <= net.n_slots, JN_ESTATE, "backward over %d slots from %d: not allocated", nsl, slot);
@@ -812,8 +818,9 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
   auto ld = [&](const View& v) { return net.bufs[v.buf].C; };
   const ChanTab ident{ctx->ident, ctx->ident + 2048, ctx->ident + 4096};
   std::map<int, std::pair<int, View>> g_alias;      // conv output buffer -> (coff, gradient view to read instead)
-  for (auto it = net.ops.rbegin(); it != net.ops.rend(); ++it) {
-    const Op& op = *it;
+  const int n_ops_b = (with_head || net.n_backbone_ops < 0) ? (int)net.ops.size() : net.n_backbone_ops;
+  for (int obi = n_ops_b - 1; obi >= 0; --obi) {
+    const Op& op = net.ops[obi];
     if (op.wslot >= 0) {
       const ConvW& cw = net.convs[op.wslot];
       JN_CHECK(cw.has_bn, JN_ESTATE, "backward of BN-free conv %s inside a PAFPN", op.name.c_str());
@@ -1189,6 +1196,65 @@ int jn_detect(jn_ctx* ctx, const float* patches_dev, int N, float* boxes_dev, in
   const int P = ctx->cfg.patch_size;
   StemSrc ss{patches_dev, nullptr, 3LL * P * P, (long long)P * P, P};
   return detect_impl(ctx, ss, N, boxes_dev, counts_dev, raw_dev, nullptr, 0, (hipStream_t)stream);
+}
+
+// xyxy (class, x1, y1, x2, y2) -> (class, cx, cy, w, h), src/models/yolox.py:59-60
+__global__ void labels_to_cxcywh_kernel(const float* __restrict__ in, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* s = in + 5 * i;
+  float* d = out + 5 * i;
+  d[0] = s[0]; d[1] = 0.5f * (s[1] + s[3]); d[2] = 0.5f * (s[2] + s[4]); d[3] = s[3] - s[1]; d[4] = s[4] - s[2];
+}
+
+int jn_detector_step(jn_ctx* ctx, const float* patches_dev, int N, const float* targets_dev, int nb, float loss_scale,
+                     float* metrics_dev, void* stream) {
+  JN_CHECK(ctx && patches_dev && targets_dev && metrics_dev, JN_EINVAL, "jn_detector_step: null argument");
+  JN_CHECK(ctx->has_net[JN_NET_DETECTOR], JN_ESTATE, "context was created without a detector");
+  JN_CHECK(ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
+  JN_CHECK(N >= 1 && N <= ctx->cfg.max_batch, JN_EINVAL, "N=%d exceeds max_batch=%d", N, ctx->cfg.max_batch);
+  JN_CHECK(nb >= 1, JN_EINVAL, "targets need at least one (padding) row per patch");
+  JN_CHECK(ctx->cfg.act_dtype == JN_F32, JN_ESTATE, "training needs act_dtype = fp32 (bf16 is the inference mode)");
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  Net& net = ctx->nets[JN_NET_DETECTOR];
+  const int MB = ctx->cfg.max_batch, A = net.n_anchors, P = ctx->cfg.patch_size;
+  int rc;
+  if ((rc = ensure_slots(ctx, net, 2))) return rc;               // slot 1 = the training pass
+  if ((rc = ensure_train_state(ctx, ctx->enc_net == JN_NET_DETECTOR ? std::max(1, ctx->nets[ctx->enc_net].g_slots) : 1))) return rc;
+  if (!ctx->det_logits) {
+    if ((rc = dev_alloc(ctx, &ctx->det_logits, (size_t)MB * A * 6))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->det_dlogits, (size_t)MB * A * 6))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->det_acc, (size_t)16))) return rc;
+  }
+  if (!ctx->det_labels || ctx->det_labels_rows < (size_t)N * nb) {
+    if ((rc = dev_alloc(ctx, &ctx->det_labels, (size_t)MB * nb * 5))) return rc;
+    ctx->det_labels_rows = (size_t)MB * nb;
+  }
+  hipLaunchKernelGGL(labels_to_cxcywh_kernel, dim3((N * nb + 255) / 256), dim3(256), 0, s, targets_dev, ctx->det_labels, N * nb);
+  StemSrc ss{patches_dev, nullptr, 3LL * P * P, (long long)P * P, P};
+  if ((rc = run_net(ctx, JN_NET_DETECTOR, N, ss, 1, 1, nullptr, 0, s, true))) return rc;
+  DetGeom geo{};
+  geo.A = A;
+  for (const Op& op : net.ops) {
+    if (op.kind != OP_PRED) continue;
+    geo.a0[op.level] = op.anchor0; geo.H[op.level] = op.in.H; geo.W[op.level] = op.in.W; geo.stride[op.level] = op.stride;
+  }
+  launch_yolox_loss(ctx->det_logits, ctx->det_labels, N, nb, geo, ctx->det_dlogits, ctx->det_acc, 1, loss_scale, metrics_dev,
+                    ctx->det_acc + 8, s);
+  for (const Op& op : net.ops) {
+    if (op.kind != OP_PRED) continue;
+    float* g_reg = net.gact + net.buf_off[op.in.buf] * (size_t)MB + op.in.coff;
+    float* g_cls = net.gact + net.buf_off[op.res.buf] * (size_t)MB + op.res.coff;
+    rc = launch_head_pred_bwd(ctx->det_dlogits, ctx->det_acc + 8, view_ptr(net, 1, MB, op.in), net.bufs[op.in.buf].C,
+                              view_tab(net, 1, op.in), view_ptr(net, 1, MB, op.res), net.bufs[op.res.buf].C, view_tab(net, 1, op.res),
+                              net.act_dtype, net.pred_w[op.level], g_reg, g_cls, grad_of(ctx, net.pred_w[op.level]),
+                              grad_of(ctx, net.pred_b[op.level]), net.head_hid, op.in.H * op.in.W, A, op.anchor0, N, s);
+    JN_CHECK(rc == 0, JN_ESTATE, "predictor backward: unsupported buffer type");
+  }
+  if ((rc = run_net_backward(ctx, JN_NET_DETECTOR, N, ss, 1, s, 1, 0, true))) return rc;
+  JN_HIP(hipGetLastError());
+  return JN_OK;
 }
 
 // ---- environment ---------------------------------------------------------------------
@@ -1681,11 +1747,21 @@ int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* cur
 }
 
 int jn_optimizer_step(jn_ctx* ctx, float lr, float weight_decay, float clip_value, float grad_scale, void* stream) {
-  JN_CHECK(ctx && ctx->grads, JN_ESTATE, "no gradients: run jn_reinforce_step first");
+  return jn_optimizer_step_group(ctx, 0, lr, weight_decay, clip_value, grad_scale, stream);
+}
+
+int jn_optimizer_step_group(jn_ctx* ctx, int group, float lr, float weight_decay, float clip_value, float grad_scale,
+                            void* stream) {
+  JN_CHECK(ctx && ctx->grads, JN_ESTATE, "no gradients: run jn_reinforce_step / jn_detector_step first");
+  JN_CHECK(group == 0 || group == 1, JN_EINVAL, "parameter group %d: 0 = optim_gpt, 1 = optim_yolox", group);
   JN_HIP(hipSetDevice(ctx->cfg.device));
-  ctx->adam_step += 1;
-  launch_adamw(ctx->params, ctx->grads, ctx->adam_m, ctx->adam_v, (long long)ctx->gpt_arena_end, lr, 0.9f, 0.999f, 1e-8f,
-               weight_decay, ctx->adam_step, clip_value, grad_scale, (hipStream_t)stream);
+  const size_t lo = group == 0 ? 0 : ctx->gpt_arena_end, hi = group == 0 ? ctx->gpt_arena_end : ctx->arena_used;
+  JN_CHECK(hi > lo, JN_ESTATE, "parameter group %d is empty", group);
+  int& step = group == 0 ? ctx->adam_step : ctx->adam_step_yolox;
+  step += 1;
+  launch_adamw(ctx->params + lo, ctx->grads + lo, ctx->adam_m + lo, ctx->adam_v + lo, (long long)(hi - lo), lr, 0.9f, 0.999f, 1e-8f,
+               weight_decay, step, clip_value, grad_scale, (hipStream_t)stream);
+  for (int ni = 0; ni < 2; ++ni) if (ctx->has_net[ni]) ctx->nets[ni].eval_tab_dirty = true;   // BN affine moved
   JN_HIP(hipGetLastError());
   return JN_OK;
 }

@@ -167,7 +167,7 @@ struct jn_ctx {
   // flat trainable-parameter arena + gradient / AdamW mirrors
   float* params = nullptr; float* grads = nullptr; float* adam_m = nullptr; float* adam_v = nullptr;
   size_t arena_size = 0, arena_used = 0, gpt_arena_end = 0;   // [0, gpt_arena_end) = optim_gpt parameters
-  int adam_step = 0;
+  int adam_step = 0, adam_step_yolox = 0;
   jnr::GptLayerPtrs* g_layers_dev = nullptr;
   float* efpn_train = nullptr;    // [T][B][h*w*C] embed_fpn.0 activations of every glimpse step
   float* tok_emb_train = nullptr; // [B][T][C] patch embeddings of every glimpse step
@@ -192,6 +192,11 @@ struct jn_ctx {
   float* ident = nullptr;         // identity table (scale 1, shift 0, flag 0) for gradient operands
   float* wpart = nullptr;         // [JN_NREP][JN_WPART_MAX] replicated weight-gradient partials (kept zero)
   float* det_raw = nullptr;       // [B][A][6] decoded head output
+  float* det_logits = nullptr;    // [B][A][6] raw predictor outputs of the training pass
+  float* det_dlogits = nullptr;   // [B][A][6] d loss / d raw (before the 1 / num_fg factor)
+  float* det_acc = nullptr;       // [8] loss accumulators, [8] scale
+  float* det_labels = nullptr;    // [B][nb][5] cxcywh labels of the training pass
+  size_t det_labels_rows = 0;
   float* det_tmp_boxes = nullptr; int32_t* det_tmp_counts = nullptr;   // one step's detections before the scatter
   float* tok_emb = nullptr;       // [B][T][C] patch embeddings of jn_gpt_forward
   jnr::EnvState env;

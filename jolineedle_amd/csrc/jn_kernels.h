@@ -98,11 +98,21 @@ int launch_conv3_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtyp
                             const SlotBatch& sb = SlotBatch{});
 int launch_head_pred(const void* reg, int reg_ld, ChanTab rt, const void* cls, int cls_ld, ChanTab ct, int dtype,
                      const float* wp, const float* bp, float* raw, int hid, int Hl, int Wl, int stride, int A, int a0,
-                     int N, hipStream_t s);
+                     int N, hipStream_t s, int logits_only = 0);
 int launch_det_scatter(const float* boxes, const int* counts, float* out_boxes, int* out_counts, int B, int cols, int col,
                        int K, const int* skip_flag, int skip_when, hipStream_t s);
 int launch_postprocess(const float* raw, int A, int N, float conf, float nms_thr, float clamp_max, float* boxes,
                        int* counts, int max_out, hipStream_t s);
+
+// ---- detector training (kernels_detloss.hip) ------------------------------------------------------------
+struct DetGeom { int A; int a0[3]; int H[3]; int W[3]; int stride[3]; };
+// raw: [N][A][6] predictor outputs; labels [N][nb][5] = (class, cx, cy, w, h) floats, zero rows = padding;
+// d_raw gets d loss / d raw before the 1 / max(num_fg, 1) factor, which `scale[0]` carries to the predictor backward
+int launch_yolox_loss(const float* raw, const float* labels, int N, int nb, const DetGeom& geo, float* d_raw, float* acc,
+                      int use_l1, float loss_scale, float* metrics, float* scale, hipStream_t s);
+int launch_head_pred_bwd(const float* d_raw, const float* scale, const void* reg, int reg_ld, ChanTab rt, const void* cls,
+                         int cls_ld, ChanTab ct, int dtype, const float* wp, float* g_reg, float* g_cls, float* g_wp,
+                         float* g_bp, int hid, int HW, int A, int a0, int N, hipStream_t s);
 
 // ---- backward of the conv stack (kernels_bwd.hip) ----------------------------------------
 int launch_bn_bwd_reduce(const float* g, int g_ld, const void* z, int z_dtype, int z_ld, ChanTab t, const float* save,

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void head_pred_kernel(const AT* __restrict__ r
                                                         const AT* __restrict__ cls, int cls_ld, ChanTab ct,
                                                         const float* __restrict__ wp, const float* __restrict__ bp,
                                                         float* __restrict__ raw, int hid, int Hl, int Wl, int stride,
-                                                        int A, int a0, int N) {
+                                                        int A, int a0, int N, int logits_only) {
   extern __shared__ float sw[];     // [6][hid] + tables
   for (int i = threadIdx.x; i < 6 * hid; i += 256) sw[i] = wp[i];
   __syncthreads();
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void head_pred_kernel(const AT* __restrict__ r
   const long long n = idx / (Hl * Wl);
   const AT* rp = reg + idx * reg_ld;
   const AT* cp = cls + idx * cls_ld;
-  float o[6] = {bp[0], bp[1], bp[2], bp[3], bp[4], bp[5]};
+  float o[6] = {bp[0], bp[1], bp[2], bp[3], bp[4], bp[8]};     // bias layout: reg 0..3 | obj 4 (+pad) | cls 8 (+pad)
   for (int k = 0; k < hid; k += 4) {
     const f32x4 rv = tf4_d(ld4(rp + k), *reinterpret_cast<const f32x4*>(rt.sc + k),
                            *reinterpret_cast<const f32x4*>(rt.sh + k), *reinterpret_cast<const f32x4*>(rt.fl + k));
@@ -395,6 +395,11 @@ __global__ __launch_bounds__(256) void head_pred_kernel(const AT* __restrict__ r
   }
   const int gy = p / Wl, gx = p % Wl;
   float* dst = raw + (n * A + a0 + p) * 6;
+  if (logits_only) {                 // training: raw predictor outputs, the loss kernel decodes
+#pragma unroll
+    for (int j = 0; j < 6; ++j) dst[j] = o[j];
+    return;
+  }
   dst[0] = (o[0] + (float)gx) * (float)stride;
   dst[1] = (o[1] + (float)gy) * (float)stride;
   dst[2] = expf(o[2]) * (float)stride;
@@ -405,15 +410,15 @@ __global__ __launch_bounds__(256) void head_pred_kernel(const AT* __restrict__ r
 
 int launch_head_pred(const void* reg, int reg_ld, ChanTab rt, const void* cls, int cls_ld, ChanTab ct, int dtype,
                      const float* wp, const float* bp, float* raw, int hid, int Hl, int Wl, int stride, int A, int a0,
-                     int N, hipStream_t s) {
+                     int N, hipStream_t s, int logits_only) {
   const long long total = (long long)N * Hl * Wl;
   const dim3 grid((unsigned)((total + 255) / 256));
   if (dtype == JN_BF16)
     hipLaunchKernelGGL(head_pred_kernel<bf16_t>, grid, dim3(256), (size_t)6 * hid * sizeof(float), s, (const bf16_t*)reg,
-                       reg_ld, rt, (const bf16_t*)cls, cls_ld, ct, wp, bp, raw, hid, Hl, Wl, stride, A, a0, N);
+                       reg_ld, rt, (const bf16_t*)cls, cls_ld, ct, wp, bp, raw, hid, Hl, Wl, stride, A, a0, N, logits_only);
   else
     hipLaunchKernelGGL(head_pred_kernel<float>, grid, dim3(256), (size_t)6 * hid * sizeof(float), s, (const float*)reg,
-                       reg_ld, rt, (const float*)cls, cls_ld, ct, wp, bp, raw, hid, Hl, Wl, stride, A, a0, N);
+                       reg_ld, rt, (const float*)cls, cls_ld, ct, wp, bp, raw, hid, Hl, Wl, stride, A, a0, N, logits_only);
   return 0;
 }
 

@@ -287,6 +287,25 @@ int build_head(Net& net, std::vector<ParamEntry>& params, const std::string& pre
   }
   net.n_anchors = a0;
   net.head_hid = hid;
+  // backward bookkeeping of the head ops (detector training): the head is differentiated before the PAFPN, its stems
+  // are the first writers of the three FPN gradient views (which the PAFPN plan treats as seeded from outside)
+  {
+    std::vector<std::vector<char>> written(net.bufs.size());
+    for (size_t i = 0; i < net.bufs.size(); ++i) written[i].assign(net.bufs[i].C, 0);
+    for (int oi = (int)net.ops.size() - 1; oi >= net.n_backbone_ops; --oi) {
+      Op& op = net.ops[oi];
+      if (op.kind == OP_PRED) {       // the predictor backward writes g[reg_feat] and g[cls_feat] in full
+        for (int c = 0; c < op.in.C; ++c) written[op.in.buf][op.in.coff + c] = 1;
+        for (int c = 0; c < op.res.C; ++c) written[op.res.buf][op.res.coff + c] = 1;
+        continue;
+      }
+      int n_w = 0;
+      for (int c = 0; c < op.in.C; ++c) n_w += written[op.in.buf][op.in.coff + c];
+      JN_CHECK(n_w == 0 || n_w == op.in.C, JN_EINVAL, "backward plan: partially written gradient view (head op %s)", op.name.c_str());
+      op.acc_in = n_w == op.in.C;
+      for (int c = 0; c < op.in.C; ++c) written[op.in.buf][op.in.coff + c] = 1;
+    }
+  }
   // buffer / table / stats offsets grew with the head
   net.buf_off.resize(net.bufs.size());
   size_t off = 0;

@@ -237,7 +237,7 @@ class GPT(nn.Module):
         eng = self._engine
         with torch.no_grad():
             for name, p in self.named_parameters():
-                if name.startswith("yolox") or not p.requires_grad:
+                if not p.requires_grad:
                     continue
                 host = torch.empty(p.shape, dtype=torch.float32)
                 check(eng.lib.jn_read_param(eng.handle, name.encode(), host.data_ptr(), host.numel()), "jn_read_param")

@@ -174,18 +174,29 @@ class ReinforceTrainer:
         if self.config.reward_norm:
             lm = buf["logit_masks"][:, :S].bool()
             self.last_return_values.append(buf["returns"][:, :S][lm].clone())
+        # detector training step on the patches that hold boxes (+ negatives), src/reinforce.py:330-339
+        detection = bool(getattr(self.config, "detection_enabled", False)) and self.yolox_model() is not None
+        yolo_losses = {}
+        if detection:
+            patches_y, boxes_y = env.get_detection_batch(int(getattr(self.config, "detection_sample_neg", 1)))
+            _, _, yolo_losses = self.yolox_model()(patches_y, boxes_y, loss_scale=1.0 / ga)
         if optimizer_step and self.iter_num % ga == 0:
             # the ONE exchange step of the iteration: flat gradient all-reduce (RCCL over xGMI)
             from .dist import allreduce_gradients
-            scale = allreduce_gradients(grads, self._optim_numel, process_group)
+            scale = allreduce_gradients(grads, grads.numel() if detection else self._optim_numel, process_group)
             lr = float(getattr(self.config, "learning_rate", 1e-4))
             check(eng.lib.jn_optimizer_step(eng.handle, lr, 0.01, 1.0, scale, stream), "jn_optimizer_step")
+            if detection:                          # optim_yolox.step(), src/reinforce.py:348-350
+                ylr = float(getattr(self.config, "yolo_lr", lr))
+                check(eng.lib.jn_optimizer_step_group(eng.handle, 1, ylr, 0.01, 1.0, scale, stream), "jn_optimizer_step_group")
             grads.zero_()
             if self.config.reward_norm:
                 self._compute_last_returns_mean_std()
         self._last_train_buffers = buf
-        return {"action_loss": m[0], "entropy_loss": m[1], "loss": m[2], "returns": m[3], "episode_length": m[4],
-                "steps": S}
+        res = {"action_loss": m[0], "entropy_loss": m[1], "loss": m[2], "returns": m[3], "episode_length": m[4], "steps": S}
+        for k, v in yolo_losses.items():
+            res["yolo_" + k] = v
+        return res
 
     def compute_metrics(self, rollout: Dict[str, torch.Tensor], env: NeedleGeneralEnv = None):
         """src/reinforce.py:217-265."""

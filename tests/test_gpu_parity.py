@@ -653,6 +653,92 @@ def test_rollout_with_detection_vs_oracle():
                 _same_boxes(g.cpu(), r, 1e-3 * P)
 
 
+@pytest.mark.parametrize("ip,P,N", [("yolox-s", 96, 3), ("yolox-nano", 128, 2)])
+def test_detector_training_step_vs_oracle(ip, P, N):
+    """NeedleYOLOX.forward(patches, targets) loss branch + backward: SimOTA assignment, the five
+    loss terms and every yolox.* gradient (PAFPN, head convs, predictors; train-mode BN) against torch autograd on
+    the CPU oracle (the YOLOX package is not in the reference tree: parity is against the restated algorithm)."""
+    product, oracle = _detector_pair(P, 0.5, image_processor=ip, max_batch=N)
+    g = torch.Generator().manual_seed(31)
+    x = _blocky_images(N, P, 8)
+    tg = torch.zeros((N, 3, 5))
+    tg[0, 0] = torch.tensor([0, 10, 14, 60, 70.])
+    tg[1, 0] = torch.tensor([0, 30, 30, 90, 64.])
+    tg[1, 1] = torch.tensor([0, 4, 50, 30, 90.])
+    if N > 2:
+        tg[2, 1] = torch.tensor([0, 40, 8, 80, 40.])          # a padding row BEFORE the box: the published head then
+                                                               # takes row 0 (zeros) as the box — reproduced
+    import copy
+    det64 = copy.deepcopy(oracle.yolox).double().train()        # conditioning reference: the same graph in fp64
+    _, _, ref64 = det64(x.double(), tg.double())
+    ref64["total_loss"].backward()
+    g64 = {n: p.grad for n, p in det64.named_parameters() if p.grad is not None}
+    det = oracle.yolox.train()
+    det.zero_grad()
+    _, _, ref = det(x, tg)
+    ref["total_loss"].backward()
+    product.engine_zero_grad()
+    _, _, got = product.yolox(x, tg)
+    for k in ("total_loss", "iou_loss", "conf_loss", "cls_loss", "l1_loss", "num_fg"):
+        r, v = float(ref[k]), float(got[k])
+        assert abs(v - r) < 2e-3 * max(1.0, abs(r)), (k, v, r)
+    grads = product.engine_grads("yolox.")
+    checked = 0
+    for name, p in det.named_parameters():
+        if p.grad is None:
+            continue
+        gp, rg = grads["yolox." + name], p.grad
+        scale = rg.abs().max().item()
+        if scale < 1e-10:
+            assert gp.abs().max().item() < 1e-7, name
+            continue
+        # the class-branch gradient is sigmoid(logit) - IoU at a handful of anchors: where the two nearly cancel, fp32
+        # itself is only good to a few per cent (the fp32 oracle's own distance to fp64 measures that)
+        cond = (rg.double() - g64[name]).abs().max().item() / scale
+        err = (gp.double() - g64[name]).abs().max().item() / scale
+        assert err < max(5e-3, 8.0 * cond), (name, err, cond, scale)
+        checked += 1
+    assert checked > 100
+    # optim_yolox.step(): AdamW with clip_grad_value_(1) on the yolox.* group only
+    params = [p for _, p in det.named_parameters()]
+    # compare the update where the gradient is well above the parity noise of the (unclipped) gradient
+    bigs = {n: p.grad.abs() > 2e-2 * p.grad.abs().max() for n, p in det.named_parameters()}
+    torch.nn.utils.clip_grad_value_(params, 1)
+    before = {n: p.detach().clone() for n, p in det.named_parameters()}
+    torch.optim.AdamW(params, lr=1e-3).step()
+    eng = product.engine()
+    _lib.check(eng.lib.jn_optimizer_step_group(eng.handle, 1, 1e-3, 0.01, 1.0, 1.0, None), "step")
+    product.pull_parameters()
+    sd = product.state_dict()
+    for name, p in det.named_parameters():
+        big = bigs[name]
+        if big.any():
+            upd_ref, upd = (p.detach() - before[name])[big], (sd["yolox." + name].cpu() - before[name])[big]
+            assert (upd - upd_ref).abs().max() < 5e-5, name
+
+
+def test_reinforce_iteration_with_detector_training():
+    """src/reinforce.py:326-353 with detection_enabled: the REINFORCE step and the detector step share one
+    iteration; optim_gpt updates everything but yolox.*, optim_yolox (yolo_lr) the detector."""
+    P, Tn, B = 64, 3, 2
+    product, _ = _detector_pair(P, 0.5, image_processor="yolox-nano", max_batch=8)    # 11 detection patches: two chunks
+    images, bboxes, start = synth_batch(B, 3, 3, P, seed=8)
+    env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True)
+    cfg = _cfg(T=Tn, learning_rate=1e-3, gradient_accumulation=1)
+    cfg.detection_enabled, cfg.yolo_lr = True, 2e-3
+    before = {k: v.clone() for k, v in product.state_dict().items()}
+    tr = ja.ReinforceTrainer(cfg, product)
+    m = tr.train_iteration(env, start_positions=start)
+    for k in ("loss", "yolo_total_loss", "yolo_iou_loss", "yolo_conf_loss", "yolo_cls_loss", "yolo_l1_loss", "yolo_num_fg"):
+        assert k in m and torch.isfinite(torch.as_tensor(float(m[k]))), k
+    product.pull_parameters()
+    after = product.state_dict()
+    kd, kg = "yolox.head.obj_preds.0.weight", "transformer.wte.weight"
+    d_det = (after[kd].cpu() - before[kd].cpu()).abs().max().item()
+    d_gpt = (after[kg].cpu() - before[kg].cpu()).abs().max().item()
+    assert 1e-3 < d_det < 2.5e-3 and 5e-4 < d_gpt < 1.2e-3, (d_det, d_gpt)     # first AdamW step ~ its group's lr
+
+
 def test_eval_on_batch_detection_metrics_vs_oracle():
     """eval_on_sample of the reference (src/reinforce.py:424-497): greedy rollout with detection, boxes moved to
     full-image coordinates, mAP-50 against the split ground-truth boxes — the GPU rollout's metric equals the one
