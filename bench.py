@@ -58,6 +58,55 @@ def synth_inputs(B, G, P, seed, device):
     return images, bboxes, start
 
 
+def bench_detector(args, ja, model_config, dev, rank, world, dist):
+    """Secondary workload: NeedleYOLOX loss branch + backward + optim_yolox step on B patches."""
+    import ctypes as C
+    from jolineedle_amd import _lib
+    B, P = args.batch, args.patch_size
+    model = ja.GPT(model_config(patch_size=P, block_size=4, image_processor="yolox-s"), max_batch=B, device=str(dev))
+    model.sync_weights()
+    gen = torch.Generator(device=dev).manual_seed(12345 + rank)
+    patches = torch.rand((B, 3, P, P), device=dev, generator=gen)
+    g = torch.Generator().manual_seed(7 + rank)
+    tg = torch.zeros((B, 3, 5))
+    for b in range(B):
+        for k in range(int(torch.randint(0, 3, (1,), generator=g))):
+            w, h = (int(torch.randint(24, P // 2, (1,), generator=g)) for _ in range(2))
+            x, y = int(torch.randint(0, P - w, (1,), generator=g)), int(torch.randint(0, P - h, (1,), generator=g))
+            tg[b, k] = torch.tensor([0.0, x, y, x + w, y + h])
+    tg = tg.to(dev)
+    eng = model.engine()
+
+    def step():
+        model.engine_zero_grad()
+        _, _, losses = model.yolox(patches, tg)
+        _lib.check(eng.lib.jn_optimizer_step_group(eng.handle, 1, 1e-4, 0.01, 1.0, 1.0, _lib.current_stream(dev)), "opt")
+        return losses
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        # yolox-s PAFPN + head @448: 3.976 + 2.521 GMAC forward per patch (SURVEY.md §8d); training ~ 3x forward
+        tflops = 3.0 * 2.0 * (3.976e9 + 2.521e9) * (P / 448.0) ** 2 * B * args.steps / dt / 1e12
+        print(json.dumps({
+            "metric": f"detector-training patches/sec ({P}px, yolox-s, SimOTA loss + backward + AdamW)",
+            "value": round(B * args.steps / dt, 1), "unit": "patches/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"secondary: NeedleYOLOX.forward(patches, targets) loss branch on {B} patches/GPU "
+                                   f"of {P}px, yolox-s detector, 0-2 boxes per patch", "global_batch": B * world},
+            "roofline": {"bound": "mfma", "kernel": "yolox-s PAFPN + head forward + backward (dense 3x3 / 1x1 on "
+                                                    "v_mfma_f32_16x16x4_f32), ~3x the forward FLOPs",
+                         "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None}}), flush=True)
+
+
 def cpu_baseline(P, T, seed, train):
     """CPU oracle (pure PyTorch fp32 restatement, oracle/) on the host cores: a bounded sample of
     the same workload — B=4 agents, T glimpse steps, 4480x4480 images would need 1 GB/agent on the
@@ -108,7 +157,9 @@ def main():
     ap.add_argument("--patch-size", type=int, default=448)
     ap.add_argument("--grid", type=int, default=10, help="image side in patches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["train", "rollout"], default="train")
+    ap.add_argument("--mode", choices=["train", "rollout", "detector"], default="train",
+                    help="train (default, the headline): full REINFORCE iteration; rollout: inference rollout; detector: "
+                         "secondary, one detector training step (yolox-s, SimOTA loss, backward, AdamW) on --batch patches")
     ap.add_argument("--config", choices=["c3", "c5"], default="c3",
                     help="c3 (default, the headline): gpt-nano + yolox-nano encoder, 448 px, T=20, B=64; "
                          "c5: gpt-mini + yolox-s encoder, 640 px, T=32, B=16 (BASELINE configs[4] topology, secondary)")
@@ -145,6 +196,8 @@ def main():
 
     B, T, P, G = args.batch, args.seq_len, args.patch_size, args.grid
     torch.manual_seed(12345)
+    if args.mode == "detector":
+        return bench_detector(args, ja, model_config, dev, rank, world, dist)
     assert not (args.dtype == "bf16" and args.mode == "train"), "bf16 is the inference mode: use --mode rollout"
     model = ja.GPT(model_config(patch_size=P, block_size=T, with_detector=False, image_processor=None,
                                 act_dtype=args.dtype, **arch),
