@@ -692,9 +692,18 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
             f.w_pw = pw.w_dev; f.out = ptr(nx.out); f.out_ld = ld(nx.out); f.dtype = net.act_dtype;
             f.C = op.out.C; f.cout = nx.out.C; f.N = N; f.H = op.in.H; f.W = op.in.W; f.OH = op.out.H; f.OW = op.out.W;
             f.stride = op.stride; f.skip_flag = skip_flag; f.skip_when = skip_when;
+            int skip_ops = 1;
+            if (oi + 2 < n_ops && net.ops[oi + 2].kind == OP_ADDACT && net.ops[oi + 2].in.buf == nx.out.buf &&
+                net.ops[oi + 2].in.coff == nx.out.coff) {
+              // bottleneck shortcut: the add + activation goes into the epilogue, the pconv's raw z is never stored
+              const Op& ad = net.ops[oi + 2];
+              f.res = ptr(ad.res); f.res_ld = ld(ad.res); f.rtab = tab(ad.res); f.ptab = tab(nx.out);
+              f.out = ptr(ad.out); f.out_ld = ld(ad.out);
+              skip_ops = 2;
+            }
             launch_dwpw(f, s);
-            if (layer_profile) { hipEventRecord(lev[oi + 1], s); hipEventRecord(lev[oi + 2], s); }
-            ++oi;
+            if (layer_profile) for (int k = 1; k <= skip_ops + 1; ++k) hipEventRecord(lev[oi + k], s);
+            oi += skip_ops;
             continue;
           }
         }

@@ -68,6 +68,8 @@ struct DwPwArgs {
   const void* in; int in_ld; ChanTab itab; const float* w_dw; ChanTab mtab; const float* w_pw;
   void* out; int out_ld; int dtype; int C, cout, N, H, W, OH, OW, stride;
   const int* skip_flag; int skip_when;
+  const void* res; int res_ld; ChanTab rtab;   // optional shortcut (eval): out = silu(bn(z)) + T(res), ptab = table of z
+  ChanTab ptab;
 };
 bool dwpw_supported(int C, int cout, int stride);
 int launch_dwpw(const DwPwArgs& a, hipStream_t s);

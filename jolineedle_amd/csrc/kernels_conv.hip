@@ -370,7 +370,8 @@ template <int S, int WM, int CT, typename AT>
 __global__ __launch_bounds__(256) void dwpw_eval_kernel(
     const AT* __restrict__ in, int in_ld, ChanTab it, const float* __restrict__ w_dw, ChanTab mt,
     const float* __restrict__ w_pw, AT* __restrict__ out, int out_ld, int C, int Nc, int H, int W, int OH, int OW,
-    int tiles_x, int tiles_y, const int* __restrict__ skip_flag, int skip_when) {
+    int tiles_x, int tiles_y, const int* __restrict__ skip_flag, int skip_when, const AT* __restrict__ res, int res_ld,
+    ChanTab rtab, ChanTab ptab) {
   if (skip_flag && *skip_flag >= skip_when) return;
   constexpr int CB = 16, Q = 4, TW = 16, TH = 2 * WM, BM = TH * TW;
   constexpr int IH = S * (TH - 1) + 3, IW = S * (TW - 1) + 3;
@@ -489,7 +490,17 @@ __global__ __launch_bounds__(256) void dwpw_eval_kernel(
 #pragma unroll
     for (int cc = 0; cc < CTW; ++cc) {
       const int nn = (wn * CTW + cc) * 16 + 4 * g;
-      if (nn < Nc) st4(op + nn, acc[p][cc]);
+      if (nn >= Nc) continue;
+      f32x4 v = acc[p][cc];
+      if (res) {
+        // bottleneck shortcut folded in (eval): out = silu(bn(z)) + T(res), a materialised activation
+        const f32x4 psc = *reinterpret_cast<const f32x4*>(ptab.sc + nn), psh = *reinterpret_cast<const f32x4*>(ptab.sh + nn);
+        const f32x4 rv = tf4(ld4(res + (((long long)n * OH + oy) * OW + ox) * res_ld + nn), *reinterpret_cast<const f32x4*>(rtab.sc + nn),
+                             *reinterpret_cast<const f32x4*>(rtab.sh + nn), *reinterpret_cast<const f32x4*>(rtab.fl + nn));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = silu(fmaf(v[k], psc[k], psh[k])) + rv[k];
+      }
+      st4(op + nn, v);
     }
   }
 }
@@ -501,7 +512,7 @@ static void launch_dwpw_t(const DwPwArgs& a, hipStream_t s) {
   const size_t smem = ((size_t)IH * IW * PS + (size_t)TH * 16 * 20 + (size_t)16 * CT * 20) * sizeof(float);
   hipLaunchKernelGGL((dwpw_eval_kernel<S, WM, CT, AT>), dim3(tiles_x * tiles_y * a.N), dim3(256), smem, s, (const AT*)a.in,
                      a.in_ld, a.itab, a.w_dw, a.mtab, a.w_pw, (AT*)a.out, a.out_ld, a.C, a.cout, a.H, a.W, a.OH, a.OW, tiles_x,
-                     tiles_y, a.skip_flag, a.skip_when);
+                     tiles_y, a.skip_flag, a.skip_when, (const AT*)a.res, a.res_ld, a.rtab, a.ptab);
 }
 
 bool dwpw_supported(int C, int cout, int stride) {
