@@ -39,8 +39,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s mea
 S_640_GMAC_PER_PATCH = 8.113e9
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
 # HBM traffic of ONE forward conv-stack pass at B=64, 448 px from the PMC counters (separate --pmc FETCH_SIZE and
-# --pmc WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM): profiles/r01_e_pmc_conv_stack_traffic.txt
-PMC_TRAFFIC_BYTES_B64_448 = 5.577e9
+# --pmc WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM, tools/pmc_traffic.py):
+# profiles/r01_f_pmc_conv_stack_traffic_{train,eval}.txt — the eval pass fuses DWConv / shortcut adds and moves
+# fewer bytes than the layer-wise algorithmic figure.
+PMC_TRAFFIC_BYTES_B64_448 = {"train": 5.683e9, "rollout": 4.401e9}
 
 
 def synth_inputs(B, G, P, seed, device):
@@ -277,7 +279,7 @@ def main():
                                                    "), one pass over the batch per glimpse step",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": (PMC_TRAFFIC_BYTES_B64_448 if (B, P, args.dtype) == (64, 448, "f32") else None),
+                         "traffic": (PMC_TRAFFIC_BYTES_B64_448[args.mode] if (B, P, args.dtype) == (64, 448, "f32") else None),
                          "ms_per_launch": round(conv_ms_per_launch, 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes)},
         }

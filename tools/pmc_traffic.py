@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter CSVs of the conv stack into HBM bytes per pass.
 
-usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <glimpse steps in the run> <batch>
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <glimpse steps in the run> <batch> [train]
+(train: counters of a `--mode train` run — only the FORWARD conv-stack kernels are summed: the data-gradient launches
+of pw_mfma_kernel carry `true` as their third template argument and are left out)
 
 Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KB;
 FETCH_SIZE reports half of the bytes of wide coalesced streaming reads, so read bytes = 2 * FETCH_SIZE * 1024.
@@ -11,7 +13,8 @@ import csv
 import re
 import sys
 
-CONV = ("stem_mfma_kernel", "dw3x3", "pw_mfma_kernel", "addact_kernel", "spp_kernel", "upsample_kernel", "conv3_mfma")
+CONV = ("stem_mfma_kernel", "dw3x3", "dwpw_eval_kernel", "pw_mfma_kernel", "addact_kernel", "spp_kernel", "upsample_kernel",
+        "conv3_mfma")
 
 
 def short(name):
@@ -20,13 +23,18 @@ def short(name):
     return re.sub(r"\(.*", "", name)
 
 
+TRAIN = False
+
+
 def load(path, counter):
     tot, calls = collections.Counter(), collections.Counter()
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
         k = short(r["Kernel_Name"])
-        if not any(c in k for c in CONV):
+        if not any(c in k for c in CONV + (("bn_finalize_kernel",) if TRAIN else ())):
+            continue
+        if TRAIN and k.startswith("pw_mfma_kernel") and ", true," in k:
             continue
         tot[k] += float(r["Counter_Value"])
         calls[k] += 1
@@ -34,6 +42,8 @@ def load(path, counter):
 
 
 def main():
+    global TRAIN
+    TRAIN = len(sys.argv) > 5 and sys.argv[5] == "train"
     fetch, calls = load(sys.argv[1], "FETCH_SIZE")
     write, _ = load(sys.argv[2], "WRITE_SIZE")
     steps, batch = int(sys.argv[3]), int(sys.argv[4])
