@@ -14,6 +14,7 @@ from .env import NeedleGeneralEnv  # noqa: F401
 from .yolox import NeedleYOLOX  # noqa: F401
 from .reinforce import ReinforceTrainer  # noqa: F401
 from .supervised import SupervisedTrainer  # noqa: F401
+from .data import padded_collate, synthetic_batch  # noqa: F401
 from .detection import (patch_bboxes2full_image, merge_boxes, merge_boxes_batched,  # noqa: F401
                         compute_detection_metrics, detection_targets)
 

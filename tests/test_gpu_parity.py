@@ -313,6 +313,27 @@ def test_rollout_forced_vs_oracle(stop, B, P, Tn):
     assert torch.equal(ro["patches"].cpu(), ref["patches"])       # bit exact gather inside the loop
 
 
+def test_rollout_config5_sizes_vs_oracle():
+    """BASELINE configs[4] at its real sizes on a small batch: gpt-mini (6 layers, 6 heads, C = 192) + yolox-s dense-3x3
+    encoder, 640-px patches (20 x 20 deepest map), forced rollout against the CPU oracle."""
+    from oracle import env_ref, rollout_ref
+    P, Tn, B = 640, 3, 2
+    product, oracle = make_pair(5, patch_size=P, block_size=Tn, model_type="gpt-mini", gpt_backbone="yolox-s",
+                                with_detector=False, image_processor=None, max_batch=B)
+    images, bboxes, start = synth_batch(B, 2, 3, P, seed=77)
+    forced = torch.tensor([[1, 3, 0], [2, 0, 3]])
+    with torch.no_grad():
+        ref = rollout_ref.rollout(oracle, env_ref.EnvRef(images, bboxes, P, Tn, 1, True), forced_actions=forced,
+                                  start_positions=start, stop_early=True)
+    env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True)
+    ro = ja.ReinforceTrainer(_cfg(T=Tn), product).rollout(env, forced_actions=forced, start_positions=start)
+    for k in ("masks", "logit_masks", "positions", "actions"):
+        assert torch.equal(ro[k].cpu(), ref[k]), k
+    assert torch.equal(ro["rewards"].cpu(), ref["rewards"])
+    for k in ("returns", "logprobs", "entropies", "logits"):
+        assert (ro[k].cpu() - ref[k]).abs().max() < 1e-3, k              # north-star bound
+
+
 def test_rollout_early_stop_and_full_length():
     """All agents STOP at step 2: reference breaks (reinforce.py:181-184) -> S == 2."""
     from oracle import env_ref, rollout_ref

@@ -150,3 +150,19 @@ def test_merge_boxes_groups_contiguous_pieces():
     tg = torch.tensor([[0, 410, 410, 447, 447], [0, 448, 410, 500, 447], [0, 900, 900, 950, 950]])
     assert ja.merge_boxes(tg, target=True).tolist() == [[0, 410, 410, 500, 447], [0, 900, 900, 950, 950]]
     assert ja.merge_boxes_batched([None, tg], target=True)[0] is None
+
+
+def test_padded_collate_layout():
+    """src/dataset.py:307-347: zero padding to the largest image rounded up to the patch size, zero-row padded boxes."""
+    ims = [torch.ones((3, 100, 130)), 2 * torch.ones((3, 64, 200))]
+    bbs = [torch.tensor([[1, 2, 30, 40]]), torch.tensor([[5, 5, 20, 20], [50, 10, 90, 60], [0, 0, 10, 10]])]
+    b = ja.padded_collate(ims, bbs, 64)
+    assert b["image"].shape == (2, 3, 128, 256) and b["bboxes"].shape == (2, 3, 4) and b["bboxes"].dtype == torch.long
+    assert float(b["image"][0, :, :100, :130].min()) == 1.0 and float(b["image"][0, :, 100:].abs().sum()) == 0.0
+    assert float(b["image"][1, :, :64, :200].min()) == 2.0 and float(b["image"][1, :, :, 200:].abs().sum()) == 0.0
+    assert b["bboxes"][0].tolist() == [[1, 2, 30, 40], [0, 0, 0, 0], [0, 0, 0, 0]] and b["class_id"].tolist() == [0, 0]
+    s1, s2 = ja.synthetic_batch(3, 4, 64, 7, device="cpu"), ja.synthetic_batch(3, 4, 64, 7, device="cpu")
+    assert torch.equal(s1["image"], s2["image"]) and torch.equal(s1["bboxes"], s2["bboxes"])
+    bb = s1["bboxes"]
+    valid = bb.abs().sum(-1) > 0
+    assert valid[:, 0].all() and (bb[valid][:, 2] <= 256).all() and (bb[valid][:, 2] > bb[valid][:, 0]).all()
