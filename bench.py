@@ -165,6 +165,8 @@ def main():
     ap.add_argument("--config", choices=["c3", "c5"], default="c3",
                     help="c3 (default, the headline): gpt-nano + yolox-nano encoder, 448 px, T=20, B=64; "
                          "c5: gpt-mini + yolox-s encoder, 640 px, T=32, B=16 (BASELINE configs[4] topology, secondary)")
+    ap.add_argument("--detect", action="store_true",
+                    help="rollout mode only (secondary): run the yolox-s detector on every visited patch (do_detection)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="activation storage / MFMA type; bf16 is the inference (rollout) mode only")
     args = ap.parse_args()
@@ -201,8 +203,12 @@ def main():
     if args.mode == "detector":
         return bench_detector(args, ja, model_config, dev, rank, world, dist)
     assert not (args.dtype == "bf16" and args.mode == "train"), "bf16 is the inference mode: use --mode rollout"
-    model = ja.GPT(model_config(patch_size=P, block_size=T, with_detector=False, image_processor=None,
-                                act_dtype=args.dtype, **arch),
+    if args.detect:
+        assert args.mode == "rollout", "--detect belongs to --mode rollout"
+        arch = dict(arch, with_detector=True, image_processor="yolox-s")
+    else:
+        arch = dict(arch, with_detector=False, image_processor=None)
+    model = ja.GPT(model_config(patch_size=P, block_size=T, act_dtype=args.dtype, **arch),
                    max_batch=B, device=f"cuda:{local_rank}")
     model.sync_weights()
     cfg = ja.CfgNode(max_seq_len=T, entropy_weight=0.01, stop_enabled=True, reward_norm=True, seed=12345 + rank,
@@ -220,7 +226,8 @@ def main():
         if train:
             m = trainer.train_iteration(env, forced_actions=forced, start_positions=start)
             return m["steps"], m["loss"]
-        ro = trainer.rollout(env, forced_actions=forced, start_positions=start, keep_patches=False)
+        ro = trainer.rollout(env, forced_actions=forced, start_positions=start, keep_patches=False,
+                             do_detection=args.detect)
         m = trainer.compute_metrics(ro)
         return ro["rewards"].shape[1], m["loss"]
 
@@ -283,6 +290,9 @@ def main():
                          "ms_per_launch": round(conv_ms_per_launch, 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes)},
         }
+        if args.detect:
+            out["metric"] += " + yolox-s detection on every visited patch"
+            out["config"]["phase"] += "; do_detection=True (yolox-s PAFPN + head + NMS per glimpse)"
         if args.config == "c5":
             tflops = 2.0 * S_640_GMAC_PER_PATCH * (P / 640.0) ** 2 * B / (conv_ms_per_launch * 1e-3) / 1e12
             out["metric"] = f"glimpse-patches/sec ({P}px, seq-len {T}) REINFORCE step, gpt-mini + yolox-s encoder"

@@ -4,6 +4,8 @@
 // src/models/yolox.py:55, 77-86, 93-113).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "jn_kernels.h"
 #include "jn_reduce.h"
 #include "jn_types.h"
@@ -133,6 +135,98 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const AT* __restrict__ 
   }
 }
 
+// bf16 inference mode: the same nine-shifted-GEMMs scheme on v_mfma_f32_16x16x32_bf16 (16x the fp32 MFMA rate; the
+// detector is MFMA-bound: 13 GFLOP per 448-px patch).  bf16 activations in and out, fp32 master weights converted
+// while staging, fp32 accumulation.  K chunk = 32 = one MFMA k-step per tap; rows of 8 consecutive k per lane.
+constexpr int C3B_KC = 32, C3B_LD = C3B_KC + 8;
+constexpr int C3B_TH = 16;          // 16 x 16 pixels per workgroup (wave = 4 rows): the 9 x 64 x 32 weight tile is staged once per 256 pixels
+
+template <int S>
+__global__ __launch_bounds__(256) void conv3_bf16_kernel(const bf16_t* __restrict__ x, int x_ld, ChanTab it,
+                                                         const float* __restrict__ w, bf16_t* __restrict__ out,
+                                                         int out_ld, int H, int W, int OH, int OW, int K, int Nc,
+                                                         int tiles_x, int tiles_y, const int* __restrict__ skip_flag,
+                                                         int skip_when) {
+  if (skip_flag && *skip_flag >= skip_when) return;
+  constexpr int IH = C3B_TH * S + 2, IW = C3_TW * S + 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  bf16_t* Xs = reinterpret_cast<bf16_t*>(smem_b);      // [IH*IW][C3B_LD]
+  bf16_t* Ws = Xs + IH * IW * C3B_LD;                  // [9][C3_BN][C3B_LD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x % (tiles_x * tiles_y);
+  const int n_img = blockIdx.x / (tiles_x * tiles_y);
+  const int oy0 = (tile / tiles_x) * C3B_TH, ox0 = (tile % tiles_x) * C3_TW;
+  const int n0 = blockIdx.y * C3_BN;
+  const bf16_t* xb = x + (long long)n_img * H * W * x_ld;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += C3B_KC) {
+    if (k0) __syncthreads();
+    for (int i = tid; i < IH * IW * (C3B_KC / 4); i += 256) {
+      const int pix = i / (C3B_KC / 4), q = i % (C3B_KC / 4);
+      const int iy = oy0 * S - 1 + pix / IW, ix = ox0 * S - 1 + pix % IW;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int kk = k0 + 4 * q;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W && kk < K)
+        v = tf4_d(ld4(xb + ((long long)iy * W + ix) * x_ld + kk), *reinterpret_cast<const f32x4*>(it.sc + kk),
+                  *reinterpret_cast<const f32x4*>(it.sh + kk), *reinterpret_cast<const f32x4*>(it.fl + kk));
+      st4(Xs + pix * C3B_LD + 4 * q, v);
+    }
+    for (int i = tid; i < 9 * C3_BN * (C3B_KC / 4); i += 256) {
+      const int q = i % (C3B_KC / 4), r = (i / (C3B_KC / 4)) % C3_BN, tp = i / ((C3B_KC / 4) * C3_BN);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n0 + r < Nc && k0 + 4 * q < K) v = *reinterpret_cast<const f32x4*>(w + ((long long)tp * Nc + n0 + r) * K + k0 + 4 * q);
+      st4(Ws + (tp * C3_BN + r) * C3B_LD + 4 * q, v);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      const int ky = tp / 3, kx = tp % 3;
+      bf16x8 xbv[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        xbv[p] = *reinterpret_cast<const bf16x8*>(Xs + (((4 * wave + p) * S + ky) * IW + lm * S + kx) * C3B_LD + 8 * g);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bf16x8 wa = *reinterpret_cast<const bf16x8*>(Ws + (tp * C3_BN + 16 * c + lm) * C3B_LD + 8 * g);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xbv[p], acc[p][c], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int oy = oy0 + 4 * wave + p, ox = ox0 + lm;
+    if (oy >= OH || ox >= OW) continue;
+    bf16_t* op = out + (((long long)n_img * OH + oy) * OW + ox) * out_ld;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int n = n0 + 16 * c + 4 * g;
+      if (n < Nc) st4(op + n, acc[p][c]);
+    }
+  }
+}
+
+template <int S>
+static void launch_conv3_bf16(const ConvArgs& a, hipStream_t s) {
+  const int tiles_x = (a.OW + C3_TW - 1) / C3_TW, tiles_y = (a.OH + C3B_TH - 1) / C3B_TH;
+  dim3 grid(tiles_x * tiles_y * a.N, (a.cout + C3_BN - 1) / C3_BN);
+  const size_t smem = ((size_t)(S * C3B_TH + 2) * (S * C3_TW + 2) + 9 * C3_BN) * C3B_LD * sizeof(bf16_t);
+  if (smem > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bf16_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL((conv3_bf16_kernel<S>), grid, dim3(256), smem, s, (const bf16_t*)a.in, a.in_ld, a.itab, a.w, (bf16_t*)a.out,
+                     a.out_ld, a.H, a.W, a.OH, a.OW, a.cin, a.cout, tiles_x, tiles_y, a.skip_flag, a.skip_when);
+}
+
 template <int S, typename AT, bool WT>
 static void launch_conv3_t(const ConvArgs& a, hipStream_t s) {
   const int tiles_x = (a.OW + C3_TW - 1) / C3_TW, tiles_y = (a.OH + C3_TH - 1) / C3_TH;
@@ -155,6 +249,11 @@ int launch_conv3(const ConvArgs& a, hipStream_t s) {
   if (a.w_transposed) {               // data gradient of a stride-1 layer (fp32 gradient buffers)
     if (a.stride != 1 || a.in_dtype != JN_F32 || a.cin % 4) return -1;
     launch_conv3_t<1, float, true>(a, s);
+    return 0;
+  }
+  static const bool no_bf16_conv3 = std::getenv("JN_NO_BF16_CONV3") != nullptr;
+  if (!no_bf16_conv3 && a.in_dtype == JN_BF16 && a.out_dtype == JN_BF16 && !a.stats && !a.accumulate && a.cin % 4 == 0) {
+    if (a.stride == 1) launch_conv3_bf16<1>(a, s); else launch_conv3_bf16<2>(a, s);
     return 0;
   }
   if (a.in_dtype == JN_BF16) { if (a.stride == 1) launch_conv3_t<1, bf16_t, false>(a, s); else launch_conv3_t<2, bf16_t, false>(a, s); }

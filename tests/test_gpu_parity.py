@@ -569,9 +569,9 @@ def _blocky_images(N, P, seed):
     return (x / 3 + 0.1 * torch.rand(N, 3, P, P, generator=g)).clamp(0, 1)
 
 
-def _detector_pair(P, thr, image_processor="yolox-s", max_batch=4, seed=9, calib=None):
+def _detector_pair(P, thr, image_processor="yolox-s", max_batch=4, seed=9, calib=None, **kw):
     product, oracle = make_pair(seed, patch_size=P, block_size=4, image_processor=image_processor,
-                                detector_conf_threshold=thr, max_batch=max_batch, max_det_per_patch=512)
+                                detector_conf_threshold=thr, max_batch=max_batch, max_det_per_patch=512, **kw)
     if calib is not None:                       # BN running statistics of real activations (signal survives the depth)
         bns = [m for m in oracle.yolox.modules() if isinstance(m, torch.nn.BatchNorm2d)]
         for m in bns:
@@ -615,6 +615,45 @@ def test_detector_backbone_and_raw_head(P, ip):
     assert A == sum((P // s) ** 2 for s in (8, 16, 32))
     assert (got_raw.cpu()[..., :4] - raw[..., :4]).abs().max() < 1e-3 * max(1.0, P / 64)   # boxes, pixels
     assert (got_raw.cpu()[..., 4:] - raw[..., 4:]).abs().max() < 1e-5                      # obj / cls probabilities
+
+
+def _bf16_emulated_backbone(net, x):
+    """The same graph with every conv's operands (activations, weights) and output rounded to bf16 on the CPU: what
+    bf16 storage + bf16 MFMA operands cost on this network, independent of any kernel."""
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    hooks, saved = [], []
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                saved.append((m, m.weight.data.clone()))
+                if m.in_channels != 12:                          # the stem reads the fp32 image with fp32 weights
+                    m.weight.data.copy_(bf(m.weight.data))
+                hooks.append(m.register_forward_pre_hook(lambda mod, inp: (inp[0] if mod.in_channels == 12 else bf(inp[0]),)))
+                hooks.append(m.register_forward_hook(lambda mod, inp, out: bf(out)))
+        out = net(x)
+        for h in hooks:
+            h.remove()
+        for m, w in saved:
+            m.weight.data.copy_(w)
+    return out
+
+
+@pytest.mark.parametrize("P", [96, 448])
+def test_bf16_mode_detector_backbone(P):
+    """bf16 inference mode of the yolox-s detector (dense 3x3 convs on v_mfma_f32_16x16x32_bf16).  A random-init
+    yolox-s is badly conditioned under bf16 (the CPU graph with bf16-rounded conv operands / outputs is itself ~7 % off
+    the fp32 one), so the bar is: the HIP path is no further from fp32 than that emulation, and agrees with it."""
+    product, oracle = _detector_pair(P, 0.5, "yolox-s", calib=_blocky_images(2, P, 3), act_dtype="bf16")
+    x = _blocky_images(2, P, 5)
+    with torch.no_grad():
+        fpn = oracle.yolox.backbone(x)
+    emu = _bf16_emulated_backbone(oracle.yolox.backbone, x)
+    got = product.backbone_features(x, net=_lib.JN_NET_DETECTOR)
+    for i in range(3):
+        g = got[i].cpu()
+        e_emu = (emu[i] - fpn[i]).abs().mean().item()
+        assert (g - fpn[i]).abs().mean().item() < 1.5 * e_emu + 1e-3 * fpn[i].abs().mean().item(), i
+        assert (g - emu[i]).abs().mean().item() < 1.5 * e_emu + 1e-3 * fpn[i].abs().mean().item(), i
 
 
 @pytest.mark.parametrize("P,keep", [(64, 20), (448, 40)])
