@@ -59,35 +59,56 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const AT* __restrict__ 
   for (int p = 0; p < 2; ++p)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < K; k0 += C3_KC) {
-    if (k0) __syncthreads();
-    for (int i = tid; i < IH * IW * 4; i += 256) {
-      const int pix = i >> 2, q = i & 3;
+  // K chunks are software-pipelined: chunk i + 1 is fetched into registers while the 288 MFMAs of chunk i run
+  constexpr int NXR = (IH * IW * 4 + 255) / 256, NWR = 9 * C3_BN * 4 / 256;
+  f32x4 xr[NXR], wr[NWR];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < NXR; ++j) {
+      const int i = tid + 256 * j, pix = i >> 2, q = i & 3;
       const int iy = oy0 * S - 1 + pix / IW, ix = ox0 * S - 1 + pix % IW;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-        const int kk = k0 + 4 * q;
-        v = tf4_d(ld4(xb + ((long long)iy * W + ix) * x_ld + kk),
-                  *reinterpret_cast<const f32x4*>(it.sc + kk), *reinterpret_cast<const f32x4*>(it.sh + kk),
-                  *reinterpret_cast<const f32x4*>(it.fl + kk));
-      }
-      *reinterpret_cast<f32x4*>(Xs + pix * C3_LD + 4 * q) = v;
+      xr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < IH * IW * 4 && iy >= 0 && iy < H && ix >= 0 && ix < W && k0 + 4 * q < K)
+        xr[j] = ld4(xb + ((long long)iy * W + ix) * x_ld + k0 + 4 * q);
     }
-    for (int i = tid; i < 9 * C3_BN * 4; i += 256) {
-      const int q = i & 3, r = (i >> 2) % C3_BN, tp = i / (4 * C3_BN);
+#pragma unroll
+    for (int j = 0; j < NWR; ++j) {
+      const int i = tid + 256 * j, q = i & 3, r = (i >> 2) % C3_BN, tp = i / (4 * C3_BN);
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (n0 + r < Nc) {
+      if (n0 + r < Nc && k0 + 4 * q < K) {
         if (WT) {
           const float* wp = w + ((long long)(8 - tp) * K + k0 + 4 * q) * Nc + n0 + r;
-          const int kr = K - (k0 + 4 * q);           // K % 4 == 0 is checked by the launcher
-          if (kr > 0) v = f32x4{wp[0], wp[Nc], wp[2 * Nc], wp[3 * Nc]};
+          v = f32x4{wp[0], wp[Nc], wp[2 * Nc], wp[3 * Nc]};
         } else {
           v = *reinterpret_cast<const f32x4*>(w + ((long long)tp * Nc + n0 + r) * K + k0 + 4 * q);
         }
       }
-      *reinterpret_cast<f32x4*>(Ws + (tp * C3_BN + r) * C3_LD + 4 * q) = v;
+      wr[j] = v;
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += C3_KC) {
+    if (k0) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NXR; ++j) {
+      const int i = tid + 256 * j, pix = i >> 2, q = i & 3;
+      if (i < IH * IW * 4) {
+        const int iy = oy0 * S - 1 + pix / IW, ix = ox0 * S - 1 + pix % IW;
+        const int kk = k0 + 4 * q;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W && kk < K)
+          v = tf4_d(xr[j], *reinterpret_cast<const f32x4*>(it.sc + kk), *reinterpret_cast<const f32x4*>(it.sh + kk),
+                    *reinterpret_cast<const f32x4*>(it.fl + kk));
+        *reinterpret_cast<f32x4*>(Xs + pix * C3_LD + 4 * q) = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NWR; ++j) {
+      const int i = tid + 256 * j, q = i & 3, r = (i >> 2) % C3_BN, tp = i / (4 * C3_BN);
+      *reinterpret_cast<f32x4*>(Ws + (tp * C3_BN + r) * C3_LD + 4 * q) = wr[j];
     }
     __syncthreads();
+    if (k0 + C3_KC < K) fetch(k0 + C3_KC);
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) {
       const int ky = tp / 3, kx = tp % 3;
