@@ -433,6 +433,7 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
   float* Gs = sm;                       // [64][LDG]  g_z tile
   float* As = Gs + 64 * LDG;            // [64][LDA]  activated input tile
   float* Wt = As + 64 * LDA;            // [K][LDW]   W^T (cin-major, cout contiguous)
+  float* Cs = Wt + K * LDW;             // [7][N] output-side constants, [3][K] input table
   float* Ts = sm;                       // [N][K]     cross-wave dW sum; reuses the tile space after the loop
   {
     const long long sl = blockIdx.y;
@@ -447,17 +448,15 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
     const int n = i / K, k = i - n * K;
     Wt[k * LDW + n] = w[i];
   }
-  // per-thread channel quads of the staging loops never change (256 % (N/4) == 0, 256 % (K/4) == 0)
+  // per-thread channel quads of the staging loops never change (256 % (N/4) == 0, 256 % (K/4) == 0); the per-channel
+  // constants live in LDS (7 x N + 3 x K floats) rather than in 40 registers: with them in registers the 64x64 layers
+  // sat at one wave per SIMD
   const int nq = tid % (N / 4), kq = tid % (K / 4);
-  f32x4 o_sc, o_sh, o_mean, o_istd, o_c1, o_c2, o_k;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int c = 4 * nq + q;
-    o_sc[q] = ot.sc[c]; o_sh[q] = ot.sh[c]; o_mean[q] = save[2 * c]; o_istd[q] = save[2 * c + 1];
-    o_c1[q] = consts[3 * c]; o_c2[q] = consts[3 * c + 1]; o_k[q] = consts[3 * c + 2];
+  for (int c = tid; c < N; c += 256) {
+    Cs[c] = ot.sc[c]; Cs[N + c] = ot.sh[c]; Cs[2 * N + c] = save[2 * c]; Cs[3 * N + c] = save[2 * c + 1];
+    Cs[4 * N + c] = consts[3 * c]; Cs[5 * N + c] = consts[3 * c + 1]; Cs[6 * N + c] = consts[3 * c + 2];
   }
-  const f32x4 i_sc = *reinterpret_cast<const f32x4*>(it.sc + 4 * kq), i_sh = *reinterpret_cast<const f32x4*>(it.sh + 4 * kq),
-              i_fl = *reinterpret_cast<const f32x4*>(it.fl + 4 * kq);
+  for (int c = tid; c < K; c += 256) { Cs[7 * N + c] = it.sc[c]; Cs[7 * N + K + c] = it.sh[c]; Cs[7 * N + 2 * K + c] = it.fl[c]; }
   f32x4 dw[CTN][CTK];
 #pragma unroll
   for (int a = 0; a < CTN; ++a)
@@ -490,6 +489,10 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
       if (i < 64 * (N / 4)) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (m0 + r < M) {
+          const f32x4 o_sc = *reinterpret_cast<const f32x4*>(Cs + 4 * nq), o_sh = *reinterpret_cast<const f32x4*>(Cs + N + 4 * nq),
+                      o_mean = *reinterpret_cast<const f32x4*>(Cs + 2 * N + 4 * nq), o_istd = *reinterpret_cast<const f32x4*>(Cs + 3 * N + 4 * nq),
+                      o_c1 = *reinterpret_cast<const f32x4*>(Cs + 4 * N + 4 * nq), o_c2 = *reinterpret_cast<const f32x4*>(Cs + 5 * N + 4 * nq),
+                      o_k = *reinterpret_cast<const f32x4*>(Cs + 6 * N + 4 * nq);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float zh = (rz[j][q] - o_mean[q]) * o_istd[q];
@@ -505,7 +508,9 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
       const int i = tid + 256 * j, r = i / (K / 4);
       if (i < 64 * (K / 4)) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m0 + r < M) v = tf4_(rx[j], i_sc, i_sh, i_fl);
+        if (m0 + r < M)
+          v = tf4_(rx[j], *reinterpret_cast<const f32x4*>(Cs + 7 * N + 4 * kq), *reinterpret_cast<const f32x4*>(Cs + 7 * N + K + 4 * kq),
+                   *reinterpret_cast<const f32x4*>(Cs + 7 * N + 2 * K + 4 * kq));
         *reinterpret_cast<f32x4*>(As + r * LDA + 4 * kq) = v;
       }
     }
@@ -585,7 +590,7 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
 template <int CTN, int CTK>
 static void launch_pw_bwd_fused_t(const PwBwdFusedArgs& a, hipStream_t s) {
   constexpr int N = 16 * CTN, K = 16 * CTK;
-  size_t smem = ((size_t)64 * (N + 4) + 64 * (K + 4) + (size_t)K * (N + 4)) * sizeof(float);
+  size_t smem = ((size_t)64 * (N + 4) + 64 * (K + 4) + (size_t)K * (N + 4) + 7 * N + 3 * K) * sizeof(float);
   if (smem < (size_t)N * K * sizeof(float)) smem = (size_t)N * K * sizeof(float);
   if (smem > 64 * 1024) {
     static bool raised = false;       // per instantiation
