@@ -796,6 +796,8 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
   float* Gs = sm;                        // [GH*GW][PS] g_z
   float* As = Gs + GH * GW * PS;         // [AH*AW][PS] activated input
   float* red = As + AH * AW * PS;        // [9][CB]
+  float* Cs = red + 9 * CB;              // [7][CB] output-side constants, [3][CB] input table, [9][CB] weights (registers
+                                         // are the occupancy limit of this kernel)
   {
     const long long sl = blockIdx.y;
     g += sl * sb.grad; z += sl * sb.act; x += sl * sb.act; gin += sl * sb.grad;
@@ -807,17 +809,15 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
   const int ncb = C / CB, cb = blockIdx.x % ncb;
   const int q = tid % Q, c = cb * CB + 4 * q;
   for (int i = tid; i < 9 * CB; i += 256) red[i] = 0.0f;
-  f32x4 wv[9];
+  for (int i = tid; i < CB; i += 256) {
+    const int cc = cb * CB + i;
+    Cs[i] = ot.sc[cc]; Cs[CB + i] = ot.sh[cc]; Cs[2 * CB + i] = save[2 * cc]; Cs[3 * CB + i] = save[2 * cc + 1];
+    Cs[4 * CB + i] = consts[3 * cc]; Cs[5 * CB + i] = consts[3 * cc + 1]; Cs[6 * CB + i] = consts[3 * cc + 2];
+    Cs[7 * CB + i] = it.sc[cc]; Cs[8 * CB + i] = it.sh[cc]; Cs[9 * CB + i] = it.fl[cc];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(w + t * C + c);
-  f32x4 o_sc, o_sh, o_mean, o_istd, o_c1, o_c2, o_k;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    o_sc[k] = ot.sc[c + k]; o_sh[k] = ot.sh[c + k]; o_mean[k] = save[2 * (c + k)]; o_istd[k] = save[2 * (c + k) + 1];
-    o_c1[k] = consts[3 * (c + k)]; o_c2[k] = consts[3 * (c + k) + 1]; o_k[k] = consts[3 * (c + k) + 2];
+    for (int t = 0; t < 9; ++t) Cs[(10 + t) * CB + i] = w[t * C + cc];
   }
-  const f32x4 i_sc = *reinterpret_cast<const f32x4*>(it.sc + c), i_sh = *reinterpret_cast<const f32x4*>(it.sh + c),
-              i_fl = *reinterpret_cast<const f32x4*>(it.fl + c);
+#define JN_C4(ROW) (*reinterpret_cast<const f32x4*>(Cs + (ROW) * CB + 4 * q))
   f32x4 dw[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) dw[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -837,6 +837,8 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
         const long long pix = ((long long)n * OH + oy) * OW + ox;
         const f32x4 gv = *reinterpret_cast<const f32x4*>(g + pix * g_ld + c);
         const f32x4 zv = *reinterpret_cast<const f32x4*>(z + pix * z_ld + c);
+        const f32x4 o_sc = JN_C4(0), o_sh = JN_C4(1), o_mean = JN_C4(2), o_istd = JN_C4(3), o_c1 = JN_C4(4), o_c2 = JN_C4(5),
+                    o_k = JN_C4(6);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float zh = (zv[k] - o_mean[k]) * o_istd[k];
@@ -851,7 +853,7 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
       const int iy = ay0 + r, ix = ax0 + cx;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-        v = tf4_(*reinterpret_cast<const f32x4*>(x + (((long long)n * H + iy) * W + ix) * x_ld + c), i_sc, i_sh, i_fl);
+        v = tf4_(*reinterpret_cast<const f32x4*>(x + (((long long)n * H + iy) * W + ix) * x_ld + c), JN_C4(7), JN_C4(8), JN_C4(9));
       *reinterpret_cast<f32x4*>(As + p * PS + 4 * q) = v;
     }
     __syncthreads();
@@ -866,7 +868,7 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
-            acc += *reinterpret_cast<const f32x4*>(Gs + ((y + 2 - ky) * GW + xx + 2 - kx) * PS + 4 * q) * wv[ky * 3 + kx];
+            acc += *reinterpret_cast<const f32x4*>(Gs + ((y + 2 - ky) * GW + xx + 2 - kx) * PS + 4 * q) * JN_C4(10 + ky * 3 + kx);
             dw[ky * 3 + kx] += gc * *reinterpret_cast<const f32x4*>(As + ((y + ky) * AW + xx + kx) * PS + 4 * q);
           }
         const int iy = oy0 + y, ix = ox0 + xx;
@@ -887,10 +889,10 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
             dw[ky * 3 + kx] += g00 * *reinterpret_cast<const f32x4*>(As + ((2 * y + ky) * AW + 2 * xx + kx) * PS + 4 * q);
         // the 2 x 2 input block (2y + dy, 2xx + dx): taps with (dy + 1 - ky), (dx + 1 - kx) even
         f32x4 r[4];
-        r[0] = g00 * wv[4];                                              // (even, even): ky = kx = 1
-        r[1] = g01 * wv[3] + g00 * wv[5];                                // (even, odd): ky = 1, kx = 0 | 2
-        r[2] = g10 * wv[1] + g00 * wv[7];                                // (odd, even): kx = 1, ky = 0 | 2
-        r[3] = g11 * wv[0] + g10 * wv[2] + g01 * wv[6] + g00 * wv[8];    // (odd, odd)
+        r[0] = g00 * JN_C4(14);                                                      // (even, even): ky = kx = 1
+        r[1] = g01 * JN_C4(13) + g00 * JN_C4(15);                                    // (even, odd): ky = 1, kx = 0 | 2
+        r[2] = g10 * JN_C4(11) + g00 * JN_C4(17);                                    // (odd, even): kx = 1, ky = 0 | 2
+        r[3] = g11 * JN_C4(10) + g10 * JN_C4(12) + g01 * JN_C4(16) + g00 * JN_C4(18);   // (odd, odd)
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           const int iy = 2 * (oy0 + y) + (d >> 1), ix = 2 * (ox0 + xx) + (d & 1);
@@ -917,6 +919,7 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
   __syncthreads();
   float* dst = (rep ? gw + ((wg + 5 * blockIdx.y) % JN_NREP) * JN_WPART_MAX : gw);
   for (int i = tid; i < 9 * CB; i += 256) atomicAdd(&dst[(i / CB) * C + cb * CB + (i % CB)], red[i]);
+#undef JN_C4
 }
 
 template <int S, int CB>
@@ -924,7 +927,7 @@ static void launch_dw_bwd_fused_t(const DwBwdFusedArgs& a, hipStream_t s) {
   constexpr int PS = S == 1 ? CB : CB + 4;
   constexpr int GH = S == 1 ? DF_TH + 2 : DF_TH + 1, GW = S == 1 ? DF_TW + 2 : DF_TW + 1;
   constexpr int AH = S == 1 ? DF_TH + 2 : 2 * DF_TH + 1, AW = S == 1 ? DF_TW + 2 : 2 * DF_TW + 1;
-  const size_t smem = ((size_t)(GH * GW + AH * AW) * PS + 9 * CB) * sizeof(float);
+  const size_t smem = ((size_t)(GH * GW + AH * AW) * PS + 9 * CB + 19 * CB) * sizeof(float);
   const int tiles_x = (a.OW + DF_TW - 1) / DF_TW, tiles_y = (a.OH + DF_TH - 1) / DF_TH;
   const int n_tiles = tiles_x * tiles_y * a.N, ncb = a.C / CB;
   int n_wg = 1536 / (ncb * a.sb.n);                 // persistent: one set of weight-gradient atomics per workgroup
