@@ -778,9 +778,9 @@ int launch_dw_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, 
 // gradient from LDS.  HBM traffic ~ (8 B/output + 4 B/input) x halo factor + 4 B/input written, instead of
 // bn_bwd_gz (12) + dw_bwd_data (4 + 4) + dw_bwd_weight (4 + 4).  Tile = 8 x 16 output pixels, CB channels;
 // stride 2: thread (a, b) owns output pixel (a, b) and the 2 x 2 input block under it.
-constexpr int DF_TH = 8, DF_TW = 16;
+constexpr int DF_TW = 16;
 
-template <int S, int CB>
+template <int S, int CB, int DF_TH>
 __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
     const float* __restrict__ g, int g_ld, const float* __restrict__ z, int z_ld, ChanTab ot,
     const float* __restrict__ save, const float* __restrict__ consts, const float* __restrict__ x, int x_ld,
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
 #undef JN_C4
 }
 
-template <int S, int CB>
+template <int S, int CB, int DF_TH>
 static void launch_dw_bwd_fused_t(const DwBwdFusedArgs& a, hipStream_t s) {
   constexpr int PS = S == 1 ? CB : CB + 4;
   constexpr int GH = S == 1 ? DF_TH + 2 : DF_TH + 1, GW = S == 1 ? DF_TW + 2 : DF_TW + 1;
@@ -934,7 +934,7 @@ static void launch_dw_bwd_fused_t(const DwBwdFusedArgs& a, hipStream_t s) {
   if (n_wg < 8) n_wg = 8;
   if (n_wg > n_tiles) n_wg = n_tiles;
   const int rep = (a.wpart && 9 * a.C <= JN_WPART_MAX) ? 1 : 0;
-  hipLaunchKernelGGL((dw_bwd_fused_kernel<S, CB>), dim3((unsigned)(n_wg * ncb), a.sb.n), dim3(256), smem, s, a.g, a.g_ld, a.z,
+  hipLaunchKernelGGL((dw_bwd_fused_kernel<S, CB, DF_TH>), dim3((unsigned)(n_wg * ncb), a.sb.n), dim3(256), smem, s, a.g, a.g_ld, a.z,
                      a.z_ld, a.ot, a.save, a.consts, a.x, a.x_ld, a.it, a.w, a.gin, a.gin_ld, a.accumulate,
                      rep ? a.wpart : a.gw, rep, a.C, a.H, a.W, a.OH, a.OW, tiles_x, tiles_y, n_tiles, a.sb);
   if (rep) launch_wpart_reduce(a.gw, a.wpart, 9 * a.C, s);
@@ -946,8 +946,8 @@ bool dw_bwd_fused_supported(int C, int H, int W, int OH, int OW, int stride) {
 }
 
 int launch_dw_bwd_fused(const DwBwdFusedArgs& a, hipStream_t s) {
-  if (a.stride == 1) { if (a.C % 32 == 0) launch_dw_bwd_fused_t<1, 32>(a, s); else launch_dw_bwd_fused_t<1, 16>(a, s); }
-  else launch_dw_bwd_fused_t<2, 16>(a, s);
+  if (a.stride == 1) { if (a.C % 32 == 0) launch_dw_bwd_fused_t<1, 32, 8>(a, s); else launch_dw_bwd_fused_t<1, 16, 8>(a, s); }
+  else launch_dw_bwd_fused_t<2, 16, 4>(a, s);       // stride 2: 4-row tiles halve the LDS tiles (more workgroups per CU)
   return 0;
 }
 
