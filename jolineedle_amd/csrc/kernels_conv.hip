@@ -748,7 +748,7 @@ template <int CT, bool WT, int WM, typename IT, typename OT, bool BF>
 static void launch_pw_cfg(const ConvArgs& a, long long M, hipStream_t s) {
   // K chunk: 64 wherever the tiles fit in 64 KB of LDS (fewer load -> LDS -> MFMA round trips); layers with
   // K <= 32 / K <= 16 get narrower LDS rows: half / a quarter of the LDS per workgroup = more workgroups per CU
-  constexpr int KC = BF ? 64 : ((CT > 4 && WM == 4) ? 32 : 64);
+  constexpr int KC = BF ? 64 : ((CT > 4) ? 32 : 64);
   if constexpr (!BF && CT <= 4) {
     if constexpr (WM >= 2) {
       if (a.cin <= 16) { launch_pw_kc<CT, 16, WT, WM, IT, OT, BF>(a, M, s); return; }
