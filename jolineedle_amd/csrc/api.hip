@@ -245,7 +245,25 @@ int pack_conv(jn_ctx* ctx, const TensorMap& tm, ConvW& cw, OpKind kind) {
   } else {
     return JN_OK;
   }
-  return store_param(ctx, wname, packed, pk, cw.cout, cw.cin, 0, &cw.w_dev);
+  int rcs = store_param(ctx, wname, packed, pk, cw.cout, cw.cin, 0, &cw.w_dev);
+  if (rcs == JN_OK && kind == OP_CONV3 && ctx->cfg.act_dtype == JN_BF16) {
+    // bf16 inference mode: the MFMA operands are bf16 anyway — round the weights once here (round to nearest even)
+    // instead of in every workgroup's staging loop
+    std::vector<uint16_t> hb(packed.size());
+    for (size_t i = 0; i < packed.size(); ++i) {
+      uint32_t u;
+      std::memcpy(&u, &packed[i], 4);
+      u += 0x7FFFu + ((u >> 16) & 1u);
+      hb[i] = (uint16_t)(u >> 16);
+    }
+    if (!cw.w_bf16) {
+      uint16_t* d = nullptr;
+      if ((rcs = dev_alloc(ctx, &d, hb.size()))) return rcs;
+      cw.w_bf16 = d;
+    }
+    JN_HIP(hipMemcpy(cw.w_bf16, hb.data(), hb.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  }
+  return rcs;
 }
 
 // get_emb(pos * inv_freq) of positional_encodings >= 6 (interleaved sin, cos), SURVEY.md §2.2
@@ -709,6 +727,7 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
         }
         ConvArgs a{};
         a.in = ptr(op.in); a.in_ld = ld(op.in); a.in_dtype = net.act_dtype; a.itab = tab(op.in); a.w = cw.w_dev;
+        a.w_bf16 = cw.w_bf16;
         a.bias = cw.b_dev; a.out = ptr(op.out); a.out_ld = ld(op.out); a.out_dtype = net.act_dtype;
         a.bf16_mfma = net.act_dtype == JN_BF16;
         a.N = N; a.H = op.in.H; a.W = op.in.W; a.OH = op.out.H; a.OW = op.out.W;

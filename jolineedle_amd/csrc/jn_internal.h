@@ -82,6 +82,7 @@ struct ConvW {
   bool has_bn = true;       // BaseConv; false = plain Conv2d with optional bias
   bool has_bias = false;    // plain Conv2d bias
   float* w_dev = nullptr;   // raw conv weight, layout depends on the op (see pack_conv)
+  void* w_bf16 = nullptr;   // dense 3x3 in bf16 inference mode: the same [tap][N][K] layout pre-rounded to bf16
   float* b_dev = nullptr;   // [cout] bias of a BN-free Conv2d (else null)
   float *gamma_dev = nullptr, *beta_dev = nullptr;     // BN affine
   float *rmean_dev = nullptr, *rvar_dev = nullptr;     // BN running statistics (updated in train mode)

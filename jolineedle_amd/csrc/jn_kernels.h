@@ -52,6 +52,7 @@ struct StemArgs {
 struct ConvArgs {
   const void* in; int in_ld; int in_dtype; ChanTab itab;
   const float* w; const float* bias;     // bias only for BN-free layers
+  const void* w_bf16;                    // dense 3x3, bf16 mode: pre-rounded copy of w (or null)
   void* out; int out_ld; int out_dtype;
   int bf16_mfma;                         // 1x1 / dense 3x3: bf16 operands on v_mfma_f32_16x16x32_bf16
   int N, H, W, OH, OW, cin, cout, stride, act;

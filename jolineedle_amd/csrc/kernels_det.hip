@@ -166,12 +166,14 @@ constexpr int C3B_TH = 16;          // 16 x 16 pixels per workgroup (wave = 4 ro
 
 template <int S>
 __global__ __launch_bounds__(256) void conv3_bf16_kernel(const bf16_t* __restrict__ x, int x_ld, ChanTab it,
-                                                         const float* __restrict__ w, bf16_t* __restrict__ out,
+                                                         const bf16_t* __restrict__ w, bf16_t* __restrict__ out,
                                                          int out_ld, int H, int W, int OH, int OW, int K, int Nc,
                                                          int tiles_x, int tiles_y, const int* __restrict__ skip_flag,
                                                          int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
   constexpr int IH = C3B_TH * S + 2, IW = C3_TW * S + 2;
+  constexpr int NXR = (IH * IW * (C3B_KC / 4) + 255) / 256;       // 4-channel groups of the halo tile per thread
+  constexpr int NWR = 9 * C3_BN * (C3B_KC / 8) / 256;              // 8-channel (16-B) groups of the weight chunk
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   bf16_t* Xs = reinterpret_cast<bf16_t*>(smem_b);      // [IH*IW][C3B_LD]
   bf16_t* Ws = Xs + IH * IW * C3B_LD;                  // [9][C3_BN][C3B_LD]
@@ -187,25 +189,50 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(const bf16_t* __restric
   for (int p = 0; p < 4; ++p)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // K chunks are software-pipelined through registers (chunk i + 1 is in flight while the MFMAs of chunk i run)
+  bf16x4 xr[NXR];
+  bf16x8 wr[NWR];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < NXR; ++j) {
+      const int i = tid + 256 * j, pix = i / (C3B_KC / 4), q = i % (C3B_KC / 4);
+      const int iy = oy0 * S - 1 + pix / IW, ix = ox0 * S - 1 + pix % IW;
+      bf16x4 v = {};
+      if (i < IH * IW * (C3B_KC / 4) && iy >= 0 && iy < H && ix >= 0 && ix < W && k0 + 4 * q < K)
+        v = *reinterpret_cast<const bf16x4*>(xb + ((long long)iy * W + ix) * x_ld + k0 + 4 * q);
+      xr[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NWR; ++j) {
+      const int i = tid + 256 * j, q = i % (C3B_KC / 8), r = (i / (C3B_KC / 8)) % C3_BN, tp = i / ((C3B_KC / 8) * C3_BN);
+      bf16x8 v = {};
+      if (n0 + r < Nc && k0 + 8 * q < K) v = *reinterpret_cast<const bf16x8*>(w + ((long long)tp * Nc + n0 + r) * K + k0 + 8 * q);
+      wr[j] = v;
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < K; k0 += C3B_KC) {
     if (k0) __syncthreads();
-    for (int i = tid; i < IH * IW * (C3B_KC / 4); i += 256) {
-      const int pix = i / (C3B_KC / 4), q = i % (C3B_KC / 4);
-      const int iy = oy0 * S - 1 + pix / IW, ix = ox0 * S - 1 + pix % IW;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      const int kk = k0 + 4 * q;
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W && kk < K)
-        v = tf4_d(ld4(xb + ((long long)iy * W + ix) * x_ld + kk), *reinterpret_cast<const f32x4*>(it.sc + kk),
-                  *reinterpret_cast<const f32x4*>(it.sh + kk), *reinterpret_cast<const f32x4*>(it.fl + kk));
-      st4(Xs + pix * C3B_LD + 4 * q, v);
+#pragma unroll
+    for (int j = 0; j < NXR; ++j) {
+      const int i = tid + 256 * j, pix = i / (C3B_KC / 4), q = i % (C3B_KC / 4);
+      if (i < IH * IW * (C3B_KC / 4)) {
+        const int iy = oy0 * S - 1 + pix / IW, ix = ox0 * S - 1 + pix % IW;
+        const int kk = k0 + 4 * q;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W && kk < K)
+          v = tf4_d(__builtin_convertvector(xr[j], f32x4), *reinterpret_cast<const f32x4*>(it.sc + kk),
+                    *reinterpret_cast<const f32x4*>(it.sh + kk), *reinterpret_cast<const f32x4*>(it.fl + kk));
+        st4(Xs + pix * C3B_LD + 4 * q, v);
+      }
     }
-    for (int i = tid; i < 9 * C3_BN * (C3B_KC / 4); i += 256) {
-      const int q = i % (C3B_KC / 4), r = (i / (C3B_KC / 4)) % C3_BN, tp = i / ((C3B_KC / 4) * C3_BN);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (n0 + r < Nc && k0 + 4 * q < K) v = *reinterpret_cast<const f32x4*>(w + ((long long)tp * Nc + n0 + r) * K + k0 + 4 * q);
-      st4(Ws + (tp * C3_BN + r) * C3B_LD + 4 * q, v);
+#pragma unroll
+    for (int j = 0; j < NWR; ++j) {
+      const int i = tid + 256 * j, q = i % (C3B_KC / 8), r = (i / (C3B_KC / 8)) % C3_BN, tp = i / ((C3B_KC / 8) * C3_BN);
+      *reinterpret_cast<bf16x8*>(Ws + (tp * C3_BN + r) * C3B_LD + 8 * q) = wr[j];
     }
     __syncthreads();
+    if (k0 + C3B_KC < K) fetch(k0 + C3B_KC);
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) {
       const int ky = tp / 3, kx = tp % 3;
@@ -246,7 +273,8 @@ static void launch_conv3_bf16(const ConvArgs& a, hipStream_t s) {
       attr_set = true;
     }
   }
-  hipLaunchKernelGGL((conv3_bf16_kernel<S>), grid, dim3(256), smem, s, (const bf16_t*)a.in, a.in_ld, a.itab, a.w, (bf16_t*)a.out,
+  hipLaunchKernelGGL((conv3_bf16_kernel<S>), grid, dim3(256), smem, s, (const bf16_t*)a.in, a.in_ld, a.itab,
+                     (const bf16_t*)a.w_bf16, (bf16_t*)a.out,
                      a.out_ld, a.H, a.W, a.OH, a.OW, a.cin, a.cout, tiles_x, tiles_y, a.skip_flag, a.skip_when);
 }
 
@@ -278,7 +306,7 @@ int launch_conv3(const ConvArgs& a, hipStream_t s) {
     return 0;
   }
   static const bool no_bf16_conv3 = std::getenv("JN_NO_BF16_CONV3") != nullptr;
-  if (!no_bf16_conv3 && a.in_dtype == JN_BF16 && a.out_dtype == JN_BF16 && !a.stats && !a.accumulate && a.cin % 4 == 0) {
+  if (!no_bf16_conv3 && a.w_bf16 && a.in_dtype == JN_BF16 && a.out_dtype == JN_BF16 && !a.stats && !a.accumulate && a.cin % 8 == 0) {
     if (a.stride == 1) launch_conv3_bf16<1>(a, s); else launch_conv3_bf16<2>(a, s);
     return 0;
   }
