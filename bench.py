@@ -109,6 +109,55 @@ def bench_detector(args, ja, model_config, dev, rank, world, dist):
                          "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None}}), flush=True)
 
 
+def bench_supervised(args, ja, model_config, dev, rank, world, dist):
+    """Secondary workload (BASELINE configs[0]/[1], SURVEY.md §8 a15 + §8f rank 3): one supervised iteration = teacher
+    walks on the host (integers only) + two device gathers + teacher-forced step over B*T patches + detector step on the
+    walks' detector patches + AdamW on both groups (src/supervised.py:844-902 without augmentation)."""
+    B = 4 if args.batch == 64 else args.batch
+    T = 8 if args.seq_len == 20 else args.seq_len
+    P, G = args.patch_size, args.grid
+    model = ja.GPT(model_config(patch_size=P, block_size=T, image_processor="yolox-s"), max_batch=B * T, device=str(dev))
+    model.sync_weights()
+    images, bboxes, _ = synth_inputs(B, G, P, 12345 + rank, dev)
+    batch = {"image": images, "bboxes": bboxes, "class_id": torch.zeros(B, dtype=torch.long)}
+    cfg = ja.CfgNode(patch_size=P, max_seq_len=T, min_keypoints=0, max_keypoints=2, binomial_keypoints=False,
+                     stop_enabled=False, learning_rate=1e-4, yolo_lr=1e-4, gradient_accumulation=1, detection_enabled=True)
+    trainer = ja.SupervisedTrainer(cfg, model)
+    for i in range(args.warmup):
+        trainer.train_iteration(batch, seed=i)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    det_patches, host_s = 0, 0.0
+    for i in range(args.steps):
+        h0 = time.perf_counter()
+        trainer.generate_trajectories(batch, seed=1000 + i)            # timed separately: host walk + gathers
+        torch.cuda.synchronize()
+        host_s += time.perf_counter() - h0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        m = trainer.train_iteration(batch, seed=1000 + i)
+        det_patches += int(m["trajectories"]["patches_yolox"].shape[0])
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"glimpse-patches/sec ({P}px, seq-len {T}) supervised step",
+            "value": round(B * T * world * args.steps / dt, 1), "unit": "glimpse-patches/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[0]/[1]: supervised, gpt-nano + yolox-nano encoder + yolox-s detector, {P}px, "
+                                   f"seq-len {T}, batch {B}/GPU, {G * P}x{G * P} synthetic images; teacher walks + device "
+                                   f"gathers + teacher-forced step + detector step ({det_patches / args.steps:.1f} patches/iter) "
+                                   f"+ AdamW x2", "global_batch": B * world, "seq_len": T,
+                       "trajectory_generation_ms": round(host_s / args.steps * 1e3, 3)},
+            "roofline": None}), flush=True)
+
+
 def cpu_baseline(P, T, seed, train):
     """CPU oracle (pure PyTorch fp32 restatement, oracle/) on the host cores: a bounded sample of
     the same workload — B=4 agents, T glimpse steps, 4480x4480 images would need 1 GB/agent on the
@@ -159,7 +208,7 @@ def main():
     ap.add_argument("--patch-size", type=int, default=448)
     ap.add_argument("--grid", type=int, default=10, help="image side in patches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["train", "rollout", "detector"], default="train",
+    ap.add_argument("--mode", choices=["train", "rollout", "detector", "supervised"], default="train",
                     help="train (default, the headline): full REINFORCE iteration; rollout: inference rollout; detector: "
                          "secondary, one detector training step (yolox-s, SimOTA loss, backward, AdamW) on --batch patches")
     ap.add_argument("--config", choices=["c3", "c5"], default="c3",
@@ -202,6 +251,8 @@ def main():
     torch.manual_seed(12345)
     if args.mode == "detector":
         return bench_detector(args, ja, model_config, dev, rank, world, dist)
+    if args.mode == "supervised":
+        return bench_supervised(args, ja, model_config, dev, rank, world, dist)
     assert not (args.dtype == "bf16" and args.mode == "train"), "bf16 is the inference mode: use --mode rollout"
     if args.detect:
         assert args.mode == "rollout", "--detect belongs to --mode rollout"

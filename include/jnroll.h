@@ -149,6 +149,14 @@ int jn_env_patches(jn_ctx* ctx, float* out_dev, void* stream);
 /* Stand-alone gather (no context state): out[b] = images[b,:,y*P:(y+1)*P, x*P:(x+1)*P]. */
 int jn_gather_patches(const float* images_dev, const int64_t* positions_dev, float* out_dev,
                       int B, int C, int H, int W, int P, void* stream);
+/* Trajectory form of the gather: out[n] = images[image_index[n], :, y_n*P:(y_n+1)*P, x_n*P:(x_n+1)*P] for N
+ * (image, position) pairs — the patches NeedleSimpleEnv.generate_sample stacks one `get_patch` at a time
+ * (src/env/simple_env.py:55-81, 472) and init_sample's detector patches (:417-419).  image_index[n] < 0 writes
+ * a zero patch (a masked step of the zero-initialised sample, :380-384).  Positions must lie on the grid and
+ * indices below n_images (the Python mirror asserts both, as get_patch does at :73-74). */
+int jn_gather_patches_indexed(const float* images_dev, const int64_t* image_index_dev,
+                              const int64_t* positions_dev, float* out_dev, int N, int n_images,
+                              int C, int H, int W, int P, void* stream);
 
 /* ---- networks ------------------------------------------------------------------- */
 /* YOLOPAFPN.forward as called at src/models/gpt.py:375 / src/models/yolox.py:55 "with the

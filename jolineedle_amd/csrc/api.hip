@@ -1368,6 +1368,18 @@ int jn_gather_patches(const float* images_dev, const int64_t* positions_dev, flo
   return JN_OK;
 }
 
+int jn_gather_patches_indexed(const float* images_dev, const int64_t* image_index_dev, const int64_t* positions_dev,
+                              float* out_dev, int N, int n_images, int C, int H, int W, int P, void* stream) {
+  JN_CHECK(images_dev && image_index_dev && positions_dev && out_dev, JN_EINVAL, "jn_gather_patches_indexed: null argument");
+  JN_CHECK(N >= 0 && n_images >= 1 && C >= 1 && P >= 1 && H % P == 0 && W % P == 0, JN_EINVAL,
+           "jn_gather_patches_indexed: bad shape");
+  if (N == 0) return JN_OK;
+  launch_gather(images_dev, positions_dev, out_dev, (long long)C * P * P, N, C, H, W, P, nullptr, 0, (hipStream_t)stream,
+                image_index_dev);
+  JN_HIP(hipGetLastError());
+  return JN_OK;
+}
+
 int jn_env_patches(jn_ctx* ctx, float* out_dev, void* stream) {
   JN_CHECK(ctx && ctx->env.ready && out_dev, JN_ESTATE, "jn_env_init has not been called");
   const EnvState& e = ctx->env;

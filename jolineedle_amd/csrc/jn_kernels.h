@@ -177,7 +177,8 @@ int launch_nchw_to_nhwc_grad(const float* in, float* out, int out_ld, int C, int
 
 // ---- env / rollout primitives (kernels_env.hip) -------------------------------------
 int launch_gather(const float* images, const int64_t* positions, float* out, long long out_sample_stride,
-                  int B, int C, int H, int W, int P, const int* skip_flag, int skip_when, hipStream_t s);
+                  int B, int C, int H, int W, int P, const int* skip_flag, int skip_when, hipStream_t s,
+                  const int64_t* image_index = nullptr);
 int launch_bbox_masks(const int64_t* bboxes, uint8_t* masks, int32_t* n_tiles, int B, int nb, int H, int W, int P,
                       hipStream_t s);
 

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ i
                                                      const long long* __restrict__ pos, float* __restrict__ out,
                                                      long long out_sample_stride, int C, int H, int W, int P,
                                                      long long total, const int* __restrict__ skip_flag,
-                                                     int skip_when) {
+                                                     int skip_when, const long long* __restrict__ img_idx) {
   if (skip_flag && *skip_flag >= skip_when) return;
   constexpr int V = VEC ? 4 : 1;
   const int PV = P / V;
@@ -25,25 +25,32 @@ __global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ i
     const int c = (int)((idx / ((long long)PV * P)) % C);
     const int b = (int)(idx / ((long long)PV * P * C));
     const long long y = pos[2 * b], x = pos[2 * b + 1];
-    const float* sp = images + (((long long)b * C + c) * H + y * P + r) * W + x * P + q * V;
+    const long long im = img_idx ? img_idx[b] : b;   // indexed form: several patches per image; < 0 = zero patch
     float* dp = out + b * out_sample_stride + ((long long)c * P + r) * P + q * V;
+    if (im < 0) {
+      if (VEC) *reinterpret_cast<f32x4*>(dp) = f32x4{0.f, 0.f, 0.f, 0.f};
+      else *dp = 0.f;
+      continue;
+    }
+    const float* sp = images + ((im * C + c) * H + y * P + r) * W + x * P + q * V;
     if (VEC) *reinterpret_cast<f32x4*>(dp) = *reinterpret_cast<const f32x4*>(sp);
     else *dp = *sp;
   }
 }
 
 int launch_gather(const float* images, const int64_t* positions, float* out, long long out_sample_stride, int B,
-                  int C, int H, int W, int P, const int* skip_flag, int skip_when, hipStream_t s) {
+                  int C, int H, int W, int P, const int* skip_flag, int skip_when, hipStream_t s,
+                  const int64_t* image_index) {
   const bool vec = (P % 4 == 0) && (W % 4 == 0) && (out_sample_stride % 4 == 0) &&
                    (((uintptr_t)images | (uintptr_t)out) % 16 == 0);
   const long long total = (long long)B * C * P * (P / (vec ? 4 : 1));
   const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, 256 * 32);
   if (vec)
     hipLaunchKernelGGL(gather_kernel<true>, dim3(blocks), dim3(256), 0, s, images, (const long long*)positions, out,
-                       out_sample_stride, C, H, W, P, total, skip_flag, skip_when);
+                       out_sample_stride, C, H, W, P, total, skip_flag, skip_when, (const long long*)image_index);
   else
     hipLaunchKernelGGL(gather_kernel<false>, dim3(blocks), dim3(256), 0, s, images, (const long long*)positions, out,
-                       out_sample_stride, C, H, W, P, total, skip_flag, skip_when);
+                       out_sample_stride, C, H, W, P, total, skip_flag, skip_when, (const long long*)image_index);
   return 0;
 }
 

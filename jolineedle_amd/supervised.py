@@ -1,9 +1,10 @@
 """``SupervisedTrainer`` — the teacher-forced training step of the reference
-(src/supervised.py:138-177 loss, :863-902 step) over ``jn_supervised_step``.  Trajectory generation
-(NeedleSimpleEnv), augmentation, the detector loss and the evaluation suite are out of scope
-(SURVEY.md §8): the caller supplies patches / actions / positions / masks of a batch."""
+(src/supervised.py:138-177 loss, :863-902 step) over ``jn_supervised_step``, fed by teacher trajectories
+(``generate_trajectories``, src/supervised.py:95-136, over trajectory.NeedleSimpleEnv) whose patches are gathered on
+the device, and followed by the detector step on the trajectories' detector patches (src/supervised.py:881-902).
+Augmentation and the evaluation suite are out of scope."""
 import ctypes as C
-from typing import Dict
+from typing import Dict, Optional, Tuple
 
 import torch
 
@@ -29,6 +30,71 @@ class SupervisedTrainer:
             self._optim_numel = gpt.value
             check(eng.lib.jn_set_grad_arena(eng.handle, ptr(self._flat_grads), tot.value), "jn_set_grad_arena")
         return self._flat_grads
+
+    def generate_trajectories(self, batch: Dict, position: Optional[Tuple[int, int]] = None, seed: Optional[int] = None) -> Dict:
+        """One teacher walk per image of `batch` (``image`` [B, C, H, W] on the device or a list of [C, H, W] of one
+        size, ``bboxes`` [B, nb, 4] xyxy with zero-row padding or a list, ``class_id``) -> the collated dict of
+        src/supervised.py:95-136: patches [B, T, C, P, P], current_actions / next_actions / labels [B, T],
+        positions [B, T, 2], masks [B, T], local_bboxes [B, T, nb, 6], patches_yolox [M, C, P, P], bboxes_yolox
+        [M, nb, 6], class_id [B].  The walks are integer work on the host; both patch tensors come from the
+        device-resident images in two gather launches.  `seed` makes the walks reproducible (the reference seeds
+        nothing here)."""
+        from .trajectory import NeedleSimpleEnv, assemble_samples
+        cfg = self.config
+        images = batch["image"]
+        if not isinstance(images, torch.Tensor):
+            images = torch.stack(list(images))
+        images = images.to(self.device, torch.float32).contiguous()
+        P = int(cfg.patch_size)
+        idx = []
+        for i in range(images.shape[0]):
+            bb = batch["bboxes"][i]
+            if isinstance(bb, torch.Tensor):
+                bb = bb[(bb != 0).any(dim=-1)] if bb.numel() else bb.reshape(0, 4)      # drop the collate's zero rows
+            env = NeedleSimpleEnv(None, P, bb, seed=None if seed is None else seed + i, height=images.shape[2], width=images.shape[3])
+            idx.append(env.generate_sample_indices(int(cfg.max_seq_len), int(getattr(cfg, "min_keypoints", 0)),
+                                                   int(getattr(cfg, "max_keypoints", 0)),
+                                                   bool(getattr(cfg, "binomial_keypoints", False)), position))
+        out = assemble_samples(images, list(range(images.shape[0])), idx, P)
+        cid = batch.get("class_id")
+        out["class_id"] = (torch.as_tensor(cid) if cid is not None else torch.zeros(images.shape[0], dtype=torch.long)).to(self.device, torch.long)
+        return out
+
+    def train_iteration(self, batch: Dict, optimizer_step: bool = True, process_group=None, seed: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        """Loop body of src/supervised.py:844-902 without augmentation: trajectories -> teacher-forced step (CE loss,
+        backward) -> detector loss + backward on the trajectories' detector patches -> AdamW on both groups."""
+        cfg = self.config
+        tr = self.generate_trajectories(batch, seed=seed)
+        cur, nxt, masks = tr["current_actions"], tr["next_actions"], tr["masks"]
+        if getattr(cfg, "loss_mode", "best-action") == "on-self-trajectory":          # src/supervised.py:870-877
+            ref_actions = torch.zeros_like(cur)
+            ref_actions[:, :-1] = cur[:, 1:]
+            last = masks.sum(dim=1).long() - 1
+            rows = torch.arange(cur.shape[0], device=cur.device)
+            ref_actions[rows, last] = nxt[rows, last]
+        else:
+            ref_actions = nxt
+        detection = self.model.yolox is not None and bool(getattr(cfg, "detection_enabled", True))
+        res = self.train_step(tr["patches"], cur, ref_actions, tr["positions"], masks, optimizer_step=False)
+        ga = int(getattr(cfg, "gradient_accumulation", 1))
+        if detection:
+            _, _, yolo = self.model.yolox(tr["patches_yolox"], tr["bboxes_yolox"], loss_scale=1.0)
+            for k, v in yolo.items():
+                res["yolo_" + k] = v
+            res["loss"] = res["loss"] + yolo["total_loss"].cpu()
+        if optimizer_step and self.iter_num % ga == 0:
+            from .dist import allreduce_gradients
+            eng, grads = self.model.engine(), self._grad_arena()
+            stream = _lib.current_stream(self.device)
+            scale = allreduce_gradients(grads, grads.numel() if detection else self._optim_numel, process_group)
+            lr = float(getattr(cfg, "learning_rate", 1e-4))
+            check(eng.lib.jn_optimizer_step(eng.handle, lr, 0.01, 0.0, scale, stream), "jn_optimizer_step")
+            if detection:
+                ylr = float(getattr(cfg, "yolo_lr", lr))
+                check(eng.lib.jn_optimizer_step_group(eng.handle, 1, ylr, 0.01, 0.0, scale, stream), "jn_optimizer_step_group")
+            grads.zero_()
+        res["trajectories"] = tr
+        return res
 
     def train_step(self, patches, current_actions, next_actions, positions, masks, optimizer_step: bool = True,
                    process_group=None) -> Dict[str, torch.Tensor]:
