@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstring>
 #include <memory>
+#include <set>
 
 #include "jn_internal.h"
 
@@ -819,6 +820,35 @@ static int ensure_train_state(jn_ctx* ctx, int g_slots = 1) {
 
 static inline float* grad_of(const jn_ctx* ctx, const float* param) { return ctx->grads + (param - ctx->params); }
 
+static inline bool views_overlap(const View& a, const View& b) {
+  return a.buf >= 0 && a.buf == b.buf && a.coff < b.coff + b.C && b.coff < a.coff + a.C;
+}
+
+// Backward fusion of a producer's BN reduce into its consumer: returns the index of the ONE BatchNorm conv whose
+// output view is exactly ops[obi].in, provided ops[obi] is the only reader of that view, nothing else writes into it
+// and no gradient arrives from outside the network (FPN outputs); -1 otherwise.
+static int sole_producer(const Net& net, int obi) {
+  const View& v = net.ops[obi].in;
+  for (int i = 0; i < 3; ++i)
+    if (views_overlap(v, net.fpn[i])) return -1;
+  int prod = -1;
+  for (int j = 0; j < (int)net.ops.size(); ++j) {
+    const Op& o = net.ops[j];
+    if (j != obi && (views_overlap(o.in, v) || views_overlap(o.res, v))) return -1;
+    if (o.kind == OP_SPP && o.out.buf == v.buf) return -1;            // works on the whole concat buffer
+    if (views_overlap(o.out, v) || views_overlap(o.alias, v)) {
+      if (prod >= 0 || j >= obi) return -1;
+      prod = j;
+    }
+  }
+  if (prod < 0) return -1;
+  const Op& po = net.ops[prod];
+  if (po.wslot < 0 || po.out.coff != v.coff || po.out.C != v.C || po.out.buf != v.buf) return -1;
+  const ConvW& pw = net.convs[po.wslot];
+  if (!pw.has_bn || !pw.prefix2.empty() || pw.cout != v.C) return -1;
+  return prod;
+}
+
 // Backward of `nsl` train-mode PAFPN passes (workspace slots slot .. slot + nsl - 1, N patches each; gradient
 // slots 0 .. nsl - 1): every kernel is launched ONCE for all the passes (SlotBatch), so a 20-step trajectory
 // costs the launches of one pass.  g[fpn views] must hold the incoming gradients; parameter gradients are
@@ -846,6 +876,8 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
   auto ld = [&](const View& v) { return net.bufs[v.buf].C; };
   const ChanTab ident{ctx->ident, ctx->ident + 2048, ctx->ident + 4096};
   std::map<int, std::pair<int, View>> g_alias;      // conv output buffer -> (coff, gradient view to read instead)
+  std::set<int> red_done;                           // conv slots whose BN-backward sums a consumer's kernel already formed
+  static const bool no_red_fusion = std::getenv("JN_NO_FUSED_REDUCE") != nullptr;
   const int n_ops_b = (with_head || net.n_backbone_ops < 0) ? (int)net.ops.size() : net.n_backbone_ops;
   for (int obi = n_ops_b - 1; obi >= 0; --obi) {
     const Op& op = net.ops[obi];
@@ -860,10 +892,11 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
       const long long M = (long long)N * op.out.H * op.out.W;
       double* red = net.bred + 2 * cw.stat_off;
       float* consts = net.bconsts + 3 * cw.stat_off;
-      launch_bn_bwd_reduce(gp_out, gld_out, ptr(op.out), net.act_dtype, ld(op.out), tab(op.out), save + 2 * cw.stat_off, cw.cout,
-                           M, red, rep_stride, s, sb);
+      if (!red_done.count(op.wslot))
+        launch_bn_bwd_reduce(gp_out, gld_out, ptr(op.out), net.act_dtype, ld(op.out), tab(op.out), save + 2 * cw.stat_off, cw.cout,
+                             M, red, rep_stride, s, sb);
       launch_bn_bwd_consts(red, rep_stride, (double)M, cw.gamma_dev, save + 2 * cw.stat_off, consts,
-                           grad_of(ctx, cw.gamma_dev), grad_of(ctx, cw.beta_dev), cw.cout, s, sb);
+                           grad_of(ctx, cw.gamma_dev), grad_of(ctx, cw.beta_dev), cw.cout, s, sb, red_done.count(op.wslot) ? 1 : 0);
       float* gw = grad_of(ctx, cw.w_dev);
       static const bool no_fused = std::getenv("JN_NO_FUSED_BWD") != nullptr;
       // a merged pair too wide for the fused kernel is differentiated as its two halves (independent output rows)
@@ -881,6 +914,14 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
           fa.x = (const float*)ptr(op.in); fa.x_ld = ld(op.in); fa.it = tab(op.in); fa.w = cw.w_dev + (size_t)c0 * cw.cin;
           fa.gx = gptr(op.in); fa.gx_ld = ld(op.in); fa.accumulate = (op.acc_in || part > 0) ? 1 : 0;
           fa.gw = gw + (size_t)c0 * cw.cin; fa.wpart = ctx->wpart; fa.M = M; fa.cout = pc; fa.cin = cw.cin; fa.sb = sb;
+          if (parts == 1 && !op.acc_in && !no_red_fusion && pw_bwd_fused_reduces_input(pc, cw.cin)) {
+            const int prod = sole_producer(net, obi);
+            if (prod >= 0) {
+              const ConvW& pcw = net.convs[net.ops[prod].wslot];
+              fa.red_in = net.bred + 2 * pcw.stat_off; fa.red_rep_stride = rep_stride;
+              red_done.insert(net.ops[prod].wslot);
+            }
+          }
           launch_pw_bwd_fused(fa, s);
         }
         continue;
@@ -895,6 +936,16 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
         fa.gin = gptr(op.in); fa.gin_ld = ld(op.in); fa.accumulate = op.acc_in ? 1 : 0; fa.gw = gw; fa.wpart = ctx->wpart;
         fa.C = cw.cout; fa.H = op.in.H; fa.W = op.in.W; fa.OH = op.out.H; fa.OW = op.out.W; fa.N = N; fa.stride = op.stride;
         fa.sb = sb;
+        // stride 1 only: the stride-2 kernel (one thread = a 2 x 2 input block) loses more to the extra loads than the
+        // separate reduce pass costs (measured on the stem output: +2.0 ms against 1.6 ms saved)
+        if (!op.acc_in && !no_red_fusion && op.stride == 1) {
+          const int prod = sole_producer(net, obi);
+          if (prod >= 0) {
+            const ConvW& pcw = net.convs[net.ops[prod].wslot];
+            fa.red_in = net.bred + 2 * pcw.stat_off; fa.red_rep_stride = rep_stride;
+            red_done.insert(net.ops[prod].wslot);
+          }
+        }
         launch_dw_bwd_fused(fa, s);
         continue;
       }

@@ -124,7 +124,7 @@ int launch_bn_bwd_reduce(const float* g, int g_ld, const void* z, int z_dtype, i
 // sums the replicas -> consts[c] = {sum_gy/n, sum_gy_zhat/n, gamma*invstd}; dgamma/dbeta += totals
 int launch_bn_bwd_consts(const double* red, long long rep_stride, double count, const float* gamma, const float* save,
                          float* consts, float* g_gamma, float* g_beta, int C, hipStream_t s,
-                         const SlotBatch& sb = SlotBatch{});
+                         const SlotBatch& sb = SlotBatch{}, int raw_moment = 0);
 int launch_bn_bwd_gz(float* g, int g_ld, const void* z, int z_dtype, int z_ld, ChanTab t, const float* save,
                      const float* consts, int C, long long M, hipStream_t s, const SlotBatch& sb = SlotBatch{});
 // weight-gradient kernels add into wpart (replicated scratch, zero on entry and on exit) when the
@@ -144,6 +144,8 @@ struct PwBwdFusedArgs {
   float* gw; float* wpart;
   long long M; int cout, cin;
   SlotBatch sb;
+  // optional: accumulate the BN-backward sums of the layer that produced the input (sole consumer, not accumulating)
+  double* red_in; long long red_rep_stride;
 };
 struct DwBwdFusedArgs {                  // the depthwise counterpart (3x3, pad 1, stride 1 / 2)
   const float* g; int g_ld; const float* z; int z_ld; ChanTab ot; const float* save; const float* consts;
@@ -151,10 +153,12 @@ struct DwBwdFusedArgs {                  // the depthwise counterpart (3x3, pad 
   float* gin; int gin_ld; int accumulate; float* gw; float* wpart;
   int C, H, W, OH, OW, N, stride;
   SlotBatch sb;
+  double* red_in; long long red_rep_stride;      // as in PwBwdFusedArgs
 };
 bool dw_bwd_fused_supported(int C, int H, int W, int OH, int OW, int stride);
 int launch_dw_bwd_fused(const DwBwdFusedArgs& a, hipStream_t s);
 bool pw_bwd_fused_supported(int cout, int cin);
+bool pw_bwd_fused_reduces_input(int cout, int cin);
 int launch_pw_bwd_fused(const PwBwdFusedArgs& a, hipStream_t s);
 int launch_dw_bwd_data(const float* gz, int g_ld, const float* w, float* gin, int gin_ld, int C, int H, int W, int OH,
                        int OW, int N, int stride, int accumulate, hipStream_t s, const SlotBatch& sb = SlotBatch{});

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "jn_kernels.h"
+#include "jn_reduce.h"
 #include "jn_types.h"
 
 namespace jnr {
@@ -109,7 +110,7 @@ int launch_bn_bwd_reduce(const float* g, int g_ld, const void* z, int z_dtype, i
 __global__ void bn_bwd_consts_kernel(const double* __restrict__ red, long long rep_stride, double count,
                                      const float* __restrict__ gamma, const float* __restrict__ save,
                                      float* __restrict__ consts, float* __restrict__ g_gamma,
-                                     float* __restrict__ g_beta, int C, SlotBatch sb) {
+                                     float* __restrict__ g_beta, int C, SlotBatch sb, int raw_moment) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const int sl = blockIdx.y;
@@ -118,6 +119,8 @@ __global__ void bn_bwd_consts_kernel(const double* __restrict__ red, long long r
   float* cs = consts + sl * sb.consts;
   double s1 = 0.0, s2 = 0.0;
   for (int r = 0; r < JN_NREP; ++r) { s1 += rd[r * rep_stride + 2 * c]; s2 += rd[r * rep_stride + 2 * c + 1]; }
+  // sums formed by a consumer's fused kernel carry sum gy * z: sum gy * zhat = invstd * (sum gy * z - mean * sum gy)
+  if (raw_moment) s2 = (double)sv[2 * c + 1] * (s2 - (double)sv[2 * c] * s1);
   cs[3 * c] = (float)(s1 / count);
   cs[3 * c + 1] = (float)(s2 / count);
   cs[3 * c + 2] = gamma[c] * sv[2 * c + 1];
@@ -126,9 +129,10 @@ __global__ void bn_bwd_consts_kernel(const double* __restrict__ red, long long r
 }
 
 int launch_bn_bwd_consts(const double* red, long long rep_stride, double count, const float* gamma, const float* save,
-                         float* consts, float* g_gamma, float* g_beta, int C, hipStream_t s, const SlotBatch& sb) {
+                         float* consts, float* g_gamma, float* g_beta, int C, hipStream_t s, const SlotBatch& sb,
+                         int raw_moment) {
   hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((C + 63) / 64, sb.n), dim3(64), 0, s, red, rep_stride, count, gamma, save,
-                     consts, g_gamma, g_beta, C, sb);
+                     consts, g_gamma, g_beta, C, sb, raw_moment);
   return 0;
 }
 
@@ -419,12 +423,15 @@ int launch_pw_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, 
 // HBM traffic 8 B/output + 8 B/input element instead of 20 + 8 for the bn_bwd_gz / data / weight kernels.
 // Workgroup = 4 waves, 64 pixels per iteration, persistent over the tiles of ONE slot (blockIdx.y) so the
 // per-channel constants sit in registers and dW in accumulators; Cout = 16*CTN, Cin = 16*CTK, CTN*CTK <= 16.
-template <int CTN, int CTK>
+// RED: the layer input is the output of ONE BatchNorm conv with no other consumer: the per-channel sums of ITS backward
+// (bn_bwd_reduce: sum g_a*silu'(y), sum g_a*silu'(y)*zhat) are accumulated here from the data gradient still in the
+// MFMA accumulators (z of the input tile is re-read, L2-hot), so that layer's reduce pass over (g, z) never runs.
+template <int CTN, int CTK, bool RED>
 __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
     const float* __restrict__ g, int g_ld, const float* __restrict__ z, int z_ld, ChanTab ot,
     const float* __restrict__ save, const float* __restrict__ consts, const float* __restrict__ x, int x_ld,
     ChanTab it, const float* __restrict__ w, float* __restrict__ gx, int gx_ld, int accumulate,
-    float* __restrict__ gw, int rep, long long M, SlotBatch sb) {
+    float* __restrict__ gw, int rep, long long M, SlotBatch sb, double* __restrict__ red_in, long long red_rep_stride) {
   constexpr int N = 16 * CTN, K = 16 * CTK;          // output / input channels
   constexpr int LDG = N + 4, LDA = K + 4, LDW = N + 4;
   constexpr int NG = 64 * (N / 4) / 256, NA = 64 * (K / 4) / 256;     // f32x4 per thread per tile (may be 0 -> 1)
@@ -439,6 +446,7 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
     const long long sl = blockIdx.y;
     g += sl * sb.grad; z += sl * sb.act; x += sl * sb.act; gx += sl * sb.grad;
     save += sl * sb.save; consts += sl * sb.consts;
+    if (RED) red_in += sl * sb.red;
     ot.sc += sl * sb.tab; ot.sh += sl * sb.tab;
     it.sc += sl * sb.tab; it.sh += sl * sb.tab; it.fl += sl * sb.tab;
   }
@@ -457,6 +465,8 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
     Cs[4 * N + c] = consts[3 * c]; Cs[5 * N + c] = consts[3 * c + 1]; Cs[6 * N + c] = consts[3 * c + 2];
   }
   for (int c = tid; c < K; c += 256) { Cs[7 * N + c] = it.sc[c]; Cs[7 * N + K + c] = it.sh[c]; Cs[7 * N + 2 * K + c] = it.fl[c]; }
+  if (RED)
+    for (int c = tid; c < 8 * K; c += 256) Cs[7 * N + 3 * K + c] = 0.0f;       // [4 waves][K][2] input-layer BN sums
   f32x4 dw[CTN][CTK];
 #pragma unroll
   for (int a = 0; a < CTN; ++a)
@@ -508,14 +518,21 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
       const int i = tid + 256 * j, r = i / (K / 4);
       if (i < 64 * (K / 4)) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m0 + r < M)
-          v = tf4_(rx[j], *reinterpret_cast<const f32x4*>(Cs + 7 * N + 4 * kq), *reinterpret_cast<const f32x4*>(Cs + 7 * N + K + 4 * kq),
-                   *reinterpret_cast<const f32x4*>(Cs + 7 * N + 2 * K + 4 * kq));
+        if (m0 + r < M) {
+          if constexpr (RED) v = rx[j];     // raw z: activated where phase 3 reads it (each element once), z itself feeds the RED sums
+          else v = tf4_(rx[j], *reinterpret_cast<const f32x4*>(Cs + 7 * N + 4 * kq), *reinterpret_cast<const f32x4*>(Cs + 7 * N + K + 4 * kq),
+                        *reinterpret_cast<const f32x4*>(Cs + 7 * N + 2 * K + 4 * kq));
+        }
         *reinterpret_cast<f32x4*>(As + r * LDA + 4 * kq) = v;
       }
     }
   };
 
+  float p_sc[RED ? CTK : 1], p_sh[RED ? CTK : 1], p_fl[RED ? CTK : 1];      // input table of channels 16 b + lm (phase 3)
+  if constexpr (RED) {
+#pragma unroll
+    for (int b = 0; b < CTK; ++b) { p_sc[b] = it.sc[16 * b + lm]; p_sh[b] = it.sh[16 * b + lm]; p_fl[b] = it.fl[16 * b + lm]; }
+  }
   long long tile = blockIdx.x;
   if (tile < n_tiles) fetch(tile * 64);
   for (; tile < n_tiles; tile += gridDim.x) {
@@ -551,6 +568,24 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
           *reinterpret_cast<f32x4*>(op) = v;
         }
       }
+      if constexpr (RED) {
+        // this wave's 16 pixels: row sums by DPP, accumulated in the wave's own LDS slots (plain read-modify-write by
+        // the row leaders) -- per-lane sums held in registers across the tiles cost a wave of occupancy
+        float* rslot = Cs + 7 * N + 3 * K + wave * 2 * K;
+#pragma unroll
+        for (int b = 0; b < CTK; ++b) {
+          const int ch = 16 * b + 4 * gq;
+          const f32x4 zv = *reinterpret_cast<const f32x4*>(As + (wave * 16 + lm) * LDA + ch);      // raw z of this pixel
+          const f32x4 i_sc = *reinterpret_cast<const f32x4*>(Cs + 7 * N + ch), i_sh = *reinterpret_cast<const f32x4*>(Cs + 7 * N + K + ch);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float gy = m < M ? acc[b][q] * dsilu_(fmaf(zv[q], i_sc[q], i_sh[q])) : 0.0f;
+            const float a1 = row16_sum(gy);
+            const float a2 = row16_sum(gy * zv[q]);      // raw second moment: bn_bwd_consts turns it into sum gy * zhat (fp64)
+            if (lm == 0) { rslot[2 * (ch + q)] += a1; rslot[2 * (ch + q) + 1] += a2; }
+          }
+        }
+      }
     }
     // ---- phase 3: dW[cout][cin] += sum_pixel g_z[pixel][cout] * a[pixel][cin]; wave = 16 pixels = 4 k-steps
 #pragma unroll
@@ -560,12 +595,23 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
 #pragma unroll
       for (int a = 0; a < CTN; ++a) av[a] = Gs[row * LDG + 16 * a + lm];
 #pragma unroll
-      for (int b = 0; b < CTK; ++b) bv[b] = As[row * LDA + 16 * b + lm];
+      for (int b = 0; b < CTK; ++b) {
+        bv[b] = As[row * LDA + 16 * b + lm];
+        if constexpr (RED) bv[b] = p_fl[b] != 0.0f ? silu_(fmaf(bv[b], p_sc[b], p_sh[b])) : bv[b];
+      }
 #pragma unroll
       for (int a = 0; a < CTN; ++a)
 #pragma unroll
         for (int b = 0; b < CTK; ++b) dw[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], dw[a][b], 0, 0, 0);
     }
+  }
+  if constexpr (RED) {
+    // per-channel sums of the input layer's BN backward: the four waves' LDS slots -> fp64 atomics
+    __syncthreads();
+    const float* rs = Cs + 7 * N + 3 * K;
+    if (tid < 2 * K)
+      atomicAdd(&red_in[(blockIdx.x % JN_NREP) * red_rep_stride + tid],
+                (double)(rs[tid] + rs[2 * K + tid] + rs[4 * K + tid] + rs[6 * K + tid]));
   }
   // cross-wave sum of dW (one wave at a time: plain LDS read-modify-write), then one set of atomics
   for (int wv = 0; wv < 4; ++wv) {
@@ -587,15 +633,15 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
   for (int i = tid; i < N * K; i += 256) atomicAdd(&dst[i], Ts[i]);
 }
 
-template <int CTN, int CTK>
-static void launch_pw_bwd_fused_t(const PwBwdFusedArgs& a, hipStream_t s) {
+template <int CTN, int CTK, bool RED>
+static void launch_pw_bwd_fused_r(const PwBwdFusedArgs& a, hipStream_t s) {
   constexpr int N = 16 * CTN, K = 16 * CTK;
-  size_t smem = ((size_t)64 * (N + 4) + 64 * (K + 4) + (size_t)K * (N + 4) + 7 * N + 3 * K) * sizeof(float);
+  size_t smem = ((size_t)64 * (N + 4) + 64 * (K + 4) + (size_t)K * (N + 4) + 7 * N + 3 * K + (RED ? 8 * K : 0)) * sizeof(float);
   if (smem < (size_t)N * K * sizeof(float)) smem = (size_t)N * K * sizeof(float);
   if (smem > 64 * 1024) {
     static bool raised = false;       // per instantiation
     if (!raised) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_fused_kernel<CTN, CTK>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_fused_kernel<CTN, CTK, RED>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       raised = true;
     }
@@ -605,11 +651,21 @@ static void launch_pw_bwd_fused_t(const PwBwdFusedArgs& a, hipStream_t s) {
   if (bx < 32) bx = 32;
   if (bx > n_tiles) bx = n_tiles;
   const int rep = (a.wpart && N * K <= JN_WPART_MAX) ? 1 : 0;
-  hipLaunchKernelGGL((pw_bwd_fused_kernel<CTN, CTK>), dim3((unsigned)bx, a.sb.n), dim3(256), smem, s, a.g, a.g_ld, a.z,
+  hipLaunchKernelGGL((pw_bwd_fused_kernel<CTN, CTK, RED>), dim3((unsigned)bx, a.sb.n), dim3(256), smem, s, a.g, a.g_ld, a.z,
                      a.z_ld, a.ot, a.save, a.consts, a.x, a.x_ld, a.it, a.w, a.gx, a.gx_ld, a.accumulate,
-                     rep ? a.wpart : a.gw, rep, a.M, a.sb);
+                     rep ? a.wpart : a.gw, rep, a.M, a.sb, a.red_in, a.red_rep_stride);
   if (rep) launch_wpart_reduce(a.gw, a.wpart, N * K, s);
 }
+
+template <int CTN, int CTK>
+static void launch_pw_bwd_fused_t(const PwBwdFusedArgs& a, hipStream_t s) {
+  if constexpr (CTK <= 4) {
+    if (a.red_in) { launch_pw_bwd_fused_r<CTN, CTK, true>(a, s); return; }
+  }
+  launch_pw_bwd_fused_r<CTN, CTK, false>(a, s);
+}
+
+bool pw_bwd_fused_reduces_input(int cout, int cin) { return pw_bwd_fused_supported(cout, cin) && cin <= 64; }
 
 bool pw_bwd_fused_supported(int cout, int cin) {
   if (cout % 16 || cin % 16) return false;
@@ -780,13 +836,15 @@ int launch_dw_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, 
 // stride 2: thread (a, b) owns output pixel (a, b) and the 2 x 2 input block under it.
 constexpr int DF_TW = 16;
 
-template <int S, int CB, int DF_TH>
-__global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
+// RED: as in pw_bwd_fused_kernel — the BN-backward sums of the layer that produced the input are formed from the data
+// gradient of each input pixel (its raw z re-read, L2-hot) and added to that layer's fp64 accumulators.
+template <int S, int CB, int DF_TH, bool RED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void dw_bwd_fused_kernel(
     const float* __restrict__ g, int g_ld, const float* __restrict__ z, int z_ld, ChanTab ot,
     const float* __restrict__ save, const float* __restrict__ consts, const float* __restrict__ x, int x_ld,
     ChanTab it, const float* __restrict__ w, float* __restrict__ gin, int gin_ld, int accumulate,
     float* __restrict__ gw, int rep, int C, int H, int W, int OH, int OW, int tiles_x, int tiles_y, int n_tiles,
-    SlotBatch sb) {
+    SlotBatch sb, double* __restrict__ red_in, long long red_rep_stride) {
   constexpr int Q = CB / 4, PS = S == 1 ? CB : CB + 4;     // stride-1 taps: a wave reads 1 KB contiguous, no padding
   constexpr int GH = S == 1 ? DF_TH + 2 : DF_TH + 1, GW = S == 1 ? DF_TW + 2 : DF_TW + 1;
   constexpr int AH = S == 1 ? DF_TH + 2 : 2 * DF_TH + 1, AW = S == 1 ? DF_TW + 2 : 2 * DF_TW + 1;
@@ -796,19 +854,20 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
   float* Gs = sm;                        // [GH*GW][PS] g_z
   float* As = Gs + GH * GW * PS;         // [AH*AW][PS] activated input
   float* red = As + AH * AW * PS;        // [9][CB]
-  float* Cs = red + 9 * CB;              // [7][CB] output-side constants, [3][CB] input table, [9][CB] weights (registers
+  float* Cs = red + 11 * CB;             // [7][CB] output-side constants, [3][CB] input table, [9][CB] weights (registers
                                          // are the occupancy limit of this kernel)
   {
     const long long sl = blockIdx.y;
     g += sl * sb.grad; z += sl * sb.act; x += sl * sb.act; gin += sl * sb.grad;
     save += sl * sb.save; consts += sl * sb.consts;
+    if (RED) red_in += sl * sb.red;
     ot.sc += sl * sb.tab; ot.sh += sl * sb.tab;
     it.sc += sl * sb.tab; it.sh += sl * sb.tab; it.fl += sl * sb.tab;
   }
   const int tid = threadIdx.x;
   const int ncb = C / CB, cb = blockIdx.x % ncb;
   const int q = tid % Q, c = cb * CB + 4 * q;
-  for (int i = tid; i < 9 * CB; i += 256) red[i] = 0.0f;
+  for (int i = tid; i < 11 * CB; i += 256) red[i] = 0.0f;
   for (int i = tid; i < CB; i += 256) {
     const int cc = cb * CB + i;
     Cs[i] = ot.sc[cc]; Cs[CB + i] = ot.sh[cc]; Cs[2 * CB + i] = save[2 * cc]; Cs[3 * CB + i] = save[2 * cc + 1];
@@ -821,6 +880,16 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
   f32x4 dw[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) dw[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 r1 = {0.f, 0.f, 0.f, 0.f}, r2 = {0.f, 0.f, 0.f, 0.f};
+  auto reduce_in = [&](const f32x4& zv, const f32x4& dx) {      // dx = data gradient of the input pixel with raw value zv
+    const f32x4 i_sc = JN_C4(7), i_sh = JN_C4(8);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gy = dx[k] * dsilu_(fmaf(zv[k], i_sc[k], i_sh[k]));
+      r1[k] += gy;
+      r2[k] += gy * zv[k];          // raw second moment: bn_bwd_consts turns it into sum gy * zhat (fp64)
+    }
+  };
   const int xx = (tid / Q) % DF_TW, grp = tid / (Q * DF_TW), j0 = grp * RPG;
   const int wg = blockIdx.x / ncb, n_wg = gridDim.x / ncb;
   for (int tile = wg; tile < n_tiles; tile += n_wg) {
@@ -863,6 +932,9 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
       if (S == 1) {
         // input pixel (y, xx) == output pixel (y, xx); Gs / As carry a 1-pixel halo
         const f32x4 gc = *reinterpret_cast<const f32x4*>(Gs + ((y + 1) * GW + xx + 1) * PS + 4 * q);
+        f32x4 zin = {0.f, 0.f, 0.f, 0.f};              // RED: raw z of this input pixel, requested before the tap loop
+        if (RED && oy0 + y < H && ox0 + xx < W)
+          zin = *reinterpret_cast<const f32x4*>(x + (((long long)n * H + oy0 + y) * W + ox0 + xx) * x_ld + c);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -874,6 +946,7 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
         const int iy = oy0 + y, ix = ox0 + xx;
         if (iy < H && ix < W) {
           float* op = gin + (((long long)n * H + iy) * W + ix) * gin_ld + c;
+          if (RED) reduce_in(zin, acc);
           if (accumulate) acc += *reinterpret_cast<const f32x4*>(op);
           *reinterpret_cast<f32x4*>(op) = acc;
         }
@@ -899,6 +972,7 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
           if (iy < H && ix < W) {
             float* op = gin + (((long long)n * H + iy) * W + ix) * gin_ld + c;
             f32x4 v = r[d];
+            if (RED) reduce_in(*reinterpret_cast<const f32x4*>(x + (((long long)n * H + iy) * W + ix) * x_ld + c), v);
             if (accumulate) v += *reinterpret_cast<const f32x4*>(op);
             *reinterpret_cast<f32x4*>(op) = v;
           }
@@ -916,28 +990,45 @@ __global__ __launch_bounds__(256) void dw_bwd_fused_kernel(
       for (int off = Q; off < 64; off <<= 1) v += __shfl_xor(v, off);
       if (lane < Q) atomicAdd(&red[t * CB + 4 * q + k], v);
     }
+  if (RED) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float a = r1[k], b = r2[k];
+      for (int off = Q; off < 64; off <<= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+      if (lane < Q) { atomicAdd(&red[9 * CB + 2 * (4 * q + k)], a); atomicAdd(&red[9 * CB + 2 * (4 * q + k) + 1], b); }
+    }
+  }
   __syncthreads();
   float* dst = (rep ? gw + ((wg + 5 * blockIdx.y) % JN_NREP) * JN_WPART_MAX : gw);
   for (int i = tid; i < 9 * CB; i += 256) atomicAdd(&dst[(i / CB) * C + cb * CB + (i % CB)], red[i]);
+  if (RED)
+    if (tid < 2 * CB) atomicAdd(&red_in[(wg % JN_NREP) * red_rep_stride + 2 * cb * CB + tid], (double)red[9 * CB + tid]);
 #undef JN_C4
 }
 
-template <int S, int CB, int DF_TH>
-static void launch_dw_bwd_fused_t(const DwBwdFusedArgs& a, hipStream_t s) {
+template <int S, int CB, int DF_TH, bool RED>
+static void launch_dw_bwd_fused_r(const DwBwdFusedArgs& a, hipStream_t s) {
   constexpr int PS = S == 1 ? CB : CB + 4;
   constexpr int GH = S == 1 ? DF_TH + 2 : DF_TH + 1, GW = S == 1 ? DF_TW + 2 : DF_TW + 1;
   constexpr int AH = S == 1 ? DF_TH + 2 : 2 * DF_TH + 1, AW = S == 1 ? DF_TW + 2 : 2 * DF_TW + 1;
-  const size_t smem = ((size_t)(GH * GW + AH * AW) * PS + 9 * CB + 19 * CB) * sizeof(float);
+  const size_t smem = ((size_t)(GH * GW + AH * AW) * PS + 11 * CB + 19 * CB) * sizeof(float);
   const int tiles_x = (a.OW + DF_TW - 1) / DF_TW, tiles_y = (a.OH + DF_TH - 1) / DF_TH;
   const int n_tiles = tiles_x * tiles_y * a.N, ncb = a.C / CB;
   int n_wg = 1536 / (ncb * a.sb.n);                 // persistent: one set of weight-gradient atomics per workgroup
   if (n_wg < 8) n_wg = 8;
   if (n_wg > n_tiles) n_wg = n_tiles;
   const int rep = (a.wpart && 9 * a.C <= JN_WPART_MAX) ? 1 : 0;
-  hipLaunchKernelGGL((dw_bwd_fused_kernel<S, CB, DF_TH>), dim3((unsigned)(n_wg * ncb), a.sb.n), dim3(256), smem, s, a.g, a.g_ld, a.z,
+  hipLaunchKernelGGL((dw_bwd_fused_kernel<S, CB, DF_TH, RED>), dim3((unsigned)(n_wg * ncb), a.sb.n), dim3(256), smem, s, a.g, a.g_ld, a.z,
                      a.z_ld, a.ot, a.save, a.consts, a.x, a.x_ld, a.it, a.w, a.gin, a.gin_ld, a.accumulate,
-                     rep ? a.wpart : a.gw, rep, a.C, a.H, a.W, a.OH, a.OW, tiles_x, tiles_y, n_tiles, a.sb);
+                     rep ? a.wpart : a.gw, rep, a.C, a.H, a.W, a.OH, a.OW, tiles_x, tiles_y, n_tiles, a.sb, a.red_in,
+                     a.red_rep_stride);
   if (rep) launch_wpart_reduce(a.gw, a.wpart, 9 * a.C, s);
+}
+
+template <int S, int CB, int DF_TH>
+static void launch_dw_bwd_fused_t(const DwBwdFusedArgs& a, hipStream_t s) {
+  if (a.red_in) launch_dw_bwd_fused_r<S, CB, DF_TH, true>(a, s);
+  else launch_dw_bwd_fused_r<S, CB, DF_TH, false>(a, s);
 }
 
 bool dw_bwd_fused_supported(int C, int H, int W, int OH, int OW, int stride) {
