@@ -158,6 +158,19 @@ int jn_gather_patches_indexed(const float* images_dev, const int64_t* image_inde
                               const int64_t* positions_dev, float* out_dev, int N, int n_images,
                               int C, int H, int W, int P, void* stream);
 
+/* ---- detection augmentation ------------------------------------- */
+/* Trainer.init_detection's on-device chain (src/trainer.py:176-186, applied at src/reinforce.py:332-333 and
+ * src/supervised.py:855-861, 884-885) fused into one pass: RandomPlanckianJitter (per-patch red / blue gains,
+ * clamp to [0,1]) -> RandomGrayscale -> RandomGaussianBlur 3x3 (reflect border) -> RandomGaussianNoise ->
+ * RandomMotionBlur 3x3 (zero border).  RandomPlasmaShadow is not implemented (kornia's fractal generator is not in
+ * the reference).  patches [N,3,P,P] f32 -> out (must not alias); params [N,16] f32 per patch = r_gain, b_gain,
+ * gray flag, Gaussian centre weight, Gaussian side weight, noise std, motion kernel k[3][3] row-major, pad; an op
+ * a patch did not draw is encoded as the identity (1, 1, 0, 1, 0, 0, delta).  noise_dev: optional [N,3,P,P]
+ * standard-normal field (parity runs); NULL = counter-based generator seeded by `seed`. */
+#define JN_AUG_NPARAM 16
+int jn_augment_patches(const float* in_dev, float* out_dev, const float* params_dev, const float* noise_dev,
+                       uint64_t seed, int N, int P, void* stream);
+
 /* ---- networks ------------------------------------------------------------------- */
 /* YOLOPAFPN.forward as called at src/models/gpt.py:375 / src/models/yolox.py:55 "with the
  * current mode of the model": train = 0 uses the BatchNorm running statistics, train != 0

@@ -15,6 +15,8 @@ from .yolox import NeedleYOLOX  # noqa: F401
 from .reinforce import ReinforceTrainer  # noqa: F401
 from .supervised import SupervisedTrainer  # noqa: F401
 from .data import padded_collate, synthetic_batch  # noqa: F401
+from .augment import DetectionAugment  # noqa: F401
+from .trajectory import NeedleSimpleEnv  # noqa: F401
 from .detection import (patch_bboxes2full_image, merge_boxes, merge_boxes_batched,  # noqa: F401
                         compute_detection_metrics, detection_targets)
 

@@ -1419,6 +1419,17 @@ int jn_gather_patches(const float* images_dev, const int64_t* positions_dev, flo
   return JN_OK;
 }
 
+int jn_augment_patches(const float* in_dev, float* out_dev, const float* params_dev, const float* noise_dev, uint64_t seed,
+                       int N, int P, void* stream) {
+  JN_CHECK(in_dev && out_dev && params_dev, JN_EINVAL, "jn_augment_patches: null argument");
+  JN_CHECK(in_dev != out_dev, JN_EINVAL, "jn_augment_patches: in-place is not supported (tiles read their neighbours' halo)");
+  JN_CHECK(N >= 0 && P >= 4, JN_EINVAL, "jn_augment_patches: bad shape");
+  if (N == 0) return JN_OK;
+  launch_augment(in_dev, out_dev, params_dev, noise_dev, (unsigned long long)seed, N, P, (hipStream_t)stream);
+  JN_HIP(hipGetLastError());
+  return JN_OK;
+}
+
 int jn_gather_patches_indexed(const float* images_dev, const int64_t* image_index_dev, const int64_t* positions_dev,
                               float* out_dev, int N, int n_images, int C, int H, int W, int P, void* stream) {
   JN_CHECK(images_dev && image_index_dev && positions_dev && out_dev, JN_EINVAL, "jn_gather_patches_indexed: null argument");

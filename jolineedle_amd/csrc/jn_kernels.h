@@ -180,6 +180,11 @@ int launch_nchw_to_nhwc_grad(const float* in, float* out, int out_ld, int C, int
                              hipStream_t s);
 
 // ---- env / rollout primitives (kernels_env.hip) -------------------------------------
+// fused detection augmentation (kernels_aug.hip): params [N][AUG_NPARAM] = r_gain, b_gain, gray flag, gauss centre weight,
+// gauss side weight, noise std, motion kernel [3][3] (row-major), 1 pad
+constexpr int AUG_NPARAM = 16;
+int launch_augment(const float* in, float* out, const float* params, const float* noise, unsigned long long seed, int N, int P,
+                   hipStream_t s);
 int launch_gather(const float* images, const int64_t* positions, float* out, long long out_sample_stride,
                   int B, int C, int H, int W, int P, const int* skip_flag, int skip_when, hipStream_t s,
                   const int64_t* image_index = nullptr);

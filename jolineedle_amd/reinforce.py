@@ -111,6 +111,15 @@ class ReinforceTrainer:
                              for b in range(B)]
         return res
 
+    def init_detection(self, **kw):
+        """``Trainer.init_detection`` (src/trainer.py:176-186): installs the on-device augmentation of the detector
+        patches.  Off until called (the parity tests compare un-augmented steps); keyword arguments go to
+        ``augment.DetectionAugment`` (e.g. ``planckian_coeffs``)."""
+        from .augment import DetectionAugment
+        kw.setdefault("seed", int(getattr(self.config, "seed", 0)) + 17 * int(getattr(self, "rank", 0)))
+        self.detection_augment = DetectionAugment(**kw)
+        return self.detection_augment
+
     # ---- training: one REINFORCE iteration (src/reinforce.py:302-353) ------------------------
     def _grad_arena(self):
         """Flat fp32 gradient buffer shared with the engine (torch-owned so that RCCL can
@@ -179,6 +188,8 @@ class ReinforceTrainer:
         yolo_losses = {}
         if detection:
             patches_y, boxes_y = env.get_detection_batch(int(getattr(self.config, "detection_sample_neg", 1)))
+            if getattr(self, "detection_augment", None) is not None:               # src/reinforce.py:332-333
+                patches_y = self.detection_augment(patches_y)
             _, _, yolo_losses = self.yolox_model()(patches_y, boxes_y, loss_scale=1.0 / ga)
         if optimizer_step and self.iter_num % ga == 0:
             # the ONE exchange step of the iteration: flat gradient all-reduce (RCCL over xGMI)

@@ -2,7 +2,7 @@
 (src/supervised.py:138-177 loss, :863-902 step) over ``jn_supervised_step``, fed by teacher trajectories
 (``generate_trajectories``, src/supervised.py:95-136, over trajectory.NeedleSimpleEnv) whose patches are gathered on
 the device, and followed by the detector step on the trajectories' detector patches (src/supervised.py:881-902).
-Augmentation and the evaluation suite are out of scope."""
+The evaluation suite is out of scope; augmentation is opt-in (``init_detection``)."""
 import ctypes as C
 from typing import Dict, Optional, Tuple
 
@@ -30,6 +30,14 @@ class SupervisedTrainer:
             self._optim_numel = gpt.value
             check(eng.lib.jn_set_grad_arena(eng.handle, ptr(self._flat_grads), tot.value), "jn_set_grad_arena")
         return self._flat_grads
+
+    def init_detection(self, **kw):
+        """``Trainer.init_detection`` (src/trainer.py:176-186): on-device augmentation of the trajectory patches and the
+        detector patches (src/supervised.py:855-861, 884-885).  Off until called."""
+        from .augment import DetectionAugment
+        kw.setdefault("seed", int(getattr(self.config, "seed", 0)) + 17 * int(self.rank))
+        self.detection_augment = DetectionAugment(**kw)
+        return self.detection_augment
 
     def generate_trajectories(self, batch: Dict, position: Optional[Tuple[int, int]] = None, seed: Optional[int] = None) -> Dict:
         """One teacher walk per image of `batch` (``image`` [B, C, H, W] on the device or a list of [C, H, W] of one
@@ -75,6 +83,11 @@ class SupervisedTrainer:
         else:
             ref_actions = nxt
         detection = self.model.yolox is not None and bool(getattr(cfg, "detection_enabled", True))
+        aug = getattr(self, "detection_augment", None)
+        if aug is not None:
+            B_, T_ = cur.shape
+            tr["patches"] = aug(tr["patches"].flatten(0, 1)).view(B_, T_, *tr["patches"].shape[2:])
+            tr["patches_yolox"] = aug(tr["patches_yolox"])
         res = self.train_step(tr["patches"], cur, ref_actions, tr["positions"], masks, optimizer_step=False)
         ga = int(getattr(cfg, "gradient_accumulation", 1))
         if detection:

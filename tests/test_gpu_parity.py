@@ -1002,3 +1002,48 @@ def test_supervised_iteration_on_generated_trajectories():
     assert moved_gpt > 50 and moved_det > 50
     m2 = tr.train_iteration(batch, seed=5)                      # same walks again: the loss went down
     assert float(m2["action_loss"]) < float(m["action_loss"])
+
+
+# --------------------------------------------------------------------------------------
+# detection augmentation: the fused pass == the op chain of the oracle for the same parameters
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,P", [(5, 64), (3, 448), (4, 37), (2, 4)])
+def test_augment_fused_pass_vs_oracle(N, P):
+    from jolineedle_amd.augment import DetectionAugment
+    from oracle.augment_ref import augment_ref
+    g = torch.Generator().manual_seed(N * 7 + P)
+    x = torch.rand((N, 3, P, P), generator=g)
+    noise = torch.randn((N, 3, P, P), generator=g)
+    aug = DetectionAugment(planckian_coeffs=torch.tensor([[1.25, 0.7], [0.85, 1.3], [1.05, 0.95]]), p_planckian=0.7, p_gray=0.4,
+                           p_blur=0.7, p_noise=0.6, p_motion=0.6, seed=N + P)
+    prm = aug.sample_params(N)
+    prm[0, 3], prm[0, 4], prm[0, 5] = 0.5, 0.25, 0.05                  # make sure every op is exercised at least once
+    prm[0, 6:15] = torch.tensor([0.2, 0.1, 0.0, 0.1, 0.2, 0.1, 0.0, 0.1, 0.2])
+    prm[-1, 0], prm[-1, 1], prm[-1, 2] = 1.4, 0.6, 1.0
+    got = aug(x.to(DEV), params=prm, noise=noise.to(DEV)).cpu()
+    want = augment_ref(x, prm, noise)
+    assert (got - want).abs().max() < 2e-6
+    ident = torch.zeros_like(prm); ident[:, 0] = ident[:, 1] = ident[:, 3] = ident[:, 10] = 1.0
+    assert torch.equal(aug(x.to(DEV), params=ident).cpu(), x)          # undrawn ops are exact identities
+
+
+def test_augment_device_noise_statistics_and_trainer_hook():
+    from jolineedle_amd.augment import DetectionAugment
+    aug = DetectionAugment(p_planckian=0, p_gray=0, p_blur=0, p_noise=1.0, p_motion=0, noise_std=0.05, seed=9)
+    x = torch.full((4, 3, 256, 256), 0.5, device=DEV)
+    d = (aug(x) - x).cpu()
+    assert abs(float(d.mean())) < 2e-4 and abs(float(d.std()) - 0.05) < 5e-4
+    k = float(((d / 0.05) ** 4).mean())                                # kurtosis of a normal = 3
+    assert abs(k - 3.0) < 0.1
+    assert abs(float((d[:, :, :, :-1] * d[:, :, :, 1:]).mean())) / 0.05 ** 2 < 0.02      # neighbours uncorrelated
+    d2 = (aug(x) - x).cpu()
+    assert not torch.equal(d, d2)                                      # a new field per call
+    # trainer hook: opt-in, applied to the detector patches of a REINFORCE iteration
+    product, _ = make_pair(3, patch_size=64, block_size=3, image_processor="yolox-nano", gpt_backbone="yolox-nano")
+    images, bboxes, start = synth_batch(2, 3, 3, 64, seed=1)
+    env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, 64, 3, 1, True)
+    tr = ja.ReinforceTrainer(_cfg(T=3, learning_rate=1e-3, gradient_accumulation=1, detection_enabled=True), product)
+    assert getattr(tr, "detection_augment", None) is None
+    tr.init_detection()
+    m = tr.train_iteration(env, start_positions=start)
+    assert tr.detection_augment.calls == 1 and np.isfinite(float(m["yolo_total_loss"]))

@@ -166,3 +166,48 @@ def test_padded_collate_layout():
     bb = s1["bboxes"]
     valid = bb.abs().sum(-1) > 0
     assert valid[:, 0].all() and (bb[valid][:, 2] <= 256).all() and (bb[valid][:, 2] > bb[valid][:, 0]).all()
+
+
+# --------------------------------------------------------------------------------------
+# detection augmentation: host-side parameter logic and the oracle's identities (no GPU)
+# --------------------------------------------------------------------------------------
+def test_augment_parameter_sampling_and_kernels():
+    from jolineedle_amd.augment import DetectionAugment, NPARAM, gaussian_weights3, motion_kernel3
+    w0, w1 = gaussian_weights3(torch.tensor([0.1, 0.7, 2.0]))
+    assert torch.allclose(w0 + 2 * w1, torch.ones(3)) and float(w1[0]) < 1e-20 and (w1[1:] > 0).all() and (w0 > w1).all()
+    for ang in (-180.0, -37.0, 0.0, 45.0, 90.0, 133.0):
+        k = motion_kernel3(ang)
+        assert abs(float(k.sum()) - 1.0) < 1e-6 and (k >= 0).all()
+        assert torch.allclose(k, k.flip(0, 1), atol=1e-6)               # a line through the centre is point-symmetric
+    assert torch.allclose(motion_kernel3(0.0)[1], torch.full((3,), 1 / 3))
+    assert torch.allclose(motion_kernel3(90.0)[:, 1], torch.full((3,), 1 / 3), atol=1e-6)
+    aug = DetectionAugment(planckian_coeffs=torch.tensor([[1.3, 0.7], [0.8, 1.2]]), seed=5)
+    prm = aug.sample_params(4000)
+    assert prm.shape == (4000, NPARAM)
+    ident = torch.zeros(NPARAM); ident[0] = ident[1] = ident[3] = ident[10] = 1.0
+    frac = lambda m: float(m.float().mean())
+    assert abs(frac(prm[:, 0] != 1.0) - 0.5) < 0.04 and abs(frac(prm[:, 2] != 0) - 0.2) < 0.03
+    assert abs(frac(prm[:, 4] != 0) - 0.5) < 0.04 and abs(frac(prm[:, 5] != 0) - 0.5) < 0.04
+    assert abs(frac(prm[:, 10] != 1.0) - 0.3) < 0.04
+    assert torch.allclose(prm[:, 3] + 2 * prm[:, 4], torch.ones(4000), atol=1e-6)
+    assert torch.allclose(prm[:, 6:15].sum(1), torch.ones(4000), atol=1e-5)
+    no_table = DetectionAugment(seed=5).sample_params(100)
+    assert (no_table[:, :2] == 1.0).all()                               # Planckian jitter needs the caller's table
+    assert (DetectionAugment(p_planckian=0, p_gray=0, p_blur=0, p_noise=0, p_motion=0).sample_params(7) == ident).all()
+
+
+def test_augment_oracle_identities():
+    from jolineedle_amd.augment import NPARAM
+    from oracle.augment_ref import augment_ref
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand((2, 3, 12, 12), generator=g)
+    nz = torch.randn((2, 3, 12, 12), generator=g)
+    ident = torch.zeros((2, NPARAM)); ident[:, 0] = ident[:, 1] = ident[:, 3] = ident[:, 10] = 1.0
+    assert torch.allclose(augment_ref(x, ident, nz), x, atol=1e-7)
+    p = ident.clone(); p[:, 2] = 1.0
+    y = augment_ref(x, p, nz)
+    assert torch.allclose(y[:, 0], y[:, 1]) and torch.allclose(y[:, 0], 0.299 * x[:, 0] + 0.587 * x[:, 1] + 0.114 * x[:, 2], atol=1e-6)
+    p = ident.clone(); p[:, 5] = 0.05
+    assert torch.allclose(augment_ref(x, p, nz), x + 0.05 * nz, atol=1e-6)
+    p = ident.clone(); p[:, 3], p[:, 4] = 0.5, 0.25                      # blur keeps a constant image constant (reflect border)
+    assert torch.allclose(augment_ref(torch.full_like(x, 0.3), p, nz), torch.full_like(x, 0.3), atol=1e-6)
