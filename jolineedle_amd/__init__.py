@@ -16,6 +16,9 @@ from .reinforce import ReinforceTrainer  # noqa: F401
 from .supervised import SupervisedTrainer  # noqa: F401
 from .data import padded_collate, synthetic_batch  # noqa: F401
 from .augment import DetectionAugment  # noqa: F401
+from .checkpoint import (save_config, config_from_file, save_checkpoint, load_checkpoint,  # noqa: F401
+                         load_detection_checkpoint)
+from .infer import infer_images, pad_to_patch_multiple, load_bboxes  # noqa: F401
 from .trajectory import NeedleSimpleEnv  # noqa: F401
 from .detection import (patch_bboxes2full_image, merge_boxes, merge_boxes_batched,  # noqa: F401
                         compute_detection_metrics, detection_targets)

@@ -1047,3 +1047,64 @@ def test_augment_device_noise_statistics_and_trainer_hook():
     tr.init_detection()
     m = tr.train_iteration(env, start_positions=start)
     assert tr.detection_augment.calls == 1 and np.isfinite(float(m["yolo_total_loss"]))
+
+
+# --------------------------------------------------------------------------------------
+# checkpoints and infer
+# --------------------------------------------------------------------------------------
+def test_checkpoint_round_trip_and_detection_checkpoint(tmp_path):
+    product, oracle = make_pair(4, patch_size=64, block_size=4, image_processor="yolox-nano", gpt_backbone="yolox-nano")
+    patches, actions, positions = synth_tokens(2, 4, 64, 9, 5, seed=3)
+    lg0, _ = product(patches, actions, torch.zeros(2, dtype=torch.long), positions)
+    # a reference-style checkpoint (DDP prefixes, optimiser entries) written by hand from the oracle's weights
+    ck = {"model": {"module." + k: v for k, v in oracle.state_dict().items()}, "optimizer-gpt": {"state": {}}, "optimizer-yolox": {}}
+    torch.save(ck, tmp_path / "checkpoint_best.pt")
+    other, _ = make_pair(5, patch_size=64, block_size=4, image_processor="yolox-nano", gpt_backbone="yolox-nano")
+    lg_other, _ = other(patches, actions, torch.zeros(2, dtype=torch.long), positions)
+    assert (lg_other - lg0).abs().max() > 1e-3
+    ja.load_checkpoint(ja.CfgNode(resume_training=str(tmp_path)), other, best=True)
+    lg1, _ = other(patches, actions, torch.zeros(2, dtype=torch.long), positions)
+    assert torch.equal(lg1, lg0)
+    # our own checkpoint: engine-side (trained) weights are pulled before saving
+    path = ja.save_checkpoint(other, tmp_path / "mine")
+    saved = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(saved) >= {"model", "optimizer-gpt", "optimizer-yolox"} and set(saved["model"]) == set(oracle.state_dict())
+    # detection checkpoint: only yolox.* is replaced
+    third, o3 = make_pair(6, patch_size=64, block_size=4, image_processor="yolox-nano", gpt_backbone="yolox-nano")
+    ja.load_detection_checkpoint(ja.CfgNode(detection_checkpoint=str(tmp_path / "checkpoint_best.pt")), third)
+    sd3, sd0 = third.state_dict(), oracle.state_dict()
+    assert all(torch.equal(sd3[k], sd0[k]) for k in sd0 if k.startswith("yolox."))
+    assert any(not torch.equal(sd3[k], sd0[k]) for k in sd0 if k.startswith("transformer."))
+    x = torch.rand(2, 3, 64, 64)
+    assert torch.equal(third.yolox(x)[1][2], product.yolox(x)[1][2])      # same detector features now
+
+
+def test_infer_images_pads_and_maps_boxes_to_the_full_image():
+    P, T = 64, 5
+    product, _ = make_pair(8, patch_size=P, block_size=T, image_processor="yolox-nano", gpt_backbone="yolox-nano",
+                           detector_conf_threshold=0.2)
+    cfg = ja.CfgNode(patch_size=P, max_seq_len=T, stop_enabled=True, detection_enabled=True, entropy_weight=0.01,
+                     reward_norm=False, seed=2)
+    tr = ja.ReinforceTrainer(cfg, product)
+    g = torch.Generator().manual_seed(5)
+    images = [(torch.rand((3, 150, 200), generator=g) * 255).to(torch.uint8), torch.rand((3, 128, 64), generator=g)]
+    targets = [[[20, 30, 90, 100]], None]
+    out = ja.infer_images(tr, images, targets, sample_actions=False)
+    assert len(out["boxes"]) == 2 and out["steps"][0] <= T and len(out["duration_ms"]) == 2
+    assert {"returns", "episode_length", "prop_patches_found", "map"} <= set(out["metrics"])
+    for img, boxes, pos in zip(images, out["boxes"], out["positions"]):
+        H, W = -(-img.shape[1] // P) * P, -(-img.shape[2] // P) * P
+        assert (pos[:, 0] < H // P).all() and (pos[:, 1] < W // P).all()
+        if boxes is not None:
+            assert boxes.shape[1] == 7 and (boxes[:, 0] >= 0).all() and (boxes[:, 2] <= W).all() and (boxes[:, 3] <= H).all()
+    # plumbing: the boxes of the first visited patch are the detector's boxes on that patch of the PADDED [0, 1] image,
+    # shifted by the patch origin (the detector itself is checked against the oracle elsewhere)
+    pad = ja.pad_to_patch_multiple((images[0].float() / 255)[None], P)
+    y0, x0 = out["positions"][0][0].tolist()
+    det = product.yolox(pad[:, :, y0 * P:(y0 + 1) * P, x0 * P:(x0 + 1) * P])[0][0]
+    assert det is not None and out["boxes"][0] is not None
+    want = det.cpu().clone()
+    want[:, [0, 2]] += x0 * P
+    want[:, [1, 3]] += y0 * P
+    got = out["boxes"][0][: len(want)].cpu()                 # same set; boxes of equal score (zero padding) may swap places
+    assert ((got[:, None, :] - want[None, :, :]).abs().max(dim=2).values.min(dim=0).values < 2e-3).all()

@@ -211,3 +211,34 @@ def test_augment_oracle_identities():
     assert torch.allclose(augment_ref(x, p, nz), x + 0.05 * nz, atol=1e-6)
     p = ident.clone(); p[:, 3], p[:, 4] = 0.5, 0.25                      # blur keeps a constant image constant (reflect border)
     assert torch.allclose(augment_ref(torch.full_like(x, 0.3), p, nz), torch.full_like(x, 0.3), atol=1e-6)
+
+
+# --------------------------------------------------------------------------------------
+# config.json / infer helpers: host logic, no GPU
+# --------------------------------------------------------------------------------------
+def test_config_json_round_trip_and_infer_helpers(tmp_path):
+    import json
+    import jolineedle_amd as ja
+    from tests.helpers import model_config
+    mc = model_config(patch_size=64, block_size=4)
+    tc = ja.CfgNode(patch_size=64, max_seq_len=4, stop_enabled=True, work_dir=str(tmp_path), env_name="run",
+                    filter_classes={"plane", "runway"}, learning_rate=1e-4)
+    path = ja.save_config(mc, tc)
+    assert path == tmp_path / "run" / "config.json"                       # main.py:436-449 location
+    cj = json.load(open(path))
+    assert set(cj) == {"model", "train"} and cj["train"]["filter_classes"] in (["plane", "runway"], ["runway", "plane"])
+    assert cj["model"]["actions_info"] == [{"action_type": "categorical", "nclasses": 9}]
+    t2, m2 = ja.config_from_file(path)
+    assert (t2.patch_size, t2.max_seq_len, t2.stop_enabled) == (64, 4, True)
+    assert (m2.model_type, m2.gpt_backbone, m2.block_size) == ("gpt-nano", "yolox-nano", 4)
+    assert not hasattr(m2, "actions_info")                                # rebuilt by the caller (infer.py:85-86)
+    m2.actions_info = ja.get_actions_info(t2)
+    assert m2.actions_info[0].nclasses == 9
+    # image padding of infer.py:138-146 and the "cls x1 y1 x2 y2" target files
+    x = torch.ones(1, 3, 100, 130)
+    y = ja.pad_to_patch_multiple(x, 64)
+    assert y.shape == (1, 3, 128, 192) and float(y[..., 100:, :].abs().sum()) == 0 and float(y[..., :, 130:].abs().sum()) == 0
+    assert torch.equal(y[..., :100, :130], x) and ja.pad_to_patch_multiple(torch.ones(1, 3, 128, 64), 64).shape == (1, 3, 128, 64)
+    f = tmp_path / "boxes.txt"
+    f.write_text("0 10 20 30 40\n1 5 6 7 8 0.9\n\n")
+    assert ja.load_bboxes(f) == [[10, 20, 30, 40], [5, 6, 7, 8]]
