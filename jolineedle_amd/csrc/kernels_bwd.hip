@@ -1044,6 +1044,10 @@ int launch_dw_bwd_fused(const DwBwdFusedArgs& a, hipStream_t s) {
 
 // ---- 4c. stem weight gradient: dW[(c,dy,dx)][oc] += sum_pixels gz[p][oc] * img[c][2oy-2+dy][2ox-2+dx]
 constexpr int SB_TY = 8, SB_TX = 32, SB_IH = 2 * SB_TY + 4, SB_IW = 2 * SB_TX + 4;
+// LDS layouts chosen for conflict-free MFMA operand reads (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE was 0.43):
+// image rows 70 floats apart -> tap (dy, dx) of 16 consecutive k lands on bank 6 dy + dx = k % 36, consecutive; the four
+// k-slots of an MFMA take pixels 8 apart (16 banks apart); g_z rows of 8 pixels are padded by 16 floats per slot group
+constexpr int SB_IWP = 70, SB_GZG = 8 * 16 + 16, SB_GZROW = 4 * SB_GZG;
 
 __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
     const float* __restrict__ src, const long long* __restrict__ pos, int pos_stride, long long sample_stride,
@@ -1051,7 +1055,7 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
     int tiles_x, int tiles_y, int n_tiles, float* __restrict__ gw, long long pos_slot, long long g_slot,
     const float* __restrict__ z, int z_ld, ChanTab ot, const float* __restrict__ save,
     const float* __restrict__ consts, SlotBatch sb) {
-  __shared__ __attribute__((aligned(16))) float tile[3 * SB_IH * SB_IW];
+  __shared__ __attribute__((aligned(16))) float tile[3 * SB_IH * SB_IWP];
   if (pos) pos += blockIdx.z * pos_slot;
   gz += blockIdx.z * g_slot;
   // z != null: `gz` holds d loss / d activation and g_z is formed while staging (no bn_bwd_gz pass over the
@@ -1067,7 +1071,7 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
       o_c1[q] = consts[3 * c]; o_c2[q] = consts[3 * c + 1]; o_k[q] = consts[3 * c + 2];
     }
   }
-  __shared__ float Gz[SB_TY * SB_TX * 16];
+  __shared__ __attribute__((aligned(16))) float Gz[SB_TY * SB_GZROW];
   __shared__ float Ts[16 * 112];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, g = lane >> 4;
@@ -1079,7 +1083,7 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
   for (int t = 0; t < 7; ++t) {
     const int k = 16 * t + lm;
     const int c = k / 36, dy = (k % 36) / 6, dx = k % 6;
-    koff[t] = k < 108 ? (c * SB_IH + dy) * SB_IW + dx : 0;
+    koff[t] = k < 108 ? (c * SB_IH + dy) * SB_IWP + dx : 0;
   }
   f32x4 acc[7];
 #pragma unroll
@@ -1122,7 +1126,7 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int i = tid + 256 * j;
-      if (i < 3 * SB_IH * SB_IW) tile[i] = pim[j];
+      if (i < 3 * SB_IH * SB_IW) tile[(i / SB_IW) * SB_IWP + i % SB_IW] = pim[j];
     }
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
@@ -1139,15 +1143,19 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
           v[k] = inside ? o_k[k] * (gy - o_c1[k] - zh * o_c2[k]) : 0.0f;
         }
       }
-      *reinterpret_cast<f32x4*>(&Gz[i * 4]) = v;
+      {
+        const int p = i >> 2, ty = p / SB_TX, tx = p % SB_TX;
+        *reinterpret_cast<f32x4*>(&Gz[ty * SB_GZROW + (tx >> 3) * SB_GZG + (tx & 7) * 16 + 4 * (i & 3)]) = v;
+      }
     }
     __syncthreads();
     if (tl + (int)gridDim.x < n_tiles) fetch(tl + gridDim.x);
+#pragma unroll 2
     for (int st = 0; st < SB_TY * SB_TX / 16; ++st) {
-      const int p = wave * (SB_TY * SB_TX / 4) + 4 * st + g;   // pixel of this k-step for this lane group
-      const int ty = p / SB_TX, tx = p % SB_TX;
-      const float av = Gz[p * 16 + lm];                     // A[i = oc][kk = pixel]
-      const int pbase = (2 * ty) * SB_IW + 2 * tx;
+      // the wave owns tile rows 2 wave, 2 wave + 1; k-slot g of this step = pixel (ty, 8 g + st % 8)
+      const int ty = 2 * wave + (st >> 3), tx = 8 * g + (st & 7);
+      const float av = Gz[ty * SB_GZROW + g * SB_GZG + (st & 7) * 16 + lm];     // A[i = oc][kk = pixel]
+      const int pbase = (2 * ty) * SB_IWP + 2 * tx;
 #pragma unroll
       for (int t = 0; t < 7; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, tile[pbase + koff[t]], acc[t], 0, 0, 0);
