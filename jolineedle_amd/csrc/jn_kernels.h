@@ -182,6 +182,10 @@ int launch_nchw_to_nhwc_grad(const float* in, float* out, int out_ld, int C, int
 // ---- env / rollout primitives (kernels_env.hip) -------------------------------------
 // fused detection augmentation (kernels_aug.hip): params [N][AUG_NPARAM] = r_gain, b_gain, gray flag, gauss centre weight,
 // gauss side weight, noise std, motion kernel [3][3] (row-major), 1 pad
+#ifndef JN_DW_S2_PAD
+#define JN_DW_S2_PAD 4      // LDS pixel-stride padding (floats) of the stride-2 depthwise tiles; 8 removes the bank
+                            // conflicts the PMC shows (0.3-0.4 of the LDS-active cycles) but not a microsecond: 126.9 vs 127.3 ms
+#endif
 constexpr int AUG_NPARAM = 16;
 int launch_augment(const float* in, float* out, const float* params, const float* noise, unsigned long long seed, int N, int P,
                    hipStream_t s);

@@ -845,7 +845,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void d
     ChanTab it, const float* __restrict__ w, float* __restrict__ gin, int gin_ld, int accumulate,
     float* __restrict__ gw, int rep, int C, int H, int W, int OH, int OW, int tiles_x, int tiles_y, int n_tiles,
     SlotBatch sb, double* __restrict__ red_in, long long red_rep_stride) {
-  constexpr int Q = CB / 4, PS = S == 1 ? CB : CB + 4;     // stride-1 taps: a wave reads 1 KB contiguous, no padding
+  constexpr int Q = CB / 4, PS = S == 1 ? CB : CB + JN_DW_S2_PAD;     // stride-1 taps: a wave reads 1 KB contiguous, no padding
   constexpr int GH = S == 1 ? DF_TH + 2 : DF_TH + 1, GW = S == 1 ? DF_TW + 2 : DF_TW + 1;
   constexpr int AH = S == 1 ? DF_TH + 2 : 2 * DF_TH + 1, AW = S == 1 ? DF_TW + 2 : 2 * DF_TW + 1;
   constexpr int GROUPS = 256 / (DF_TW * Q), RPG = DF_TH / GROUPS;
@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void d
 
 template <int S, int CB, int DF_TH, bool RED>
 static void launch_dw_bwd_fused_r(const DwBwdFusedArgs& a, hipStream_t s) {
-  constexpr int PS = S == 1 ? CB : CB + 4;
+  constexpr int PS = S == 1 ? CB : CB + JN_DW_S2_PAD;
   constexpr int GH = S == 1 ? DF_TH + 2 : DF_TH + 1, GW = S == 1 ? DF_TW + 2 : DF_TW + 1;
   constexpr int AH = S == 1 ? DF_TH + 2 : 2 * DF_TH + 1, AW = S == 1 ? DF_TW + 2 : 2 * DF_TW + 1;
   const size_t smem = ((size_t)(GH * GW + AH * AW) * PS + 11 * CB + 19 * CB) * sizeof(float);

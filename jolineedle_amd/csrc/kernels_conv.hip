@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void dw3x3_lds_kernel(
   if (skip_flag && *skip_flag >= skip_when) return;
   constexpr int Q = CB / 4;                          // channel quads per workgroup
   constexpr int IH = S * (DW_TH - 1) + 3, IW = S * (DW_TW - 1) + 3;
-  constexpr int PS = S == 1 ? CB : CB + 4;           // pixel stride in LDS: stride-1 taps read 1 KB contiguous per wave
+  constexpr int PS = S == 1 ? CB : CB + JN_DW_S2_PAD;           // pixel stride in LDS: stride-1 taps read 1 KB contiguous per wave
   constexpr int GROUPS = 256 / (DW_TW * Q), RPG = DW_TH / GROUPS;   // row groups, output rows per thread
   static_assert(GROUPS >= 1 && RPG >= 1 && RPG * GROUPS == DW_TH, "tile / thread mapping");
   extern __shared__ __attribute__((aligned(16))) float sm[];        // [IH*IW][PS] then red[2*CB]
@@ -351,7 +351,7 @@ template <int S, int CB, int DW_TH, typename AT>
 static void launch_dw_lds(const ConvArgs& a, hipStream_t s) {
   constexpr int IH = S * (DW_TH - 1) + 3, IW = S * (DW_TW - 1) + 3;
   const int tiles_x = (a.OW + DW_TW - 1) / DW_TW, tiles_y = (a.OH + DW_TH - 1) / DW_TH;
-  const size_t smem = ((size_t)IH * IW * (S == 1 ? CB : CB + 4) + 16 * 2 * CB) * sizeof(float);
+  const size_t smem = ((size_t)IH * IW * (S == 1 ? CB : CB + JN_DW_S2_PAD) + 16 * 2 * CB) * sizeof(float);
   dim3 grid((unsigned)(tiles_x * tiles_y * (a.cin / CB)), (unsigned)a.N);
   hipLaunchKernelGGL((dw3x3_lds_kernel<S, CB, DW_TH, AT>), grid, dim3(256), smem, s, (const AT*)a.in, a.in_ld, a.itab, a.w,
                      (AT*)a.out, a.out_ld, a.cin, a.H, a.W, a.OH, a.OW, tiles_x, tiles_y, a.stats, a.stats_rep_stride,
