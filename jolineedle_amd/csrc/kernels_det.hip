@@ -282,7 +282,8 @@ template <int S, typename AT, bool WT>
 static void launch_conv3_t(const ConvArgs& a, hipStream_t s) {
   // 8 x 16 pixels per workgroup (2 rows per wave).  16 x 16 (PR = 4) halves the weight-tile staging per MFMA but
   // measured 6 % slower in fp32 (72 KB of LDS per workgroup: fewer workgroups per CU)
-  constexpr int PR = 2, TH = 4 * PR;
+  // stride 2: 4 x 16 pixels (PR = 1) — the 18 x 34 halo tile of 8 rows left room for one workgroup per CU
+  constexpr int PR = S == 2 ? 1 : 2, TH = 4 * PR;
   const int tiles_x = (a.OW + C3_TW - 1) / C3_TW, tiles_y = (a.OH + TH - 1) / TH;
   dim3 grid(tiles_x * tiles_y * a.N, (a.cout + C3_BN - 1) / C3_BN, a.n_slots > 1 ? a.n_slots : 1);
   const size_t smem = (((size_t)(S * TH + 2) * (S * C3_TW + 2) + 9 * C3_BN) * C3_LD + 4 * 2 * C3_BN) * sizeof(float);
@@ -416,16 +417,18 @@ int launch_conv3_bwd_data_s2(const float* gz, int g_ld, const float* w, float* g
 // tile w, 2 input tiles and the 9 taps (18 accumulators), persistent over its tiles; one set of atomics at the end.
 constexpr int CW_BO = 64, CW_BK = 32, CW_LDG = CW_BO + 4, CW_LDX = CW_BK + 4;
 
-template <int S, typename XT>
+// TH = tile rows: 8 for stride 1; 4 for stride 2 (the 18 x 34 input halo tile of an 8-row tile left room for ONE
+// workgroup per CU and nothing to overlap its loads with: matrix pipe 28 % busy)
+template <int S, typename XT, int TH>
 __global__ __launch_bounds__(256) void conv3_bwd_weight_kernel(const float* __restrict__ gz, int g_ld,
                                                                const XT* __restrict__ x, int x_ld, ChanTab it,
                                                                float* __restrict__ gw, int H, int W, int OH, int OW,
                                                                int Co, int Ci, int tiles_x, int tiles_y, int n_tiles,
                                                                SlotBatch sb) {
-  constexpr int IH = C3_TH * S + 2, IW = C3_TW * S + 2;
+  constexpr int IH = TH * S + 2, IW = C3_TW * S + 2, NPIX = TH * C3_TW;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Gs = smem;                              // [128][CW_LDG]
-  float* Xs = smem + 128 * CW_LDG;               // [IH*IW][CW_LDX]
+  float* Gs = smem;                              // [NPIX][CW_LDG]
+  float* Xs = smem + NPIX * CW_LDG;               // [IH*IW][CW_LDX]
   {
     const long long sl = blockIdx.z / ((Ci + CW_BK - 1) / CW_BK);
     gz += sl * sb.grad; x += sl * sb.act;
@@ -439,9 +442,9 @@ __global__ __launch_bounds__(256) void conv3_bwd_weight_kernel(const float* __re
   for (int t = 0; t < 9; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int tr = tile % (tiles_x * tiles_y), n_img = tile / (tiles_x * tiles_y);
-    const int oy0 = (tr / tiles_x) * C3_TH, ox0 = (tr % tiles_x) * C3_TW;
+    const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * C3_TW;
     __syncthreads();
-    for (int i = tid; i < 128 * (CW_BO / 4); i += 256) {
+    for (int i = tid; i < NPIX * (CW_BO / 4); i += 256) {
       const int pix = i / (CW_BO / 4), q = i % (CW_BO / 4);
       const int oy = oy0 + pix / C3_TW, ox = ox0 + pix % C3_TW;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(256) void conv3_bwd_weight_kernel(const float* __re
     }
     __syncthreads();
 #pragma unroll 2
-    for (int st = 0; st < 32; ++st) {              // 4 pixels per k-step: lane group g takes pixel 4 st + g
+    for (int st = 0; st < NPIX / 4; ++st) {              // 4 pixels per k-step: lane group g takes pixel 4 st + g
       const int pix = 4 * st + g, ty = pix / C3_TW, tx = pix % C3_TW;
       const float av = Gs[pix * CW_LDG + 16 * wave + lm];            // A[i = cout][k = pixel]
       const float* xp = Xs + ((ty * S) * IW + tx * S) * CW_LDX + lm;
@@ -487,28 +490,29 @@ __global__ __launch_bounds__(256) void conv3_bwd_weight_kernel(const float* __re
 
 int launch_conv3_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, int x_ld, ChanTab it, float* gw, int H,
                             int W, int OH, int OW, int Co, int Ci, int N, int stride, hipStream_t s, const SlotBatch& sb) {
-  const int tiles_x = (OW + C3_TW - 1) / C3_TW, tiles_y = (OH + C3_TH - 1) / C3_TH, n_tiles = tiles_x * tiles_y * N;
+  const int TH = 4;
+  const int tiles_x = (OW + C3_TW - 1) / C3_TW, tiles_y = (OH + TH - 1) / TH, n_tiles = tiles_x * tiles_y * N;
   const int nbo = (Co + CW_BO - 1) / CW_BO, nbk = (Ci + CW_BK - 1) / CW_BK;
   long long gx = 2048 / ((long long)nbo * nbk * sb.n);      // persistent workgroups over the pixel tiles
   if (gx < 1) gx = 1;
   if (gx > n_tiles) gx = n_tiles;
   dim3 grid((unsigned)gx, nbo, nbk * sb.n);
-#define JN_CW(S_, T_)                                                                                                 \
+#define JN_CW(S_, T_, TH_)                                                                                                 \
   {                                                                                                                   \
-    const size_t smem = ((size_t)128 * CW_LDG + (size_t)(C3_TH * S_ + 2) * (C3_TW * S_ + 2) * CW_LDX) * sizeof(float); \
+    const size_t smem = ((size_t)TH_ * C3_TW * CW_LDG + (size_t)(TH_ * S_ + 2) * (C3_TW * S_ + 2) * CW_LDX) * sizeof(float); \
     if (smem > 64 * 1024) {                                                                                           \
       static bool raised = false;                                                                                     \
       if (!raised) {                                                                                                  \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bwd_weight_kernel<S_, T_>),                    \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bwd_weight_kernel<S_, T_, TH_>),                    \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                             \
         raised = true;                                                                                                \
       }                                                                                                               \
     }                                                                                                                 \
-    hipLaunchKernelGGL((conv3_bwd_weight_kernel<S_, T_>), grid, dim3(256), smem, s, gz, g_ld, (const T_*)x, x_ld, it, \
+    hipLaunchKernelGGL((conv3_bwd_weight_kernel<S_, T_, TH_>), grid, dim3(256), smem, s, gz, g_ld, (const T_*)x, x_ld, it, \
                        gw, H, W, OH, OW, Co, Ci, tiles_x, tiles_y, n_tiles, sb);                                      \
   }
-  if (x_dtype == JN_BF16) { if (stride == 1) JN_CW(1, bf16_t) else JN_CW(2, bf16_t) }
-  else { if (stride == 1) JN_CW(1, float) else JN_CW(2, float) }
+  if (x_dtype == JN_BF16) { if (stride == 1) JN_CW(1, bf16_t, 4) else JN_CW(2, bf16_t, 4) }
+  else { if (stride == 1) JN_CW(1, float, 4) else JN_CW(2, float, 4) }
 #undef JN_CW
   return 0;
 }
