@@ -332,20 +332,33 @@ __global__ __launch_bounds__(256) void pw_bwd_weight_wide_kernel(const float* __
     i_sc = *reinterpret_cast<const f32x4*>(it.sc + k0 + 4 * q); i_sh = *reinterpret_cast<const f32x4*>(it.sh + k0 + 4 * q);
     i_fl = *reinterpret_cast<const f32x4*>(it.fl + k0 + 4 * q);
   }
+  // the next 64-row block is fetched into registers while the MFMAs of the current one run (two workgroups per CU
+  // alone left the matrix pipe 50 % busy)
+  f32x4 pg[8], px[8];
+  auto fetch = [&](long long rb) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = (tid >> 5) + 8 * j;
+      pg[j] = f32x4{0.f, 0.f, 0.f, 0.f}; px[j] = pg[j];
+      if (rb + r < r1) {
+        if (n0 + 4 * q < N) pg[j] = *reinterpret_cast<const f32x4*>(gz + (rb + r) * g_ld + n0 + 4 * q);
+        if (k0 + 4 * q < K) px[j] = ld4(x + (rb + r) * x_ld + k0 + 4 * q);
+      }
+    }
+  };
+  if (r0 < r1) fetch(r0);
   for (long long rb = r0; rb < r1; rb += 64) {
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int r = (tid >> 5) + 8 * j;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f}, u = {0.f, 0.f, 0.f, 0.f};
-      if (rb + r < r1) {
-        if (n0 + 4 * q < N) v = *reinterpret_cast<const f32x4*>(gz + (rb + r) * g_ld + n0 + 4 * q);
-        if (k0 + 4 * q < K) u = tf4_(ld4(x + (rb + r) * x_ld + k0 + 4 * q), i_sc, i_sh, i_fl);
-      }
-      *reinterpret_cast<f32x4*>(Gs + r * LD + 4 * q) = v;
+      f32x4 u = {0.f, 0.f, 0.f, 0.f};
+      if (rb + r < r1 && k0 + 4 * q < K) u = tf4_(px[j], i_sc, i_sh, i_fl);
+      *reinterpret_cast<f32x4*>(Gs + r * LD + 4 * q) = pg[j];
       *reinterpret_cast<f32x4*>(As + r * LD + 4 * q) = u;
     }
     __syncthreads();
+    if (rb + 64 < r1) fetch(rb + 64);
 #pragma unroll 4
     for (int st = 0; st < 16; ++st) {
       const int row = 4 * st + g;
