@@ -440,29 +440,54 @@ __global__ __launch_bounds__(256) void conv3_bwd_weight_kernel(const float* __re
   f32x4 acc[9][2];
 #pragma unroll
   for (int t = 0; t < 9; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  // the next tile's values are fetched into registers while the MFMAs of the current one run
+  constexpr int NGF = (NPIX * (CW_BO / 4) + 255) / 256, NXF = (IH * IW * (CW_BK / 4) + 255) / 256;
+  f32x4 pg[NGF], px[NXF];
+  auto fetch = [&](int tile) {
     const int tr = tile % (tiles_x * tiles_y), n_img = tile / (tiles_x * tiles_y);
     const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * C3_TW;
-    __syncthreads();
-    for (int i = tid; i < NPIX * (CW_BO / 4); i += 256) {
-      const int pix = i / (CW_BO / 4), q = i % (CW_BO / 4);
+#pragma unroll
+    for (int j = 0; j < NGF; ++j) {
+      const int i = tid + 256 * j, pix = i / (CW_BO / 4), q = i % (CW_BO / 4);
       const int oy = oy0 + pix / C3_TW, ox = ox0 + pix % C3_TW;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (oy < OH && ox < OW && o0 + 4 * q < Co)
-        v = *reinterpret_cast<const f32x4*>(gz + (((long long)n_img * OH + oy) * OW + ox) * g_ld + o0 + 4 * q);
-      *reinterpret_cast<f32x4*>(Gs + pix * CW_LDG + 4 * q) = v;
+      pg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < NPIX * (CW_BO / 4) && oy < OH && ox < OW && o0 + 4 * q < Co)
+        pg[j] = *reinterpret_cast<const f32x4*>(gz + (((long long)n_img * OH + oy) * OW + ox) * g_ld + o0 + 4 * q);
     }
-    for (int i = tid; i < IH * IW * (CW_BK / 4); i += 256) {
-      const int pix = i / (CW_BK / 4), q = i % (CW_BK / 4);
+#pragma unroll
+    for (int j = 0; j < NXF; ++j) {
+      const int i = tid + 256 * j, pix = i / (CW_BK / 4), q = i % (CW_BK / 4);
       const int iy = oy0 * S - 1 + pix / IW, ix = ox0 * S - 1 + pix % IW;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      const int kk = k0 + 4 * q;
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W && kk < Ci)
-        v = tf4_d(ld4(x + (((long long)n_img * H + iy) * W + ix) * x_ld + kk), *reinterpret_cast<const f32x4*>(it.sc + kk),
-                  *reinterpret_cast<const f32x4*>(it.sh + kk), *reinterpret_cast<const f32x4*>(it.fl + kk));
-      *reinterpret_cast<f32x4*>(Xs + pix * CW_LDX + 4 * q) = v;
+      px[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < IH * IW * (CW_BK / 4) && iy >= 0 && iy < H && ix >= 0 && ix < W && k0 + 4 * q < Ci)
+        px[j] = ld4(x + (((long long)n_img * H + iy) * W + ix) * x_ld + k0 + 4 * q);
+    }
+  };
+  if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int tr = tile % (tiles_x * tiles_y);
+    const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * C3_TW;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NGF; ++j) {
+      const int i = tid + 256 * j, pix = i / (CW_BO / 4), q = i % (CW_BO / 4);
+      if (i < NPIX * (CW_BO / 4)) *reinterpret_cast<f32x4*>(Gs + pix * CW_LDG + 4 * q) = pg[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NXF; ++j) {
+      const int i = tid + 256 * j, pix = i / (CW_BK / 4), q = i % (CW_BK / 4);
+      if (i < IH * IW * (CW_BK / 4)) {
+        const int iy = oy0 * S - 1 + pix / IW, ix = ox0 * S - 1 + pix % IW;
+        const int kk = k0 + 4 * q;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};                     // padding stays 0 (not silu(shift))
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W && kk < Ci)
+          v = tf4_d(px[j], *reinterpret_cast<const f32x4*>(it.sc + kk), *reinterpret_cast<const f32x4*>(it.sh + kk),
+                    *reinterpret_cast<const f32x4*>(it.fl + kk));
+        *reinterpret_cast<f32x4*>(Xs + pix * CW_LDX + 4 * q) = v;
+      }
     }
     __syncthreads();
+    if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
 #pragma unroll 2
     for (int st = 0; st < NPIX / 4; ++st) {              // 4 pixels per k-step: lane group g takes pixel 4 st + g
       const int pix = 4 * st + g, ty = pix / C3_TW, tx = pix % C3_TW;
