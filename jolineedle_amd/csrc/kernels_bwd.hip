@@ -9,6 +9,8 @@
 // g buffers mirror the activation buffers (NHWC fp32, same views).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "jn_kernels.h"
 #include "jn_reduce.h"
 #include "jn_types.h"
@@ -1214,6 +1216,8 @@ __global__ __launch_bounds__(256) void spp_bwd_kernel(const AT* __restrict__ cat
   const int HW = H * W;
   float* A = sp;                 // activation of slice 0
   float* G = sp + HW * cb;       // gradient accumulator for slice 0
+  float* Rv = G + HW * cb;       // row pass: max of the horizontal window ...
+  int* Rx = reinterpret_cast<int*>(Rv + HW * cb);   // ... and the column it sits in (leftmost on ties)
   const int n = blockIdx.y, c0 = blockIdx.x * cb;
   const AT* base = cat + (long long)n * HW * ld + c0;
   float* gbase = gcat + (long long)n * HW * ld + c0;
@@ -1225,35 +1229,63 @@ __global__ __launch_bounds__(256) void spp_bwd_kernel(const AT* __restrict__ cat
     G[e] = 0.0f;
   }
   __syncthreads();
-  for (int e = tid; e < HW * cb; e += 256) {
-    const int p = e / cb, c = e % cb, y = p / W, x = p - y * W;
-    for (int stage = 1; stage <= 3; ++stage) {
-      const int rad = 2 * stage;
+  // The gradient of each pooled value goes to the FIRST maximum of its window in row-major order (MaxPool2d).  The 2-D
+  // arg-max is separable with that tie rule: leftmost maximum of every window row, then the topmost row holding the
+  // overall maximum — 2 (2 r + 1) reads per element and radius instead of (2 r + 1)^2 (275 reads for r = 2, 4, 6).
+  // compile-time radii: the window loads are independent and issued back to back (a run-time trip count serialised
+  // one LDS round trip per tap)
+  auto route = [&](auto rad_c, int stage) {
+    constexpr int RAD = decltype(rad_c)::value;
+    for (int e = tid; e < HW * cb; e += 256) {
+      const int p = e / cb, c = e % cb, y = p / W, x = p - y * W;
+      float v[2 * RAD + 1];
+#pragma unroll
+      for (int d = -RAD; d <= RAD; ++d) {
+        const int xx = x + d;
+        v[d + RAD] = (xx >= 0 && xx < W) ? A[(y * W + xx) * cb + c] : -INFINITY;
+      }
       float best = -INFINITY;
-      int bi = p;
-      for (int yy = max(0, y - rad); yy <= min(H - 1, y + rad); ++yy)
-        for (int xx = max(0, x - rad); xx <= min(W - 1, x + rad); ++xx) {
-          const float v = A[(yy * W + xx) * cb + c];
-          if (v > best) { best = v; bi = yy * W + xx; }
-        }
+      int bx = x;
+#pragma unroll
+      for (int d = -RAD; d <= RAD; ++d)
+        if (v[d + RAD] > best) { best = v[d + RAD]; bx = x + d; }
+      Rv[e] = best; Rx[e] = bx;
+    }
+    __syncthreads();
+    for (int e = tid; e < HW * cb; e += 256) {
+      const int p = e / cb, c = e % cb, y = p / W, x = p - y * W;
+      float v[2 * RAD + 1];
+#pragma unroll
+      for (int d = -RAD; d <= RAD; ++d) {
+        const int yy = y + d;
+        v[d + RAD] = (yy >= 0 && yy < H) ? Rv[(yy * W + x) * cb + c] : -INFINITY;
+      }
+      float best = -INFINITY;
+      int by = y;
+#pragma unroll
+      for (int d = -RAD; d <= RAD; ++d)
+        if (v[d + RAD] > best) { best = v[d + RAD]; by = y + d; }
+      const int bi = by * W + Rx[(by * W + x) * cb + c];
       atomicAdd(&G[bi * cb + c], gbase[(long long)p * ld + stage * h + c]);
     }
-  }
-  __syncthreads();
+    __syncthreads();
+  };
+  route(std::integral_constant<int, 2>{}, 1);
+  route(std::integral_constant<int, 4>{}, 2);
+  route(std::integral_constant<int, 6>{}, 3);
   for (int e = tid; e < HW * cb; e += 256) gbase[(long long)(e / cb) * ld + (e % cb)] += G[e];
 }
 
 int launch_spp_bwd(const void* cat, int dtype, float* gcat, int ld, int h, int H, int W, int N, ChanTab it,
                    hipStream_t s, const SlotBatch& sb) {
   int cb = 32;
-  while (cb > 4 && (size_t)H * W * cb * 2 * sizeof(float) > 48 * 1024) cb >>= 1;
+  while (cb > 4 && (size_t)H * W * cb * 4 * sizeof(float) > 60 * 1024) cb >>= 1;
   dim3 grid(h / cb, N, sb.n);
+  const size_t smem = (size_t)H * W * cb * 4 * sizeof(float);
   if (dtype == JN_BF16)
-    hipLaunchKernelGGL(spp_bwd_kernel<bf16_t>, grid, dim3(256), (size_t)H * W * cb * 2 * sizeof(float), s, (const bf16_t*)cat,
-                       gcat, ld, h, H, W, cb, it, sb);
+    hipLaunchKernelGGL(spp_bwd_kernel<bf16_t>, grid, dim3(256), smem, s, (const bf16_t*)cat, gcat, ld, h, H, W, cb, it, sb);
   else
-    hipLaunchKernelGGL(spp_bwd_kernel<float>, grid, dim3(256), (size_t)H * W * cb * 2 * sizeof(float), s, (const float*)cat,
-                       gcat, ld, h, H, W, cb, it, sb);
+    hipLaunchKernelGGL(spp_bwd_kernel<float>, grid, dim3(256), smem, s, (const float*)cat, gcat, ld, h, H, W, cb, it, sb);
   return 0;
 }
 
