@@ -402,6 +402,9 @@ int jn_destroy(jn_ctx* ctx) {
   for (void* p : ctx->owned) (void)hipFree(p);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
   for (auto& e : ctx->conv_ev) (void)hipEventDestroy(e);
+  if (ctx->aux_fork) (void)hipEventDestroy(ctx->aux_fork);
+  if (ctx->aux_join) (void)hipEventDestroy(ctx->aux_join);
+  if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
   delete ctx;
   return JN_OK;
 }
@@ -877,6 +880,15 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
   const ChanTab ident{ctx->ident, ctx->ident + 2048, ctx->ident + 4096};
   std::map<int, std::pair<int, View>> g_alias;      // conv output buffer -> (coff, gradient view to read instead)
   std::set<int> red_done;                           // conv slots whose BN-backward sums a consumer's kernel already formed
+  // Wide 1x1 layers (unfused path): the weight-gradient GEMM only feeds the optimiser, so it runs on a second stream
+  // beside the data-gradient GEMM of the same layer and whatever follows; joined before this function returns.
+  static const bool no_aux = std::getenv("JN_NO_AUX_STREAM") != nullptr;
+  bool aux_used = false;
+  if (!no_aux && !ctx->aux_stream) {
+    JN_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    JN_HIP(hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
+    JN_HIP(hipEventCreateWithFlags(&ctx->aux_join, hipEventDisableTiming));
+  }
   static const bool no_red_fusion = std::getenv("JN_NO_FUSED_REDUCE") != nullptr;
   const int n_ops_b = (with_head || net.n_backbone_ops < 0) ? (int)net.ops.size() : net.n_backbone_ops;
   for (int obi = n_ops_b - 1; obi >= 0; --obi) {
@@ -966,9 +978,16 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
         a.cin = cw.cout; a.cout = cw.cin; a.stride = 1; a.act = ACT_NONE;
         a.accumulate = op.acc_in ? 1 : 0; a.w_transposed = 1;
         a.n_slots = nsl; a.in_slot_stride = sb.grad; a.out_slot_stride = sb.grad; a.tab_slot_stride = 0;
+        hipStream_t ws = s;
+        if (!no_aux && cw.cout >= 128 && cw.cin >= 128) {      // the wide kernel: plain atomics on gw, no shared scratch
+          JN_HIP(hipEventRecord(ctx->aux_fork, s));           // g_z is complete
+          JN_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
+          ws = ctx->aux_stream;
+          aux_used = true;
+        }
         launch_pw(a, s);
         launch_pw_bwd_weight(gp_out, gld_out, ptr(op.in), net.act_dtype, ld(op.in), tab(op.in), gw, ctx->wpart, M, cw.cout,
-                             cw.cin, s, sb);
+                             cw.cin, ws, sb);
       } else if (op.kind == OP_DW) {
         launch_dw_bwd_data(gp_out, gld_out, cw.w_dev, gptr(op.in), ld(op.in), cw.cout, op.in.H, op.in.W, op.out.H,
                            op.out.W, N, op.stride, op.acc_in ? 1 : 0, s, sb);
@@ -982,6 +1001,13 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
         // dense 3x3 (non-depthwise patch encoders, e.g. yolox-s): stride 1 = the forward kernel over g_z with
         // mirrored taps and the transposed weight; stride 2 = one MFMA tile loop per input-pixel parity class
         int rc3 = 0;
+        hipStream_t ws3 = s;
+        if (!no_aux) {                     // the 9-tap weight gradient (plain atomics on gw) beside the data gradient
+          JN_HIP(hipEventRecord(ctx->aux_fork, s));
+          JN_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->aux_fork, 0));
+          ws3 = ctx->aux_stream;
+          aux_used = true;
+        }
         if (op.stride == 1) {
           ConvArgs a{};
           a.in = gp_out; a.in_ld = gld_out; a.in_dtype = JN_F32; a.itab = ident; a.w = cw.w_dev; a.bias = nullptr;
@@ -997,7 +1023,7 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
         }
         JN_CHECK(rc3 == 0, JN_ESTATE, "backward of dense 3x3 conv %s: unsupported shape", op.name.c_str());
         launch_conv3_bwd_weight(gp_out, gld_out, ptr(op.in), net.act_dtype, ld(op.in), tab(op.in), gw, op.in.H, op.in.W,
-                                op.out.H, op.out.W, cw.cout, cw.cin, N, op.stride, s, sb);
+                                op.out.H, op.out.W, cw.cout, cw.cin, N, op.stride, ws3, sb);
       } else {
         set_error("backward of op %s is not implemented", op.name.c_str());
         return JN_ESTATE;
@@ -1023,6 +1049,10 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
         break;
       default: break;
     }
+  }
+  if (aux_used) {
+    JN_HIP(hipEventRecord(ctx->aux_join, ctx->aux_stream));
+    JN_HIP(hipStreamWaitEvent(s, ctx->aux_join, 0));
   }
   JN_HIP(hipGetLastError());
   return JN_OK;

@@ -192,6 +192,8 @@ struct jn_ctx {
   int32_t* found = nullptr;       // [B] visited bbox tiles
   float* ident = nullptr;         // identity table (scale 1, shift 0, flag 0) for gradient operands
   float* wpart = nullptr;         // [JN_NREP][JN_WPART_MAX] replicated weight-gradient partials (kept zero)
+  // second stream of the conv-stack backward: the wide 1x1 weight-gradient GEMMs run beside the data-gradient GEMMs
+  hipStream_t aux_stream = nullptr; hipEvent_t aux_fork = nullptr, aux_join = nullptr;
   float* det_raw = nullptr;       // [B][A][6] decoded head output
   float* det_logits = nullptr;    // [B][A][6] raw predictor outputs of the training pass
   float* det_dlogits = nullptr;   // [B][A][6] d loss / d raw (before the 1 / num_fg factor)
