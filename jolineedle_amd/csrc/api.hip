@@ -823,6 +823,16 @@ static int ensure_train_state(jn_ctx* ctx, int g_slots = 1) {
 
 static inline float* grad_of(const jn_ctx* ctx, const float* param) { return ctx->grads + (param - ctx->params); }
 
+// The context's second stream (non-blocking) with its fork / join events: independent kernel families run beside the
+// caller's stream — weight-gradient GEMMs in the backward, the detector beside the next glimpse step in a rollout.
+static int ensure_aux_stream(jn_ctx* ctx) {
+  if (ctx->aux_stream) return JN_OK;
+  JN_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+  JN_HIP(hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
+  JN_HIP(hipEventCreateWithFlags(&ctx->aux_join, hipEventDisableTiming));
+  return JN_OK;
+}
+
 static inline bool views_overlap(const View& a, const View& b) {
   return a.buf >= 0 && a.buf == b.buf && a.coff < b.coff + b.C && b.coff < a.coff + a.C;
 }
@@ -884,11 +894,7 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
   // beside the data-gradient GEMM of the same layer and whatever follows; joined before this function returns.
   static const bool no_aux = std::getenv("JN_NO_AUX_STREAM") != nullptr;
   bool aux_used = false;
-  if (!no_aux && !ctx->aux_stream) {
-    JN_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-    JN_HIP(hipEventCreateWithFlags(&ctx->aux_fork, hipEventDisableTiming));
-    JN_HIP(hipEventCreateWithFlags(&ctx->aux_join, hipEventDisableTiming));
-  }
+  if (!no_aux) { int ra = ensure_aux_stream(ctx); if (ra) return ra; }
   static const bool no_red_fusion = std::getenv("JN_NO_FUSED_REDUCE") != nullptr;
   const int n_ops_b = (with_head || net.n_backbone_ops < 0) ? (int)net.ops.size() : net.n_backbone_ops;
   for (int obi = n_ops_b - 1; obi >= 0; --obi) {
@@ -1534,12 +1540,34 @@ static int rollout_impl(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev
       if ((rc2 = dev_alloc(ctx, &ctx->det_tmp_counts, (size_t)c.max_batch))) return rc2;
     }
   }
+  // The detector pass of a glimpse only feeds the detection outputs, so it runs on the context's second stream beside
+  // the next glimpse step of the decision path: the positions it reads are snapshotted per step (the agents move on),
+  // forked after the step that produced them, joined before the rollout returns.
+  static const bool no_aux_det = std::getenv("JN_NO_AUX_STREAM") != nullptr;
+  hipStream_t ds_stream = s;
+  if (do_detection && !no_aux_det) {
+    int ra = ensure_aux_stream(ctx);
+    if (ra) return ra;
+    if (!ctx->det_pos || ctx->det_pos_cap < (size_t)(T + 1) * B * 2) {
+      if ((ra = dev_alloc(ctx, &ctx->det_pos, (size_t)(T + 1) * B * 2))) return ra;
+      ctx->det_pos_cap = (size_t)(T + 1) * B * 2;
+    }
+    ds_stream = ctx->aux_stream;
+  }
   auto detect_step = [&](int col, const int* flag) -> int {
-    StemSrc ds{e.images, e.positions, 3LL * e.H * e.W, (long long)e.H * e.W, e.W};
-    int r = detect_impl(ctx, ds, B, ctx->det_tmp_boxes, ctx->det_tmp_counts, nullptr, flag, B, s);
+    const int64_t* pos = e.positions;
+    if (ds_stream != s) {
+      int64_t* snap = ctx->det_pos + (size_t)col * B * 2;
+      JN_HIP(hipMemcpyAsync(snap, e.positions, (size_t)B * 2 * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+      JN_HIP(hipEventRecord(ctx->aux_fork, s));
+      JN_HIP(hipStreamWaitEvent(ds_stream, ctx->aux_fork, 0));
+      pos = snap;
+    }
+    StemSrc ds{e.images, pos, 3LL * e.H * e.W, (long long)e.H * e.W, e.W};
+    int r = detect_impl(ctx, ds, B, ctx->det_tmp_boxes, ctx->det_tmp_counts, nullptr, flag, B, ds_stream);
     if (r) return r;
     launch_det_scatter(ctx->det_tmp_boxes, ctx->det_tmp_counts, out->det_boxes_dev, out->det_counts_dev, B, T + 1, col, Kd,
-                       flag, B, s);
+                       flag, B, ds_stream);
     return JN_OK;
   };
   if (do_detection) { int r0 = detect_step(0, nullptr); if (r0) return r0; }
@@ -1605,6 +1633,10 @@ static int rollout_impl(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev
       launch_gather(e.images, e.positions, out->patches_dev + (long long)(t + 1) * 3 * P * P, patch_stride, B, 3, e.H, e.W,
                     P, flag, B, s);
     if (do_detection && (rc = detect_step(t + 1, flag))) return rc;     // src/reinforce.py:162-167
+  }
+  if (ds_stream != s) {
+    JN_HIP(hipEventRecord(ctx->aux_join, ds_stream));
+    JN_HIP(hipStreamWaitEvent(s, ctx->aux_join, 0));
   }
   launch_rollout_epilogue(r, ctx->n_done, B, T, stop_early ? 1 : 0, s);
   ctx->last_stop_early = stop_early != 0;
