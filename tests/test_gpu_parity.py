@@ -1108,3 +1108,34 @@ def test_infer_images_pads_and_maps_boxes_to_the_full_image():
     want[:, [1, 3]] += y0 * P
     got = out["boxes"][0][: len(want)].cpu()                 # same set; boxes of equal score (zero padding) may swap places
     assert ((got[:, None, :] - want[None, :, :]).abs().max(dim=2).values.min(dim=0).values < 2e-3).all()
+
+
+# --------------------------------------------------------------------------------------
+# edge shapes of the rollout: single agent, single step, 1 x 1 grid, immediate STOP, longest sequence
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,G,Tn,actions", [
+    (1, (1, 1), 1, [[3]]),                      # one agent on a one-patch image, one step (every move is clipped)
+    (1, (2, 3), 4, [[8, 0, 0, 0]]),             # STOP first: sticky, the episode ends after one step
+    (2, (1, 4), 6, [[1, 1, 1, 1, 1, 1], [0, 0, 1, 8, 1, 1]]),   # a one-row image: walks into the border, late STOP
+    (3, (3, 3), 20, None),                      # a long sequence (block_size 20) with random moves
+])
+def test_rollout_edge_shapes_vs_oracle(B, G, Tn, actions):
+    from oracle import env_ref, rollout_ref
+    P = 64
+    product, oracle = make_pair(11, patch_size=P, block_size=Tn, with_detector=False, image_processor=None, max_batch=B)
+    images, bboxes, start = synth_batch(B, G[0], G[1], P, seed=B * 10 + Tn)
+    forced = (torch.tensor(actions) if actions is not None
+              else torch.randint(0, 8, (B, Tn), generator=torch.Generator().manual_seed(3)))
+    with torch.no_grad():
+        ref = rollout_ref.rollout(oracle, env_ref.EnvRef(images, bboxes, P, Tn, 1, True), forced_actions=forced,
+                                  start_positions=start, stop_early=True)
+    env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True)
+    ro = ja.ReinforceTrainer(_cfg(T=Tn), product).rollout(env, forced_actions=forced, start_positions=start)
+    S = ref["rewards"].shape[1]
+    assert ro["rewards"].shape[1] == S and 1 <= S <= Tn
+    for k in ("masks", "logit_masks", "positions", "actions"):
+        assert torch.equal(ro[k].cpu(), ref[k]), k
+    assert torch.equal(ro["rewards"].cpu(), ref["rewards"])
+    for k in ("returns", "logprobs", "entropies", "logits"):
+        assert (ro[k].cpu() - ref[k]).abs().max() < TOL_LOGIT, k
+    assert torch.equal(ro["patches"].cpu(), ref["patches"])
