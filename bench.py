@@ -344,6 +344,8 @@ def main():
         if args.detect:
             out["metric"] += " + yolox-s detection on every visited patch"
             out["config"]["phase"] += "; do_detection=True (yolox-s PAFPN + head + NMS per glimpse)"
+            out["roofline"]["note"] = ("the encoder's conv stack is timed while the detector pass of the previous glimpse runs "
+                                       "beside it on the engine's second stream: not comparable with the headline figure")
         if args.config == "c5":
             tflops = 2.0 * S_640_GMAC_PER_PATCH * (P / 640.0) ** 2 * B / (conv_ms_per_launch * 1e-3) / 1e12
             out["metric"] = f"glimpse-patches/sec ({P}px, seq-len {T}) REINFORCE step, gpt-mini + yolox-s encoder"
