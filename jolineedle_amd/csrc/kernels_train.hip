@@ -13,6 +13,9 @@
 namespace jnr {
 
 constexpr int TB = 256;
+// gpt_backward_kernel: one workgroup per agent, so the only parallelism inside an agent is the workgroup's width; its
+// phases are short loops over <= L x 4C elements with a K-long inner product each (1024 threads: 3.4 -> see DESIGN)
+constexpr int GB = 1024;
 
 // ---- REINFORCE loss (src/reinforce.py:217-265) and d loss / d logits --------------------------
 // loss = -sum(logp*adv*m)/sum(m) + w * (-sum(H*m)/sum(m)),  adv = (returns - mean)/(std + 1e-8)
@@ -140,7 +143,7 @@ int launch_ce_loss(const float* logits, const int64_t* target, const uint8_t* ma
 // ---- helpers on per-agent global scratch (all threads of the block, barrier at the end) --------
 __device__ __forceinline__ void lin_fwd(float* out, const float* in, const float* __restrict__ wt,
                                         const float* __restrict__ b, int L, int K, int N) {
-  for (int e = threadIdx.x; e < L * N; e += TB) {
+  for (int e = threadIdx.x; e < L * N; e += GB) {
     const int i = e / N, n = e - i * N;
     float acc = b ? b[n] : 0.0f;
     const float* ip = in + i * K;
@@ -152,7 +155,7 @@ __device__ __forceinline__ void lin_fwd(float* out, const float* in, const float
 // din[i][k] = sum_n dout[i][n] * wt[k][n]
 __device__ __forceinline__ void lin_bwd_data(float* din, const float* dout, const float* __restrict__ wt, int L, int K,
                                              int N, bool accumulate) {
-  for (int e = threadIdx.x; e < L * K; e += TB) {
+  for (int e = threadIdx.x; e < L * K; e += GB) {
     const int i = e / K, k = e - i * K;
     float acc = 0.0f;
     const float* dp = dout + i * N;
@@ -165,14 +168,14 @@ __device__ __forceinline__ void lin_bwd_data(float* din, const float* dout, cons
 // gwt[k][n] += sum_i in[i][k] * dout[i][n];  gb[n] += sum_i dout[i][n]
 __device__ __forceinline__ void lin_bwd_weight(float* __restrict__ gwt, float* __restrict__ gb, const float* in,
                                                const float* dout, int L, int K, int N, int i0) {
-  for (int e = threadIdx.x; e < K * N; e += TB) {
+  for (int e = threadIdx.x; e < K * N; e += GB) {
     const int k = e / N, n = e - k * N;
     float acc = 0.0f;
     for (int i = i0; i < L; ++i) acc = fmaf(in[i * K + k], dout[i * N + n], acc);
     atomicAdd(&gwt[e], acc);
   }
   if (gb)
-    for (int n = threadIdx.x; n < N; n += TB) {
+    for (int n = threadIdx.x; n < N; n += GB) {
       float acc = 0.0f;
       for (int i = i0; i < L; ++i) acc += dout[i * N + n];
       atomicAdd(&gb[n], acc);
@@ -181,7 +184,7 @@ __device__ __forceinline__ void lin_bwd_weight(float* __restrict__ gwt, float* _
 }
 __device__ __forceinline__ void ln_fwd(float* out, const float* in, const float* __restrict__ w,
                                        const float* __restrict__ b, float* mu, float* rs, int L, int C) {
-  for (int i = threadIdx.x; i < L; i += TB) {
+  for (int i = threadIdx.x; i < L; i += GB) {
     const float* x = in + i * C;
     float m = 0.0f;
     for (int c = 0; c < C; ++c) m += x[c];
@@ -192,7 +195,7 @@ __device__ __forceinline__ void ln_fwd(float* out, const float* in, const float*
     rs[i] = 1.0f / sqrtf(v / C + 1e-5f);
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < L * C; e += TB) {
+  for (int e = threadIdx.x; e < L * C; e += GB) {
     const int i = e / C, c = e - i * C;
     out[e] = (in[e] - mu[i]) * rs[i] * w[c] + b[c];
   }
@@ -202,13 +205,13 @@ __device__ __forceinline__ void ln_fwd(float* out, const float* in, const float*
 __device__ __forceinline__ void ln_bwd(float* din, const float* dout, const float* in, const float* __restrict__ w,
                                        float* __restrict__ gw, float* __restrict__ gb, const float* mu, const float* rs,
                                        int L, int C, bool accumulate, int i0) {
-  for (int c = threadIdx.x; c < C; c += TB) {
+  for (int c = threadIdx.x; c < C; c += GB) {
     float a = 0.0f, b = 0.0f;
     for (int i = i0; i < L; ++i) { const float d = dout[i * C + c]; a += d * (in[i * C + c] - mu[i]) * rs[i]; b += d; }
     atomicAdd(&gw[c], a);
     atomicAdd(&gb[c], b);
   }
-  for (int i = threadIdx.x; i < L; i += TB) {
+  for (int i = threadIdx.x; i < L; i += GB) {
     const float* x = in + i * C;
     const float* d = dout + i * C;
     float m1 = 0.0f, m2 = 0.0f;
@@ -233,7 +236,7 @@ __device__ __forceinline__ float gelu_d(float x) {
 }
 
 // ---- GPT backward, one workgroup per agent ------------------------------------------------------
-__global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
+__global__ __launch_bounds__(GB) void gpt_backward_kernel(GptBwdArgs a) {
   __shared__ float mu[64], rs[64];
   __shared__ int s_S;
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
   float* PARTS = HF + L * C;       // [4C]
 
   // ---------------- forward recompute ----------------
-  for (int e = tid; e < L * C; e += TB) X[e] = a.final_emb[((long long)b * (a.T + 1)) * C + e];
+  for (int e = tid; e < L * C; e += GB) X[e] = a.final_emb[((long long)b * (a.T + 1)) * C + e];
   __syncthreads();
   for (int l = 0; l < nL; ++l) {
     const GptLayerPtrs W = a.layers[l];
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
     float* Fp = H2 + L * C;         // [L][4C] pre-activation
     ln_fwd(H1, x, W.ln1_w, W.ln1_b, mu, rs, L, C);
     lin_fwd(QKV, H1, W.qkv_wt, W.qkv_b, L, C, 3 * C);
-    for (int e = tid; e < nh * L * L; e += TB) {
+    for (int e = tid; e < nh * L * L; e += GB) {
       const int h = e / (L * L), i = (e / L) % L, j = e % L;
       float d = -INFINITY;
       if (j <= i) {
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
       ATT[e] = d;
     }
     __syncthreads();
-    for (int e = tid; e < nh * L; e += TB) {
+    for (int e = tid; e < nh * L; e += GB) {
       float* row = ATT + e * L;
       const int i = e % L;
       float m = -INFINITY;
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
       for (int j = 0; j < L; ++j) row[j] = j <= i ? row[j] / s : 0.0f;
     }
     __syncthreads();
-    for (int e = tid; e < L * C; e += TB) {
+    for (int e = tid; e < L * C; e += GB) {
       const int i = e / C, c = e - i * C, h = c / hs;
       float acc = 0.0f;
       for (int j = 0; j <= i; ++j) acc = fmaf(ATT[(h * L + i) * L + j], QKV[j * 3 * C + 2 * C + c], acc);
@@ -307,16 +310,16 @@ __global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
     }
     __syncthreads();
     lin_fwd(XM, Y, W.proj_wt, W.proj_b, L, C, C);
-    for (int e = tid; e < L * C; e += TB) XM[e] += x[e];
+    for (int e = tid; e < L * C; e += GB) XM[e] += x[e];
     __syncthreads();
     ln_fwd(H2, XM, W.ln2_w, W.ln2_b, mu, rs, L, C);
     lin_fwd(Fp, H2, W.fc_wt, W.fc_b, L, C, 4 * C);
     float* xo = X + (l + 1) * L * C;
     // mlp out: needs gelu(F); use dF as a temporary activation buffer
-    for (int e = tid; e < L * 4 * C; e += TB) dF[e] = gelu_f(Fp[e]);
+    for (int e = tid; e < L * 4 * C; e += GB) dF[e] = gelu_f(Fp[e]);
     __syncthreads();
     lin_fwd(xo, dF, W.fc2_wt, W.fc2_b, L, 4 * C, C);
-    for (int e = tid; e < L * C; e += TB) xo[e] += XM[e];
+    for (int e = tid; e < L * C; e += GB) xo[e] += XM[e];
     __syncthreads();
   }
   float* xl = X + nL * L * C;
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
 
   // ---------------- head + ln_f backward ----------------
   // dHF[i][c] = sum_a dlogits[b][i-1][a] * head_wt[c][a]   (token 0 has no logits)
-  for (int e = tid; e < L * C; e += TB) {
+  for (int e = tid; e < L * C; e += GB) {
     const int i = e / C, c = e - i * C;
     float acc = 0.0f;
     if (i >= 1) {
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
     }
     dH[e] = acc;
   }
-  for (int e = tid; e < C * a.nA; e += TB) {
+  for (int e = tid; e < C * a.nA; e += GB) {
     const int c = e / a.nA, q = e - c * a.nA;
     float acc = 0.0f;
     for (int i = 1; i < L; ++i) acc = fmaf(HF[i * C + c], a.dlogits[((long long)b * a.T + (i - 1)) * a.nA + q], acc);
@@ -357,23 +360,23 @@ __global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
     // mlp: xo = XM + fc2(gelu(fc(H2)))
     lin_bwd_data(dF, dX, W.fc2_wt, L, 4 * C, C, false);                     // dA
     // weight grad of fc2 needs gelu(F): recompute into dQKV/dY-sized temp is too small -> use dP? no: reuse Y? keep simple:
-    for (int e = tid; e < 4 * C * C; e += TB) {
+    for (int e = tid; e < 4 * C * C; e += GB) {
       const int k = e / C, c = e - k * C;
       float acc = 0.0f;
       for (int i = 0; i < L; ++i) acc = fmaf(gelu_f(Fp[i * 4 * C + k]), dX[i * C + c], acc);
       atomicAdd(&G.fc2_wt[e], acc);
     }
-    for (int c = tid; c < C; c += TB) {
+    for (int c = tid; c < C; c += GB) {
       float acc = 0.0f;
       for (int i = 0; i < L; ++i) acc += dX[i * C + c];
       atomicAdd(&G.fc2_b[c], acc);
     }
-    for (int e = tid; e < L * 4 * C; e += TB) dF[e] *= gelu_d(Fp[e]);
+    for (int e = tid; e < L * 4 * C; e += GB) dF[e] *= gelu_d(Fp[e]);
     __syncthreads();
     lin_bwd_data(dH, dF, W.fc_wt, L, C, 4 * C, false);
     lin_bwd_weight(G.fc_wt, G.fc_b, H2, dF, L, C, 4 * C, 0);
     // ln2 statistics of XM
-    for (int i = tid; i < L; i += TB) {
+    for (int i = tid; i < L; i += GB) {
       const float* xx = XM + i * C;
       float m = 0.0f;
       for (int c = 0; c < C; ++c) m += xx[c];
@@ -383,14 +386,14 @@ __global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
       mu[i] = m; rs[i] = 1.0f / sqrtf(v / C + 1e-5f);
     }
     __syncthreads();
-    for (int e = tid; e < L * C; e += TB) dXM[e] = dX[e];
+    for (int e = tid; e < L * C; e += GB) dXM[e] = dX[e];
     __syncthreads();
     ln_bwd(dXM, dH, XM, W.ln2_w, G.ln2_w, G.ln2_b, mu, rs, L, C, true, 0);
     // attention output projection: XM = x + proj(Y)
     lin_bwd_data(dY, dXM, W.proj_wt, L, C, C, false);
     lin_bwd_weight(G.proj_wt, G.proj_b, Y, dXM, L, C, C, 0);
     // dP[h][i][j] = sum_d dY[i][h,d] * v[j][h,d]
-    for (int e = tid; e < nh * L * L; e += TB) {
+    for (int e = tid; e < nh * L * L; e += GB) {
       const int h = e / (L * L), i = (e / L) % L, j = e % L;
       float acc = 0.0f;
       if (j <= i)
@@ -399,14 +402,14 @@ __global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
     }
     __syncthreads();
     // dV[j][c] = sum_{i>=j} P[h][i][j] * dY[i][c]
-    for (int e = tid; e < L * C; e += TB) {
+    for (int e = tid; e < L * C; e += GB) {
       const int j = e / C, c = e - j * C, h = c / hs;
       float acc = 0.0f;
       for (int i = j; i < L; ++i) acc = fmaf(ATT[(h * L + i) * L + j], dY[i * C + c], acc);
       dQKV[j * 3 * C + 2 * C + c] = acc;
     }
     // softmax backward in place: dS = P * (dP - sum_j P*dP)
-    for (int e = tid; e < nh * L; e += TB) {
+    for (int e = tid; e < nh * L; e += GB) {
       float* dp = dP + e * L;
       const float* pr = ATT + e * L;
       const int i = e % L;
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
       for (int j = 0; j < L; ++j) dp[j] = j <= i ? pr[j] * (dp[j] - dot) * scale : 0.0f;
     }
     __syncthreads();
-    for (int e = tid; e < L * C; e += TB) {
+    for (int e = tid; e < L * C; e += GB) {
       const int i = e / C, c = e - i * C, h = c / hs;
       float dq = 0.0f, dk = 0.0f;
       for (int j = 0; j <= i; ++j) dq = fmaf(dP[(h * L + i) * L + j], QKV[j * 3 * C + C + c], dq);
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
     __syncthreads();
     lin_bwd_data(dH, dQKV, W.qkv_wt, L, C, 3 * C, false);
     lin_bwd_weight(G.qkv_wt, G.qkv_b, H1, dQKV, L, C, 3 * C, 0);
-    for (int i = tid; i < L; i += TB) {
+    for (int i = tid; i < L; i += GB) {
       const float* xx = x + i * C;
       float m = 0.0f;
       for (int c = 0; c < C; ++c) m += xx[c];
@@ -436,13 +439,13 @@ __global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
       mu[i] = m; rs[i] = 1.0f / sqrtf(v / C + 1e-5f);
     }
     __syncthreads();
-    for (int e = tid; e < L * C; e += TB) dX[e] = dXM[e];
+    for (int e = tid; e < L * C; e += GB) dX[e] = dXM[e];
     __syncthreads();
     ln_bwd(dX, dH, x, W.ln1_w, G.ln1_w, G.ln1_b, mu, rs, L, C, true, 0);
   }
 
   // ---------------- token embeddings ----------------
-  for (int c = tid; c < C; c += TB) atomicAdd(&a.g_embed_class[c], dX[c]);          // class token id 0
+  for (int c = tid; c < C; c += GB) atomicAdd(&a.g_embed_class[c], dX[c]);          // class token id 0
   for (int i = 1; i < L; ++i) {
     const int t = i - 1;
     // rollout: token i carries the action taken BEFORE its patch (BOS = 0); teacher-forced full sequence:
@@ -452,20 +455,20 @@ __global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
     const int row = (int)a.positions[((long long)b * a.pos_tokens + t) * 2];
     const int col = (int)a.positions[((long long)b * a.pos_tokens + t) * 2 + 1];
     int p = 0;
-    for (int c = tid; c < C; c += TB) PARTS[c] = a.wte[act * C + c];
+    for (int c = tid; c < C; c += GB) PARTS[c] = a.wte[act * C + c];
     ++p;
     const int p1 = a.pos1d_by_token ? t : 0;            // recurrent tokens: 1-D position 0 (gpt.py:431-449)
-    for (int c = tid; c < C; c += TB) PARTS[p * C + c] = a.dec_pos_enc ? a.pos1d[p1 * C + c] : a.wpe[p1 * C + c];
+    for (int c = tid; c < C; c += GB) PARTS[p * C + c] = a.dec_pos_enc ? a.pos1d[p1 * C + c] : a.wpe[p1 * C + c];
     const int p_pos = p; ++p;
     int p_patch = -1, p_pos2 = -1;
     if (!a.no_patch_emb) {
       p_patch = p;
-      for (int c = tid; c < C; c += TB) PARTS[p * C + c] = a.tok_emb[((long long)b * a.T + t) * C + c];
+      for (int c = tid; c < C; c += GB) PARTS[p * C + c] = a.tok_emb[((long long)b * a.T + t) * C + c];
       ++p;
     }
     if (a.use_pos_emb) {
       p_pos2 = p;
-      for (int c = tid; c < C; c += TB)
+      for (int c = tid; c < C; c += GB)
         PARTS[p * C + c] = (c < a.pe2_ch) ? a.pe2[col * a.pe2_ch + c] : a.pe2[row * a.pe2_ch + (c - a.pe2_ch)];
       ++p;
     }
@@ -473,32 +476,32 @@ __global__ __launch_bounds__(TB) void gpt_backward_kernel(GptBwdArgs a) {
     const float* dx = dX + i * C;
     float* dparts = dF;   // [p*C] scratch (dF holds >= 4C floats and is free now)
     if (a.concat_emb) {
-      for (int k = tid; k < p * C; k += TB) {
+      for (int k = tid; k < p * C; k += GB) {
         float acc = 0.0f;
         for (int c = 0; c < C; ++c) acc = fmaf(dx[c], a.proj_wt[(long long)k * C + c], acc);
         dparts[k] = acc;
       }
-      for (int e = tid; e < p * C * C; e += TB) atomicAdd(&a.g_proj_wt[e], PARTS[e / C] * dx[e % C]);
-      for (int c = tid; c < C; c += TB) atomicAdd(&a.g_proj_b[c], dx[c]);
+      for (int e = tid; e < p * C * C; e += GB) atomicAdd(&a.g_proj_wt[e], PARTS[e / C] * dx[e % C]);
+      for (int c = tid; c < C; c += GB) atomicAdd(&a.g_proj_b[c], dx[c]);
     } else {
-      for (int k = tid; k < p * C; k += TB) dparts[k] = dx[k % C] / p;
+      for (int k = tid; k < p * C; k += GB) dparts[k] = dx[k % C] / p;
     }
     __syncthreads();
-    for (int c = tid; c < C; c += TB) atomicAdd(&a.g_wte[act * C + c], dparts[c]);
+    for (int c = tid; c < C; c += GB) atomicAdd(&a.g_wte[act * C + c], dparts[c]);
     if (!a.dec_pos_enc && a.g_wpe)
-      for (int c = tid; c < C; c += TB) atomicAdd(&a.g_wpe[p1 * C + c], dparts[p_pos * C + c]);
+      for (int c = tid; c < C; c += GB) atomicAdd(&a.g_wpe[p1 * C + c], dparts[p_pos * C + c]);
     if (p_patch >= 0)
-      for (int c = tid; c < C; c += TB) a.d_tok_emb[((long long)b * a.dte_stride_b + t * a.dte_stride_t) * C + c] = dparts[p_patch * C + c];
+      for (int c = tid; c < C; c += GB) a.d_tok_emb[((long long)b * a.dte_stride_b + t * a.dte_stride_t) * C + c] = dparts[p_patch * C + c];
     (void)p_pos2;
     __syncthreads();
   }
   // steps that were never executed get a zero patch-embedding gradient
   for (int t = S; t < a.T; ++t)
-    for (int c = tid; c < C; c += TB) a.d_tok_emb[((long long)b * a.dte_stride_b + t * a.dte_stride_t) * C + c] = 0.0f;
+    for (int c = tid; c < C; c += GB) a.d_tok_emb[((long long)b * a.dte_stride_b + t * a.dte_stride_t) * C + c] = 0.0f;
 }
 
 int launch_gpt_backward(const GptBwdArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(gpt_backward_kernel, dim3(a.B), dim3(TB), 0, s, a);
+  hipLaunchKernelGGL(gpt_backward_kernel, dim3(a.B), dim3(GB), 0, s, a);
   return 0;
 }
 
