@@ -734,6 +734,139 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
   }
 }
 
+// Narrow 1x1 layers (K = 16 / 32 / 64 input channels, fp32, train or eval forward): the whole K fits one LDS chunk, so
+// the generic kernel above has nothing to pipeline inside a workgroup — its 3000-12000 workgroups all load, then all
+// compute, then all store.  This variant is persistent over pixel tiles: the weight tile is staged ONCE, the next
+// tile's pixels are fetched into registers while the MFMAs and stores of the current one run, the per-thread table
+// quad sits in registers and the BatchNorm sums stay in registers across tiles (one set of fp64 atomics per workgroup).
+template <int CT, int KC>
+__global__ __launch_bounds__(256) void pw_narrow_kernel(
+    const float* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, float* __restrict__ out, int out_ld,
+    long long M, int Nc, double* __restrict__ stats, long long rep_stride, const int* __restrict__ skip_flag,
+    int skip_when) {
+  if (skip_flag && *skip_flag >= skip_when) return;
+  constexpr int LD = KC + 4, BM = 64, CTW = CT / 2, Q4 = KC / 4, NX = BM * Q4 / 256, NW = (16 * CT * Q4 + 255) / 256;
+  static_assert(CT % 2 == 0 && NX >= 1, "pw_narrow tile mapping");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* Xs = reinterpret_cast<float*>(smem_raw);     // [BM][LD]
+  float* Ws = Xs + BM * LD;                            // [16*CT][LD]
+  float* red = Ws + 16 * CT * LD;                      // [2][16*CT][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int lm = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.y * (16 * CT);
+#pragma unroll
+  for (int j = 0; j < NW; ++j) {
+    const int i = tid + 256 * j, r = i / Q4, q = i - r * Q4;
+    if (i < 16 * CT * Q4) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n0 + r < Nc) v = *reinterpret_cast<const f32x4*>(w + (long long)(n0 + r) * KC + 4 * q);
+      *reinterpret_cast<f32x4*>(Ws + r * LD + 4 * q) = v;
+    }
+  }
+  const int q = tid % Q4, r0 = tid / Q4;               // this thread's channel quad and first row of a tile (fixed)
+  const f32x4 t_sc = *reinterpret_cast<const f32x4*>(it.sc + 4 * q), t_sh = *reinterpret_cast<const f32x4*>(it.sh + 4 * q),
+              t_fl = *reinterpret_cast<const f32x4*>(it.fl + 4 * q);
+  const long long n_tiles = (M + BM - 1) / BM;
+  f32x4 xr[NX];
+  auto fetch = [&](long long m0) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const long long m = m0 + r0 + (256 / Q4) * j;
+      xr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (m < M) xr[j] = *reinterpret_cast<const f32x4*>(x + m * x_ld + 4 * q);
+    }
+  };
+  f32x4 s1[CTW], s2[CTW];
+#pragma unroll
+  for (int c = 0; c < CTW; ++c) { s1[c] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[c] = s1[c]; }
+  long long tile = blockIdx.x;
+  if (tile < n_tiles) fetch(tile * BM);
+  for (; tile < n_tiles; tile += gridDim.x) {
+    const long long m0 = tile * BM;
+    __syncthreads();                     // the previous tile's fragment reads are done (and Ws is in place)
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int r = r0 + (256 / Q4) * j;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m0 + r < M) v = tf4(xr[j], t_sc, t_sh, t_fl);
+      *reinterpret_cast<f32x4*>(Xs + r * LD + 4 * q) = v;
+    }
+    __syncthreads();
+    if (tile + gridDim.x < n_tiles) fetch((tile + gridDim.x) * BM);
+    f32x4 acc[2][CTW];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int c = 0; c < CTW; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xrow0 = Xs + (wm * 32 + lm) * LD + 4 * g;
+    const float* xrow1 = xrow0 + 16 * LD;
+    const float* wrow = Ws + (wn * CTW * 16 + lm) * LD + 4 * g;
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 16) {
+      const f32x4 xb0 = *reinterpret_cast<const f32x4*>(xrow0 + kk);
+      const f32x4 xb1 = *reinterpret_cast<const f32x4*>(xrow1 + kk);
+      f32x4 wa[CTW];
+#pragma unroll
+      for (int c = 0; c < CTW; ++c) wa[c] = *reinterpret_cast<const f32x4*>(wrow + c * 16 * LD + kk);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) {
+          acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][j], xb0[j], acc[0][c], 0, 0, 0);
+          acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][j], xb1[j], acc[1][c], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const long long m = m0 + wm * 32 + p * 16 + lm;
+      if (m >= M) continue;
+#pragma unroll
+      for (int c = 0; c < CTW; ++c) {
+        const int n = n0 + (wn * CTW + c) * 16 + 4 * g;
+        if (n >= Nc) continue;
+        *reinterpret_cast<f32x4*>(out + m * out_ld + n) = acc[p][c];
+        s1[c] += acc[p][c];
+        s2[c] += acc[p][c] * acc[p][c];
+      }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    wave_stats_to_lds<CTW>(s1, s2, red + wm * 32 * CT + 2 * (wn * CTW * 16), lane, Nc - n0 - wn * CTW * 16);
+    __syncthreads();
+    if (tid < 32 * CT && n0 + (tid >> 1) < Nc)
+      atomicAdd(&stats[(blockIdx.x % JN_NREP) * rep_stride + 2 * n0 + tid], (double)(red[tid] + red[32 * CT + tid]));
+  }
+}
+
+template <int CT, int KC>
+static void launch_pw_narrow_t(const ConvArgs& a, long long M, hipStream_t s) {
+  const long long n_tiles = (M + 63) / 64;
+  static const int cap = std::getenv("JN_PWN_GRID") ? std::atoi(std::getenv("JN_PWN_GRID")) : 1536;
+  const unsigned gx = (unsigned)std::min<long long>(n_tiles, cap);
+  dim3 grid(gx, (unsigned)((a.cout + 16 * CT - 1) / (16 * CT)));
+  const size_t smem = (size_t)(64 + 16 * CT) * (KC + 4) * sizeof(float) + 2 * 32 * CT * sizeof(float);
+  hipLaunchKernelGGL((pw_narrow_kernel<CT, KC>), grid, dim3(256), smem, s, (const float*)a.in, a.in_ld, a.itab, a.w,
+                     (float*)a.out, a.out_ld, M, a.cout, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when);
+}
+
+// true when the persistent narrow kernel took the launch
+static bool launch_pw_narrow(const ConvArgs& a, hipStream_t s) {
+  static const bool off = std::getenv("JN_NO_PW_NARROW") != nullptr;
+  if (off || a.bf16_mfma || a.in_dtype != JN_F32 || a.out_dtype != JN_F32 || a.w_transposed || a.accumulate || a.bias ||
+      a.act != ACT_NONE || a.n_slots > 1)
+    return false;
+  const long long M = (long long)a.N * a.H * a.W;
+  const int nt = (a.cout + 15) / 16;
+  if (M < 65536) return false;                 // small maps have too few tiles to walk
+#define JN_PWN(CT_, KC_) if (nt == CT_ && a.cin == KC_) { launch_pw_narrow_t<CT_, KC_>(a, M, s); return true; }
+  JN_PWN(2, 16) JN_PWN(2, 32) JN_PWN(4, 32) JN_PWN(4, 64) JN_PWN(8, 64)
+#undef JN_PWN
+  return false;
+}
+
 template <int CT, int KC, bool WT, int WM, typename IT, typename OT, bool BF>
 static void launch_pw_kc(const ConvArgs& a, long long M, hipStream_t s) {
   constexpr int BM = 32 * WM;
@@ -791,6 +924,7 @@ static void launch_pw_types(const ConvArgs& a, hipStream_t s) {
 // Type combinations in use: fp32 mode (f32, f32, fp32 MFMA); bf16 mode: activations (bf16 -> bf16),
 // embed_fpn.0 (bf16 -> f32) and gradients (f32 -> f32), all on the bf16 MFMA.
 int launch_pw(const ConvArgs& a, hipStream_t s) {
+  if (launch_pw_narrow(a, s)) return 0;
   if (!a.bf16_mfma) {
     if (a.in_dtype == JN_F32 && a.out_dtype == JN_F32) { launch_pw_types<float, float, false>(a, s); return 0; }
     return -1;
