@@ -860,7 +860,10 @@ static bool launch_pw_narrow(const ConvArgs& a, hipStream_t s) {
     return false;
   const long long M = (long long)a.N * a.H * a.W;
   const int nt = (a.cout + 15) / 16;
-  if (M < 65536) return false;                 // small maps have too few tiles to walk
+  // small maps have too few tiles to walk (JN_PWN_MIN_M: test hook, read per launch so that a test can force the kernel
+  // onto small maps)
+  const char* mm = std::getenv("JN_PWN_MIN_M");
+  if (M < (mm ? std::atoll(mm) : 65536)) return false;
 #define JN_PWN(CT_, KC_) if (nt == CT_ && a.cin == KC_) { launch_pw_narrow_t<CT_, KC_>(a, M, s); return true; }
   JN_PWN(2, 16) JN_PWN(2, 32) JN_PWN(4, 32) JN_PWN(4, 64) JN_PWN(8, 64)
 #undef JN_PWN

@@ -1139,3 +1139,36 @@ def test_rollout_edge_shapes_vs_oracle(B, G, Tn, actions):
     for k in ("returns", "logprobs", "entropies", "logits"):
         assert (ro[k].cpu() - ref[k]).abs().max() < TOL_LOGIT, k
     assert torch.equal(ro["patches"].cpu(), ref["patches"])
+
+
+# --------------------------------------------------------------------------------------
+# the persistent narrow 1x1 kernel only takes maps of >= 65536 pixels by itself (B = 64 at 448 px): force it onto the
+# small parity shapes (ragged last tile, fewer tiles than workgroups) and at its natural size on a 6-patch batch
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("P,N,train", [(64, 3, False), (96, 5, True), (160, 3, True), (448, 6, False)])
+def test_narrow_pointwise_kernel_forced_on_small_maps(P, N, train, monkeypatch):
+    if P != 448:
+        monkeypatch.setenv("JN_PWN_MIN_M", "1")
+    product, oracle = make_pair(3, patch_size=P, block_size=6, with_detector=False, image_processor=None, max_batch=N)
+    x = torch.rand((N, 3, P, P), generator=torch.Generator().manual_seed(P + N))
+    oracle.gpt_backbone.train(train)
+    with torch.no_grad():
+        ref = oracle.gpt_backbone(x)
+    got = product.backbone_features(x, train=train)
+    for i in range(3):
+        err = (got[i].cpu() - ref[i]).abs().max().item()
+        assert err < (1e-3 if train else TOL_MAP), (i, err)
+    if train:                                                   # gradients through the same maps (saved statistics)
+        oracle.zero_grad()
+        outs = oracle.gpt_backbone(x)
+        gs = [torch.randn(o.shape, generator=torch.Generator().manual_seed(7 + i)) for i, o in enumerate(outs)]
+        sum((o * g).sum() for o, g in zip(outs, gs)).backward()
+        product.engine_zero_grad()
+        product.backbone_features(x, train=True)
+        product.backbone_backward(x, gs)
+        grads = product.engine_grads("gpt_backbone.")
+        for name, p in oracle.gpt_backbone.named_parameters():
+            if p.grad is None:
+                continue
+            scale = p.grad.abs().max().item() + 1e-6
+            assert (grads["gpt_backbone." + name] - p.grad).abs().max().item() / scale < 5e-3, name
