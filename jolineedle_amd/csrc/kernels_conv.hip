@@ -903,7 +903,9 @@ static void launch_pw_ct(const ConvArgs& a, long long M, hipStream_t s) {
   const long long Mtot = M * (a.n_slots > 1 ? a.n_slots : 1);
   const bool tiny_m = Mtot <= 16384;                  // 14x14 maps at 64 patches
   if (a.w_transposed) {              // data gradients (step-batched, large): 128-pixel workgroups unless the map is small
-    if (can_split && Mtot <= 65536) launch_pw_cfg<CT, true, can_split ? 2 : 4, IT, OT, BF>(a, M, s);
+    // (JN_PW_WT_SMALL_M: test hook, read per launch — 0 forces the large-map variant onto the small parity shapes)
+    const char* sm_env = std::getenv("JN_PW_WT_SMALL_M");
+    if (can_split && Mtot <= (sm_env ? std::atoll(sm_env) : 65536)) launch_pw_cfg<CT, true, can_split ? 2 : 4, IT, OT, BF>(a, M, s);
     else launch_pw_cfg<CT, true, 4, IT, OT, BF>(a, M, s);
   } else {
     // 14x14 maps with K <= 128: 32-pixel workgroups (the four waves split the channel tiles) quadruple the

@@ -1172,3 +1172,25 @@ def test_narrow_pointwise_kernel_forced_on_small_maps(P, N, train, monkeypatch):
                 continue
             scale = p.grad.abs().max().item() + 1e-6
             assert (grads["gpt_backbone." + name] - p.grad).abs().max().item() / scale < 5e-3, name
+
+
+def test_wide_data_gradient_large_map_variant_forced_on_small_shapes(monkeypatch):
+    """The data gradient of the wide 1x1 layers switches to 128-pixel workgroups above 65536 pixels (B = 64 x 20 steps):
+    force that variant onto a parity-sized backward."""
+    monkeypatch.setenv("JN_PW_WT_SMALL_M", "0")
+    P, N = 96, 3
+    product, oracle = make_pair(3, patch_size=P, block_size=6, with_detector=False, image_processor=None)
+    g = torch.Generator().manual_seed(23)
+    x = torch.rand((N, 3, P, P), generator=g)
+    net = oracle.gpt_backbone.train()
+    outs = net(x)
+    R = [torch.randn(o.shape, generator=g) for o in outs]
+    net.zero_grad()
+    sum((o * r).sum() for o, r in zip(outs, R)).backward()
+    product.engine_zero_grad()
+    product.backbone_features(x, train=True)
+    product.backbone_backward(x, R)
+    got = product.engine_grads("gpt_backbone.")
+    for name, p in net.named_parameters():
+        scale = p.grad.abs().max().item() + 1e-6
+        assert (got["gpt_backbone." + name] - p.grad).abs().max().item() / scale < 2e-3, name
