@@ -40,9 +40,9 @@ S_640_GMAC_PER_PATCH = 8.113e9
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
 # HBM traffic of ONE forward conv-stack pass at B=64, 448 px from the PMC counters (separate --pmc FETCH_SIZE and
 # --pmc WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM, tools/pmc_traffic.py):
-# profiles/r01_f_pmc_conv_stack_traffic_{train,eval}.txt — the eval pass fuses DWConv / shortcut adds and moves
+# profiles/r01_g_pmc_conv_stack_traffic_{train,eval}.txt — the eval pass fuses DWConv / shortcut adds and moves
 # fewer bytes than the layer-wise algorithmic figure.
-PMC_TRAFFIC_BYTES_B64_448 = {"train": 5.683e9, "rollout": 4.401e9}
+PMC_TRAFFIC_BYTES_B64_448 = {"train": 5.651e9, "rollout": 4.399e9}
 
 
 def synth_inputs(B, G, P, seed, device):

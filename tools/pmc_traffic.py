@@ -13,7 +13,7 @@ import csv
 import re
 import sys
 
-CONV = ("stem_mfma_kernel", "dw3x3", "dwpw_eval_kernel", "pw_mfma_kernel", "addact_kernel", "spp_kernel", "upsample_kernel",
+CONV = ("stem_mfma_kernel", "dw3x3", "dwpw_eval_kernel", "pw_mfma_kernel", "pw_narrow_kernel", "addact_kernel", "spp_kernel", "upsample_kernel",
         "conv3_mfma")
 
 
