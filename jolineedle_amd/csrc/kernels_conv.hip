@@ -597,7 +597,15 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
   LT* Xs = reinterpret_cast<LT*>(smem_raw);     // [BM][PW_LD]
   LT* Ws = Xs + BM * PW_LD;                      // [16*CT][PW_LD]
   float* red = reinterpret_cast<float*>(Ws + 16 * CT * PW_LD);   // [WM][16*CT][2]: one slot set per pixel-wave
+  // (scale, shift, flag) of the K input channels in LDS: the staging below used to read them from global memory per
+  // staged quad, a dependent L2 round trip inside every chunk's critical path
+  float* Tb = red + WM * 32 * CT;                                 // [3][K4]
+  const int K4 = (K + 3) & ~3;
   const int tid = threadIdx.x;
+  for (int c = tid; c < K4; c += 256) {
+    const bool in = c < K;
+    Tb[c] = in ? it.sc[c] : 1.0f; Tb[K4 + c] = in ? it.sh[c] : 0.0f; Tb[2 * K4 + c] = in ? it.fl[c] : 0.0f;
+  }
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM;
   const int lm = lane & 15, g = lane >> 4;
@@ -644,8 +652,8 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const int kk = k0 + 4 * q;
         if (m0 + r < M && kk < K)
-          v = tf4(xr[j], *reinterpret_cast<const f32x4*>(it.sc + kk), *reinterpret_cast<const f32x4*>(it.sh + kk),
-                  *reinterpret_cast<const f32x4*>(it.fl + kk));
+          v = tf4(xr[j], *reinterpret_cast<const f32x4*>(Tb + kk), *reinterpret_cast<const f32x4*>(Tb + K4 + kk),
+                  *reinterpret_cast<const f32x4*>(Tb + 2 * K4 + kk));
         st4(Xs + r * PW_LD + 4 * q, v);
       }
     }
@@ -657,6 +665,7 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
   };
 
   fetch(0);
+  __syncthreads();                        // Tb is in place
   for (int k0 = 0; k0 < K; k0 += PW_KC) {
     const int kc = chunk_q4(k0) << 2;     // multiple of KSTEP
     if (k0) __syncthreads();
@@ -874,7 +883,8 @@ template <int CT, int KC, bool WT, int WM, typename IT, typename OT, bool BF>
 static void launch_pw_kc(const ConvArgs& a, long long M, hipStream_t s) {
   constexpr int BM = 32 * WM;
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.cout + 16 * CT - 1) / (16 * CT)), a.n_slots > 1 ? a.n_slots : 1);
-  const size_t smem = (size_t)(BM + 16 * CT) * (KC + (BF ? 8 : 4)) * (BF ? 2 : 4) + WM * 32 * CT * sizeof(float);
+  const size_t smem = (size_t)(BM + 16 * CT) * (KC + (BF ? 8 : 4)) * (BF ? 2 : 4) + WM * 32 * CT * sizeof(float) +
+                      (size_t)3 * ((a.cin + 3) & ~3) * sizeof(float);
   hipLaunchKernelGGL((pw_mfma_kernel<CT, KC, WT, WM, IT, OT, BF>), grid, dim3(256), smem, s, (const IT*)a.in, a.in_ld,
                      a.itab, a.w, a.bias, (OT*)a.out, a.out_ld, M, a.cin, a.cout, a.act, a.accumulate, a.stats,
                      a.stats_rep_stride, a.skip_flag, a.skip_when, a.in_slot_stride, a.out_slot_stride, a.tab_slot_stride);
