@@ -63,7 +63,15 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const AT* __restrict__ 
   // K chunks are software-pipelined: chunk i + 1 is fetched into registers while the 288 MFMAs of chunk i run
   constexpr int NXR = (IH * IW * 4 + 255) / 256, NWR = 9 * C3_BN * 4 / 256;
   f32x4 xr[NXR], wr[NWR];
+  // the thread's channel quad (tid & 3) is the same for all its staged pixels: its (scale, shift, flag) entries of the
+  // next chunk travel with the prefetch instead of being read from global memory inside the staging
+  f32x4 t_sc = {1.f, 1.f, 1.f, 1.f}, t_sh = {0.f, 0.f, 0.f, 0.f}, t_fl = {0.f, 0.f, 0.f, 0.f};
   auto fetch = [&](int k0) {
+    if (k0 + 4 * (tid & 3) < K) {
+      t_sc = *reinterpret_cast<const f32x4*>(it.sc + k0 + 4 * (tid & 3));
+      t_sh = *reinterpret_cast<const f32x4*>(it.sh + k0 + 4 * (tid & 3));
+      t_fl = *reinterpret_cast<const f32x4*>(it.fl + k0 + 4 * (tid & 3));
+    }
 #pragma unroll
     for (int j = 0; j < NXR; ++j) {
       const int i = tid + 256 * j, pix = i >> 2, q = i & 3;
@@ -98,8 +106,7 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const AT* __restrict__ 
         const int kk = k0 + 4 * q;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (iy >= 0 && iy < H && ix >= 0 && ix < W && kk < K)
-          v = tf4_d(xr[j], *reinterpret_cast<const f32x4*>(it.sc + kk), *reinterpret_cast<const f32x4*>(it.sh + kk),
-                    *reinterpret_cast<const f32x4*>(it.fl + kk));
+          v = tf4_d(xr[j], t_sc, t_sh, t_fl);
         *reinterpret_cast<f32x4*>(Xs + pix * C3_LD + 4 * q) = v;
       }
     }
