@@ -199,7 +199,16 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(const bf16_t* __restric
   // K chunks are software-pipelined through registers (chunk i + 1 is in flight while the MFMAs of chunk i run)
   bf16x4 xr[NXR];
   bf16x8 wr[NWR];
+  static_assert(256 % (C3B_KC / 4) == 0, "the thread's channel quad is fixed");
+  f32x4 t_sc = {1.f, 1.f, 1.f, 1.f}, t_sh = {0.f, 0.f, 0.f, 0.f}, t_fl = {0.f, 0.f, 0.f, 0.f};   // table quad of the prefetched chunk
   auto fetch = [&](int k0) {
+    {
+      const int kq = k0 + 4 * (tid % (C3B_KC / 4));
+      if (kq < K) {
+        t_sc = *reinterpret_cast<const f32x4*>(it.sc + kq); t_sh = *reinterpret_cast<const f32x4*>(it.sh + kq);
+        t_fl = *reinterpret_cast<const f32x4*>(it.fl + kq);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NXR; ++j) {
       const int i = tid + 256 * j, pix = i / (C3B_KC / 4), q = i % (C3B_KC / 4);
@@ -228,8 +237,7 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(const bf16_t* __restric
         const int kk = k0 + 4 * q;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (iy >= 0 && iy < H && ix >= 0 && ix < W && kk < K)
-          v = tf4_d(__builtin_convertvector(xr[j], f32x4), *reinterpret_cast<const f32x4*>(it.sc + kk),
-                    *reinterpret_cast<const f32x4*>(it.sh + kk), *reinterpret_cast<const f32x4*>(it.fl + kk));
+          v = tf4_d(__builtin_convertvector(xr[j], f32x4), t_sc, t_sh, t_fl);
         st4(Xs + pix * C3B_LD + 4 * q, v);
       }
     }
@@ -450,6 +458,13 @@ __global__ __launch_bounds__(256) void conv3_bwd_weight_kernel(const float* __re
   // the next tile's values are fetched into registers while the MFMAs of the current one run
   constexpr int NGF = (NPIX * (CW_BO / 4) + 255) / 256, NXF = (IH * IW * (CW_BK / 4) + 255) / 256;
   f32x4 pg[NGF], px[NXF];
+  static_assert(256 % (CW_BK / 4) == 0, "the thread's channel quad is fixed");
+  f32x4 w_sc = {1.f, 1.f, 1.f, 1.f}, w_sh = {0.f, 0.f, 0.f, 0.f}, w_fl = {0.f, 0.f, 0.f, 0.f};   // k0 and the quad never change
+  if (k0 + 4 * (tid % (CW_BK / 4)) < Ci) {
+    const int kq = k0 + 4 * (tid % (CW_BK / 4));
+    w_sc = *reinterpret_cast<const f32x4*>(it.sc + kq); w_sh = *reinterpret_cast<const f32x4*>(it.sh + kq);
+    w_fl = *reinterpret_cast<const f32x4*>(it.fl + kq);
+  }
   auto fetch = [&](int tile) {
     const int tr = tile % (tiles_x * tiles_y), n_img = tile / (tiles_x * tiles_y);
     const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * C3_TW;
@@ -488,8 +503,7 @@ __global__ __launch_bounds__(256) void conv3_bwd_weight_kernel(const float* __re
         const int kk = k0 + 4 * q;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};                     // padding stays 0 (not silu(shift))
         if (iy >= 0 && iy < H && ix >= 0 && ix < W && kk < Ci)
-          v = tf4_d(px[j], *reinterpret_cast<const f32x4*>(it.sc + kk), *reinterpret_cast<const f32x4*>(it.sh + kk),
-                    *reinterpret_cast<const f32x4*>(it.fl + kk));
+          v = tf4_d(px[j], w_sc, w_sh, w_fl);
         *reinterpret_cast<f32x4*>(Xs + pix * CW_LDX + 4 * q) = v;
       }
     }
