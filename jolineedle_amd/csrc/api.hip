@@ -663,7 +663,8 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
   if (!train && (rc = refresh_eval_table(ctx, net, s))) return rc;
   double* stats = train ? slot_stats(net, slot) : nullptr;
   float* save = train ? slot_save(net, slot) : nullptr;
-  if (train) JN_HIP(hipMemsetAsync(stats, 0, (size_t)JN_NREP * 2 * net.stat_channels * sizeof(double), s));
+  // (a train-mode rollout zeroes the statistics of all its slots with ONE memset up front)
+  if (train && !ctx->stats_prezeroed) JN_HIP(hipMemsetAsync(stats, 0, (size_t)JN_NREP * 2 * net.stat_channels * sizeof(double), s));
   const long long rep_stride = 2LL * net.stat_channels;
   auto ptr = [&](const View& v) { return view_ptr(net, slot, MB, v); };
   auto tab = [&](const View& v) { return view_tab(net, slot, v); };
@@ -1604,6 +1605,12 @@ static int rollout_impl(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev
       if ((rc = dev_alloc(ctx, &ctx->dlogits, MBt * nA))) return rc;
       if ((rc = dev_alloc(ctx, &ctx->de_ws, MBt * ctx->efpn_h * ctx->efpn_w * C))) return rc;
     }
+  }
+  struct PrezeroGuard { jn_ctx* c; ~PrezeroGuard() { c->stats_prezeroed = false; } } prezero_guard{ctx};
+  if (train && !c.no_patch_emb) {
+    Net& tn = ctx->nets[ctx->enc_net];
+    JN_HIP(hipMemsetAsync(slot_stats(tn, 1), 0, (size_t)T * JN_NREP * 2 * tn.stat_channels * sizeof(double), s));
+    ctx->stats_prezeroed = true;
   }
   for (int t = 0; t < T; ++t) {
     const int* flag = stop_early ? ctx->n_done + t : nullptr;

@@ -194,6 +194,7 @@ struct jn_ctx {
   float* wpart = nullptr;         // [JN_NREP][JN_WPART_MAX] replicated weight-gradient partials (kept zero)
   // second stream of the conv-stack backward: the wide 1x1 weight-gradient GEMMs run beside the data-gradient GEMMs
   hipStream_t aux_stream = nullptr; hipEvent_t aux_fork = nullptr, aux_join = nullptr;
+  bool stats_prezeroed = false;   // run_net(train): the caller already zeroed the BN sums of the slots it walks
   int64_t* det_pos = nullptr; size_t det_pos_cap = 0;   // [T+1][B][2] per-step position snapshots for the detector stream
   float* det_raw = nullptr;       // [B][A][6] decoded head output
   float* det_logits = nullptr;    // [B][A][6] raw predictor outputs of the training pass
