@@ -384,7 +384,16 @@ __global__ __launch_bounds__(256) void dwpw_eval_kernel(
   float* Ti = sm;                                     // [IH*IW][PS]  activated input chunk
   float* Xs = Ti + IH * IW * PS;                      // [BM][LDX]    activated depthwise outputs
   float* Ws = Xs + BM * LDX;                          // [16*CT][LDX] pointwise weight chunk
+  // per-channel constants of ALL chunks, staged once: input table (3 rows), depthwise taps (9), dconv BN table (2) —
+  // read from global memory at the top of every chunk they were a dependent L2 round trip (two per chunk)
+  float* Cst = Ws + 16 * CT * LDX;                    // [14][C]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < C; i += 256) {
+    Cst[i] = it.sc[i]; Cst[C + i] = it.sh[i]; Cst[2 * C + i] = it.fl[i];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) Cst[(3 + t) * C + i] = w_dw[t * C + i];
+    Cst[12 * C + i] = mt.sc[i]; Cst[13 * C + i] = mt.sh[i];
+  }
   const int lm = lane & 15, g = lane >> 4;
   const int wm = wave % WM, wn = wave / WM;
   const int tile = blockIdx.x % (tiles_x * tiles_y), n = blockIdx.x / (tiles_x * tiles_y);
@@ -414,11 +423,12 @@ __global__ __launch_bounds__(256) void dwpw_eval_kernel(
     }
   };
   fetch(0);
+  __syncthreads();                                             // Cst is in place
   const int x = (tid >> 2) & 15, j0 = (tid >> 6) * RPG;       // depthwise phase: column, first row of this thread
   for (int k0 = 0; k0 < C; k0 += CB) {
     const int c = k0 + 4 * q;
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(it.sc + c), sh = *reinterpret_cast<const f32x4*>(it.sh + c),
-                fl = *reinterpret_cast<const f32x4*>(it.fl + c);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(Cst + c), sh = *reinterpret_cast<const f32x4*>(Cst + C + c),
+                fl = *reinterpret_cast<const f32x4*>(Cst + 2 * C + c);
     if (k0) __syncthreads();                          // the previous chunk's MFMAs have read Xs / Ws
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -440,8 +450,8 @@ __global__ __launch_bounds__(256) void dwpw_eval_kernel(
     {   // depthwise 3x3 on the chunk, then the dconv layer's BN + SiLU -> MFMA operand tile
       f32x4 wv[9];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(w_dw + t * C + c);
-      const f32x4 msc = *reinterpret_cast<const f32x4*>(mt.sc + c), msh = *reinterpret_cast<const f32x4*>(mt.sh + c);
+      for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(Cst + (3 + t) * C + c);
+      const f32x4 msc = *reinterpret_cast<const f32x4*>(Cst + 12 * C + c), msh = *reinterpret_cast<const f32x4*>(Cst + 13 * C + c);
       f32x4 d[RPG];
 #pragma unroll
       for (int j = 0; j < RPG; ++j) d[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -509,7 +519,7 @@ template <int S, int WM, int CT, typename AT>
 static void launch_dwpw_t(const DwPwArgs& a, hipStream_t s) {
   constexpr int TH = 2 * WM, IH = S * (TH - 1) + 3, IW = S * 15 + 3, PS = S == 1 ? 16 : 20;
   const int tiles_x = (a.OW + 15) / 16, tiles_y = (a.OH + TH - 1) / TH;
-  const size_t smem = ((size_t)IH * IW * PS + (size_t)TH * 16 * 20 + (size_t)16 * CT * 20) * sizeof(float);
+  const size_t smem = ((size_t)IH * IW * PS + (size_t)TH * 16 * 20 + (size_t)16 * CT * 20 + (size_t)14 * a.C) * sizeof(float);
   hipLaunchKernelGGL((dwpw_eval_kernel<S, WM, CT, AT>), dim3(tiles_x * tiles_y * a.N), dim3(256), smem, s, (const AT*)a.in,
                      a.in_ld, a.itab, a.w_dw, a.mtab, a.w_pw, (AT*)a.out, a.out_ld, a.C, a.cout, a.H, a.W, a.OH, a.OW, tiles_x,
                      tiles_y, a.skip_flag, a.skip_when, (const AT*)a.res, a.res_ld, a.rtab, a.ptab);
