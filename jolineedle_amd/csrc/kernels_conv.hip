@@ -278,12 +278,27 @@ __global__ __launch_bounds__(256) void dw3x3_lds_kernel(
     const f32x4 sc = *reinterpret_cast<const f32x4*>(it.sc + c), sh = *reinterpret_cast<const f32x4*>(it.sh + c),
                 fl = *reinterpret_cast<const f32x4*>(it.fl + c);
     const AT* inb = in + (long long)n * H * W * in_ld + c;
-    for (int i = tid; i < IH * IW * Q; i += 256) {   // 256 % Q == 0: the quad of a thread never changes
-      const int p = i / Q, r = p / IW, cx = p - r * IW;
+    // all loads of the tile are issued back to back into registers, then transformed and stored (a load -> transform ->
+    // store loop with a run-time trip count waited for one global round trip per iteration); 256 % Q == 0: the quad
+    // of a thread never changes
+    constexpr int NT = (IH * IW * Q + 255) / 256;
+    f32x4 rv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int i = tid + 256 * j, p = i / Q, r = p / IW, cx = p - r * IW;
       const int iy = iy0 + r, ix = ix0 + cx;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = tf4(ld4(inb + ((long long)iy * W + ix) * in_ld), sc, sh, fl);
-      *reinterpret_cast<f32x4*>(sm + p * PS + 4 * q) = v;
+      rv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < IH * IW * Q && iy >= 0 && iy < H && ix >= 0 && ix < W) rv[j] = ld4(inb + ((long long)iy * W + ix) * in_ld);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int i = tid + 256 * j, p = i / Q, r = p / IW, cx = p - r * IW;
+      const int iy = iy0 + r, ix = ix0 + cx;
+      if (i < IH * IW * Q) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = tf4(rv[j], sc, sh, fl);
+        *reinterpret_cast<f32x4*>(sm + p * PS + 4 * q) = v;
+      }
     }
   }
   f32x4 wv[9];
