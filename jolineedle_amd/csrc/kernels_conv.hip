@@ -779,14 +779,17 @@ __global__ __launch_bounds__(256) void pw_narrow_kernel(
     long long M, int Nc, double* __restrict__ stats, long long rep_stride, const int* __restrict__ skip_flag,
     int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
-  constexpr int LD = KC + 4, BM = 64, CTW = CT / 2, Q4 = KC / 4, NX = BM * Q4 / 256, NW = (16 * CT * Q4 + 255) / 256;
-  static_assert(CT % 2 == 0 && NX >= 1, "pw_narrow tile mapping");
+  // waves along the pixel dimension: 2 (64-pixel tiles, wave pairs split the channel tiles) or, for a single channel
+  // tile, 4 (128-pixel tiles)
+  constexpr int WMW = (CT % 2 == 0) ? 2 : 4;
+  constexpr int LD = KC + 4, BM = 32 * WMW, CTW = CT * WMW / 4, Q4 = KC / 4, NX = BM * Q4 / 256, NW = (16 * CT * Q4 + 255) / 256;
+  static_assert(CTW >= 1 && NX >= 1, "pw_narrow tile mapping");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* Xs = reinterpret_cast<float*>(smem_raw);     // [BM][LD]
   float* Ws = Xs + BM * LD;                            // [16*CT][LD]
-  float* red = Ws + 16 * CT * LD;                      // [2][16*CT][2]
+  float* red = Ws + 16 * CT * LD;                      // [WMW][16*CT][2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WMW, wn = wave / WMW;
   const int lm = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.y * (16 * CT);
 #pragma unroll
@@ -870,18 +873,23 @@ __global__ __launch_bounds__(256) void pw_narrow_kernel(
     __syncthreads();
     wave_stats_to_lds<CTW>(s1, s2, red + wm * 32 * CT + 2 * (wn * CTW * 16), lane, Nc - n0 - wn * CTW * 16);
     __syncthreads();
-    if (tid < 32 * CT && n0 + (tid >> 1) < Nc)
-      atomicAdd(&stats[(blockIdx.x % JN_NREP) * rep_stride + 2 * n0 + tid], (double)(red[tid] + red[32 * CT + tid]));
+    if (tid < 32 * CT && n0 + (tid >> 1) < Nc) {
+      float v = 0.0f;
+#pragma unroll
+      for (int qq = 0; qq < WMW; ++qq) v += red[qq * 32 * CT + tid];
+      atomicAdd(&stats[(blockIdx.x % JN_NREP) * rep_stride + 2 * n0 + tid], (double)v);
+    }
   }
 }
 
 template <int CT, int KC>
 static void launch_pw_narrow_t(const ConvArgs& a, long long M, hipStream_t s) {
-  const long long n_tiles = (M + 63) / 64;
+  constexpr int BM = (CT % 2 == 0) ? 64 : 128;
+  const long long n_tiles = (M + BM - 1) / BM;
   static const int cap = std::getenv("JN_PWN_GRID") ? std::atoi(std::getenv("JN_PWN_GRID")) : 1536;
   const unsigned gx = (unsigned)std::min<long long>(n_tiles, cap);
   dim3 grid(gx, (unsigned)((a.cout + 16 * CT - 1) / (16 * CT)));
-  const size_t smem = (size_t)(64 + 16 * CT) * (KC + 4) * sizeof(float) + 2 * 32 * CT * sizeof(float);
+  const size_t smem = (size_t)(BM + 16 * CT) * (KC + 4) * sizeof(float) + (BM / 32) * 32 * CT * sizeof(float);
   hipLaunchKernelGGL((pw_narrow_kernel<CT, KC>), grid, dim3(256), smem, s, (const float*)a.in, a.in_ld, a.itab, a.w,
                      (float*)a.out, a.out_ld, M, a.cout, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when);
 }
@@ -899,7 +907,7 @@ static bool launch_pw_narrow(const ConvArgs& a, hipStream_t s) {
   const char* mm = std::getenv("JN_PWN_MIN_M");
   if (M < (mm ? std::atoll(mm) : 65536)) return false;
 #define JN_PWN(CT_, KC_) if (nt == CT_ && a.cin == KC_) { launch_pw_narrow_t<CT_, KC_>(a, M, s); return true; }
-  JN_PWN(2, 16) JN_PWN(2, 32) JN_PWN(4, 32) JN_PWN(4, 64) JN_PWN(8, 64)
+  JN_PWN(1, 16) JN_PWN(2, 16) JN_PWN(2, 32) JN_PWN(4, 32) JN_PWN(4, 64) JN_PWN(8, 64)
 #undef JN_PWN
   return false;
 }
