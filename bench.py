@@ -42,7 +42,21 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
 # --pmc WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM, tools/pmc_traffic.py):
 # profiles/r01_g_pmc_conv_stack_traffic_{train,eval}.txt — the eval pass fuses DWConv / shortcut adds and moves
 # fewer bytes than the layer-wise algorithmic figure.
-PMC_TRAFFIC_BYTES_B64_448 = {"train": 5.651e9, "rollout": 4.399e9}
+PMC_TRAFFIC_BYTES_B64_448 = {"train": 5.651e9, "rollout": 4.399e9}       # round-1 values, used when no newer file exists
+# Backward of the same stack: 2 (in + out) + 2 out = 2 * 17.44 M + 2 * 7.35 M elements per patch.
+NANO_448_BWD_ELEMS_PER_PATCH = 2 * 17.44e6 + 2 * 7.35e6
+
+
+def pmc_traffic(mode):
+    """HBM bytes of one forward conv-stack pass (B=64, 448 px, fp32) from the committed PMC passes of THIS bench command
+    (tools/pmc_traffic.py -> profiles/pmc_traffic_latest.json; rocprofv3 cannot run inside the timed process)."""
+    f = ROOT / "profiles" / "pmc_traffic_latest.json"
+    if f.exists():
+        try:
+            return float(json.loads(f.read_text())[mode])
+        except (KeyError, ValueError):
+            pass
+    return PMC_TRAFFIC_BYTES_B64_448.get(mode)
 
 
 def synth_inputs(B, G, P, seed, device):
@@ -158,17 +172,41 @@ def bench_supervised(args, ja, model_config, dev, rank, world, dist):
             "roofline": None}), flush=True)
 
 
+def _pick_threads(oracle, P):
+    """Thread count for the CPU oracle: a short sweep on the box (fwd + bwd of the patch encoder on 4 patches), because
+    an oversubscribed MKL-DNN conv on a small batch is several times slower than the best count."""
+    import os
+    ncpu = os.cpu_count() or 1
+    cands = sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu} or {ncpu})
+    x = torch.rand(4, 3, P, P)
+    best, best_t = cands[0], float("inf")
+    for c in cands:
+        torch.set_num_threads(c)
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            out = oracle.gpt_backbone(x)[-1]
+            out.sum().backward()
+            ts.append(time.perf_counter() - t0)
+        if min(ts) < best_t:
+            best, best_t = c, min(ts)
+    oracle.zero_grad()
+    torch.set_num_threads(best)
+    return best, ncpu
+
+
 def cpu_baseline(P, T, seed, train):
-    """CPU oracle (pure PyTorch fp32 restatement, oracle/) on the host cores: a bounded sample of
-    the same workload — B=4 agents, T glimpse steps, 4480x4480 images would need 1 GB/agent on the
-    host, so the sample uses a 3x3 grid (patch content is what costs; the grid size does not)."""
+    """CPU oracle (pure PyTorch fp32 restatement, oracle/) on the host cores: a bounded sample of the same workload —
+    B=4 agents x T glimpse steps, 1 warm-up + median of 3, thread count picked by a sweep.
+    4480x4480 images would need 1 GB/agent on the host, so the sample uses a 3x3 grid (the patch content is what costs;
+    the grid size does not)."""
     from oracle import env_ref, rollout_ref
     from oracle.gpt_ref import build_gpt_ref
     torch.manual_seed(seed)
-    B, G = (2, 3) if train else (4, 3)
-    T = min(T, 10) if train else T
+    B, G = 4, 3
     oracle = build_gpt_ref(1, patch_size=P, block_size=T, with_detector=False, image_processor=None)
     oracle.train(train)
+    threads, ncpu = _pick_threads(oracle, P)
     params = [p for n, p in oracle.named_parameters()]
     opt = torch.optim.AdamW(params, lr=1e-4)
     images = torch.rand(B, 3, G * P, G * P)
@@ -176,7 +214,7 @@ def cpu_baseline(P, T, seed, train):
     forced = torch.randint(0, 8, (B, T))
     start = torch.randint(0, G, (B, 2))
     times = []
-    for it in range(2 if train else 3):
+    for it in range(4):                                    # 1 warm-up + 3 timed
         env = env_ref.EnvRef(images, bboxes, P, T, 1, True)
         t0 = time.perf_counter()
         if train:
@@ -190,12 +228,37 @@ def cpu_baseline(P, T, seed, train):
             with torch.no_grad():
                 ro = rollout_ref.rollout(oracle, env, forced_actions=forced, start_positions=start)
                 rollout_ref.reinforce_metrics(ro, 0.01, rollout_ref.ReturnNormaliser())
-        times.append(time.perf_counter() - t0)
-    best = sorted(times)[len(times) // 2] if len(times) >= 3 else min(times)
+        if it:
+            times.append(time.perf_counter() - t0)
+        if it == 0 and time.perf_counter() - t0 > 40.0:   # a slow host: keep the default run within minutes
+            times.append(time.perf_counter() - t0)
+            break
+    med = sorted(times)[len(times) // 2]
     what = "full REINFORCE iteration (fwd + bwd + clip + AdamW)" if train else "forward rollout + loss"
-    return {"value": round(B * T / best, 2), "unit": "glimpse-patches/s", "cores": torch.get_num_threads(),
+    return {"value": round(B * T / med, 2), "unit": "glimpse-patches/s", "cores": threads,
             "kind": "port", "sample": f"B={B} agents x T={T} steps, {P}px patches, 3x3-patch images, forced actions, "
-            f"{what}, best-of-{len(times)} ({best:.2f} s)"}
+            f"{what}, 1 warm-up + median of {len(times)} ({med:.2f} s), {threads} torch threads picked by a sweep on a "
+            f"{ncpu}-CPU host"}
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` without a launcher: this process has not touched the GPU; it starts one child per rank
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the env, as torch.distributed.run would set them), relays their output
+    and exits with the worst child code.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env))
+    code = 0
+    for pr in procs:
+        code = max(code, abs(pr.wait()))
+    sys.exit(code)
 
 
 def main():
@@ -216,9 +279,15 @@ def main():
                          "c5: gpt-mini + yolox-s encoder, 640 px, T=32, B=16 (BASELINE configs[4] topology, secondary)")
     ap.add_argument("--detect", action="store_true",
                     help="rollout mode only (secondary): run the yolox-s detector on every visited patch (do_detection)")
+    ap.add_argument("--sample", action="store_true",
+                    help="free-running trajectories (SURVEY.md §8d): sampled actions, episodes end at STOP / when every box is "
+                         "found, the batch stops when every agent is done; reports the mean executed steps.  Default: forced "
+                         "non-STOP actions, S = T (a fixed amount of work)")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="activation storage / MFMA type; bf16 is the inference (rollout) mode only")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return _self_launch(args)
     arch = {}
     if args.config == "c5":
         arch = dict(model_type="gpt-mini", gpt_backbone="yolox-s")
@@ -235,6 +304,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    n_ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -243,6 +313,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        n_ranks_seen = dist.get_world_size()
 
     import jolineedle_amd as ja
     from tests.helpers import model_config
@@ -266,7 +337,7 @@ def main():
                      learning_rate=1e-4, gradient_accumulation=1)
     trainer = ja.ReinforceTrainer(cfg, model)
     images, bboxes, start = synth_inputs(B, G, P, 12345 + rank, dev)
-    forced = torch.randint(0, 8, (B, T), generator=torch.Generator().manual_seed(777 + rank)).to(dev)
+    forced = None if args.sample else torch.randint(0, 8, (B, T), generator=torch.Generator().manual_seed(777 + rank)).to(dev)
     eng = model.engine()
     eng.lib.jn_set_profiling(eng.handle, 1)
 
@@ -275,10 +346,10 @@ def main():
     def one_step():
         env = ja.NeedleGeneralEnv(images, bboxes, P, T, 1, True, engine=eng)
         if train:
-            m = trainer.train_iteration(env, forced_actions=forced, start_positions=start)
+            m = trainer.train_iteration(env, forced_actions=forced, start_positions=start, sample_actions=True)
             return m["steps"], m["loss"]
         ro = trainer.rollout(env, forced_actions=forced, start_positions=start, keep_patches=False,
-                             do_detection=args.detect)
+                             do_detection=args.detect, sample_actions=True)
         m = trainer.compute_metrics(ro)
         return ro["rewards"].shape[1], m["loss"]
 
@@ -292,13 +363,17 @@ def main():
         one_step()
     sync()
     t0 = time.perf_counter()
-    patches, conv_ms = 0, 0.0
+    patches, conv_ms, bwd_ms, glimpse_steps = 0, 0.0, 0.0, 0
     for _ in range(args.steps):
         S, loss = one_step()
         patches += B * S
+        glimpse_steps += S
         ms = C.c_float()
         eng.lib.jn_last_timing(eng.handle, 1, C.byref(ms))
         conv_ms += ms.value
+        if train:
+            eng.lib.jn_last_timing(eng.handle, 2, C.byref(ms))
+            bwd_ms += ms.value
     sync()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed, float(patches)], device=dev, dtype=torch.float64)
@@ -312,20 +387,21 @@ def main():
         total_patches = float(patches)
 
     if rank == 0:
-        glimpse_steps = args.steps * T
-        conv_ms_per_launch = conv_ms / glimpse_steps          # one PAFPN pass over B patches
+        conv_ms_per_launch = conv_ms / max(glimpse_steps, 1)  # one PAFPN pass over B patches
         esz = 2.0 if args.dtype == "bf16" else 4.0
         algo_bytes = NANO_448_ELEMS_PER_PATCH * (P / 448.0) ** 2 * esz * B
         achieved = algo_bytes / (conv_ms_per_launch * 1e-3) / 1e9
+        actions = (f"sampled actions, early STOP (free-running: {glimpse_steps / args.steps:.2f} of {T} steps executed per "
+                   f"trajectory batch)") if args.sample else "forced non-STOP actions (S=T)"
         out = {
             "metric": "glimpse-patches/sec (448px, seq-len 20) REINFORCE step",
             "value": round(total_patches / elapsed, 1), "unit": "glimpse-patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "n_ranks_seen": n_ranks_seen,
             "config": {"workload": f"configs[2]/[3]: REINFORCE rollout, gpt-nano + yolox-nano encoder, {P}px, "
                                    f"seq-len {T}, --enable-stop, {B} agents/GPU x {world} GPU, "
-                                   f"{G * P}x{G * P} synthetic images, forced non-STOP actions (S=T)",
+                                   f"{G * P}x{G * P} synthetic images, {actions}",
                        "global_batch": B * world, "seq_len": T,
                        "phase": ("full REINFORCE iteration: env build + rollout (train-mode BN) + loss + backward + "
                                  "flat-gradient all-reduce + clip + AdamW") if train else
@@ -337,10 +413,22 @@ def main():
                                                    "), one pass over the batch per glimpse step",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": (PMC_TRAFFIC_BYTES_B64_448[args.mode] if (B, P, args.dtype) == (64, 448, "f32") else None),
+                         "traffic": pmc_traffic(args.mode) if (B, P, args.dtype) == (64, 448, "f32") else None,
                          "ms_per_launch": round(conv_ms_per_launch, 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes)},
         }
+        if train and args.config == "c3":
+            # second entry: the step-batched conv-stack backward (embed_fpn + PAFPN), priced at DESIGN.md §4's algorithmic
+            # backward traffic: per conv layer read g_out and z_out twice (the BN-backward sums must be complete before g_z
+            # exists), read x_in, write g_in = 2 (in + out) + 2 out elements
+            bwd_bytes = NANO_448_BWD_ELEMS_PER_PATCH * (P / 448.0) ** 2 * 4.0 * B
+            bwd_ms_per_pass = bwd_ms / max(glimpse_steps, 1)
+            bwd_ach = bwd_bytes / (bwd_ms_per_pass * 1e-3) / 1e9
+            out["roofline_backward"] = {
+                "bound": "hbm", "kernel": "yolox-nano PAFPN conv-stack backward (step-batched: fused 1x1 / depthwise data + "
+                                          "weight gradients, BN-backward reductions, stem weight gradient), per glimpse step",
+                "achieved": round(bwd_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bwd_ach / HBM_PEAK_GBS, 4),
+                "traffic": None, "ms_per_launch": round(bwd_ms_per_pass, 4), "algorithmic_bytes_per_launch": int(bwd_bytes)}
         if args.detect:
             out["metric"] += " + yolox-s detection on every visited patch"
             out["config"]["phase"] += "; do_detection=True (yolox-s PAFPN + head + NMS per glimpse)"
@@ -350,7 +438,7 @@ def main():
             tflops = 2.0 * S_640_GMAC_PER_PATCH * (P / 640.0) ** 2 * B / (conv_ms_per_launch * 1e-3) / 1e12
             out["metric"] = f"glimpse-patches/sec ({P}px, seq-len {T}) REINFORCE step, gpt-mini + yolox-s encoder"
             out["config"]["workload"] = (f"configs[4] topology on {world} GPU: gpt-mini + yolox-s (dense 3x3) encoder, {P}px, "
-                                         f"seq-len {T}, {B} agents/GPU, forced non-STOP actions")
+                                         f"seq-len {T}, {B} agents/GPU, {actions}")
             out["roofline"] = {"bound": "mfma", "kernel": "yolox-s PAFPN forward conv stack (dense 3x3 + 1x1 on "
                                                           "v_mfma_f32_16x16x4_f32), one pass over the batch per glimpse step",
                                "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -279,7 +279,8 @@ int jn_rollout(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev,
 int jn_rollout_steps(jn_ctx* ctx, int* n_steps, void* stream);
 
 /* Wall-clock helpers for bench.py: HIP-event time of the most recent jn_rollout on its
- * stream, split per kernel family.  what = 0 total ms, 1 backbone conv ms. Synchronises. */
+ * stream, split per kernel family.  what = 0 total ms, 1 backbone conv ms (forward, summed over the glimpse steps),
+ * 2 conv-stack backward ms of the most recent jn_reinforce_step (embed_fpn + PAFPN backward).  Synchronises. */
 int jn_last_timing(jn_ctx* ctx, int what, float* ms);
 /* Enables HIP-event bracketing of the backbone conv section (costs two events/step). */
 int jn_set_profiling(jn_ctx* ctx, int enabled);

@@ -1546,7 +1546,9 @@ static int rollout_impl(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev
   // forked after the step that produced them, joined before the rollout returns.
   static const bool no_aux_det = std::getenv("JN_NO_AUX_STREAM") != nullptr;
   hipStream_t ds_stream = s;
-  if (do_detection && !no_aux_det) {
+  // (only with a separate patch encoder: when the detector's own PAFPN encodes the patches — no gpt_backbone, the
+  // reference's default — both passes use the slot-0 workspace and table of the same net and must stay in stream order)
+  if (do_detection && !no_aux_det && ctx->enc_net != JN_NET_DETECTOR) {
     int ra = ensure_aux_stream(ctx);
     if (ra) return ra;
     if (!ctx->det_pos || ctx->det_pos_cap < (size_t)(T + 1) * B * 2) {
@@ -1586,7 +1588,8 @@ static int rollout_impl(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev
     Net& tn = ctx->nets[ctx->enc_net];
     if ((rc = ensure_slots(ctx, tn, T + 1))) return rc;
     int g_want = tn.g_slots;
-    if (g_want < T) {
+    if (ctx->enc_net == JN_NET_DETECTOR) g_want = std::max(1, g_want);   // detached encoder: no conv-stack backward
+    else if (g_want < T) {
       // gradient buffers for as many glimpse steps as fit in ~80 % of the free HBM (the whole trajectory on a
       // 288 GB MI355X at the headline sizes); the backward then runs in ceil(S / g_slots) step-batched passes
       size_t free_b = 0, total_b = 0;
@@ -1759,8 +1762,11 @@ int jn_reinforce_step(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, 
   const View& f2 = net.fpn[2];
   const ChanTab ident{ctx->ident, ctx->ident + 2048, ctx->ident + 4096};
   const long long g_slot = (long long)net.per_image_floats * MB;
-  for (int t0 = 0; t0 < S; t0 += net.g_slots) {
-    const int g_n = std::min(net.g_slots, S - t0);
+  if (ctx->profiling && ctx->ev[2]) JN_HIP(hipEventRecord(ctx->ev[2], s));     // conv-stack backward section (bench.py)
+  // (a detached encoder needs no gradient slots: all steps in one chunk)
+  const int chunk = ctx->enc_net == JN_NET_DETECTOR ? std::max(S, 1) : net.g_slots;
+  for (int t0 = 0; t0 < S; t0 += chunk) {
+    const int g_n = std::min(chunk, S - t0);
     const long long Mr = (long long)g_n * B;                       // (step, agent) rows of this chunk
     const float* e_c = ctx->efpn_train + (size_t)t0 * B * K;       // [g_n*B][K] embed_fpn.0 activations
     const float* dpe = ctx->d_tok_emb + (size_t)t0 * B * C;        // [g_n*B][C]  d loss / d patch embedding
@@ -1783,9 +1789,13 @@ int jn_reinforce_step(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, 
     a.N = B; a.H = f2.H; a.W = f2.W; a.OH = f2.H; a.OW = f2.W; a.cin = C; a.cout = f2.C; a.stride = 1; a.act = ACT_NONE;
     a.accumulate = 0; a.w_transposed = 1;
     a.n_slots = g_n; a.in_slot_stride = (long long)B * K; a.out_slot_stride = g_slot; a.tab_slot_stride = 0;
-    launch_pw(a, s);
+    // the detector's PAFPN as patch encoder is detached (src/models/gpt.py:376-380 "Do not backpropagate through
+    // yolox"): the policy gradient stops at embed_fpn.0's weight
+    const bool detached = ctx->enc_net == JN_NET_DETECTOR;
+    if (!detached) launch_pw(a, s);
     launch_pw_bwd_weight(ctx->de_ws, C, view_ptr(net, t0 + 1, MB, f2), net.act_dtype, net.bufs[f2.buf].C, view_tab(net, t0 + 1, f2),
                          grad_of(ctx, g.efpn_w), ctx->wpart, (long long)B * HW, C, f2.C, s, sb, (long long)B * K);
+    if (detached) continue;
     for (int i = 0; i < 2; ++i) {
       const View& f = net.fpn[i];
       for (int j = 0; j < g_n; ++j)
@@ -1796,6 +1806,7 @@ int jn_reinforce_step(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, 
     ss.pos_stride = 2 * (T + 1);
     if ((rc = run_net_backward(ctx, ctx->enc_net, B, ss, t0 + 1, s, g_n, 2))) return rc;
   }
+  if (ctx->profiling && ctx->ev[3]) { JN_HIP(hipEventRecord(ctx->ev[3], s)); ctx->bwd_timed = true; }
   (void)P;
   JN_HIP(hipGetLastError());
   return JN_OK;
@@ -1905,9 +1916,11 @@ int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* cur
   ca.out = g_f2; ca.out_ld = net.bufs[f2.buf].C; ca.out_dtype = JN_F32; ca.bf16_mfma = net.act_dtype == JN_BF16;
   ca.N = N; ca.H = f2.H; ca.W = f2.W; ca.OH = f2.H; ca.OW = f2.W; ca.cin = C; ca.cout = f2.C; ca.stride = 1; ca.act = ACT_NONE;
   ca.accumulate = 0; ca.w_transposed = 1;
-  launch_pw(ca, s);
+  const bool detached = ctx->enc_net == JN_NET_DETECTOR;        // src/models/gpt.py:376-380, see jn_reinforce_step
+  if (!detached) launch_pw(ca, s);
   launch_pw_bwd_weight(ctx->de_ws, C, view_ptr(net, 0, MB, f2), net.act_dtype, net.bufs[f2.buf].C, view_tab(net, 0, f2),
                        grad_of(ctx, g.efpn_w), ctx->wpart, (long long)N * HW, C, f2.C, s);
+  if (detached) { JN_HIP(hipGetLastError()); return JN_OK; }
   for (int i = 0; i < 2; ++i) {
     const View& f = net.fpn[i];
     JN_HIP(hipMemsetAsync(net.gact + net.buf_off[f.buf] * (size_t)MB + f.coff, 0, (size_t)N * f.H * f.W * f.C * sizeof(float), s));
@@ -1973,6 +1986,10 @@ int jn_last_timing(jn_ctx* ctx, int what, float* ms) {
   JN_HIP(hipEventSynchronize(ctx->ev[1]));
   if (what == 0) {
     JN_HIP(hipEventElapsedTime(ms, ctx->ev[0], ctx->ev[1]));
+  } else if (what == 2) {
+    JN_CHECK(ctx->bwd_timed, JN_ESTATE, "no profiled jn_reinforce_step has run");
+    JN_HIP(hipEventSynchronize(ctx->ev[3]));
+    JN_HIP(hipEventElapsedTime(ms, ctx->ev[2], ctx->ev[3]));
   } else {
     float tot = 0.0f;
     for (int i = 0; i + 1 < ctx->conv_ev_used; i += 2) {

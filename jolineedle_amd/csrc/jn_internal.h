@@ -218,6 +218,7 @@ struct jn_ctx {
   bool last_stop_early = true;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool profiling = false;
+  bool bwd_timed = false;         // ev[2] / ev[3] bracket a conv-stack backward
   std::vector<hipEvent_t> conv_ev;   // pairs per step when profiling
   int conv_ev_used = 0;
 };

@@ -441,6 +441,35 @@ def test_full_size_c3_properties():
 # --------------------------------------------------------------------------------------
 # training: one REINFORCE iteration (src/reinforce.py:302-353)
 # --------------------------------------------------------------------------------------
+GRAD_TOL = 5e-3      # tightened once the per-tensor report of a GPU run is in
+
+# Gradient bar: max|got - ref| <= 1e-3 * max|ref| per tensor (north star: 1e-3).  `loose` names the tensors that are held to
+# 5e-3 instead, with the reason at the call site.  JN_TEST_GRAD_REPORT=<file> appends every tensor's error (a measuring aid).
+def _check_grads(grads, oracle, skip_prefix=("yolox",), tol=1e-3, loose=(), loose_tol=5e-3, tag=""):
+    import os
+    rows, checked = [], 0
+    for name, p in oracle.named_parameters():
+        if any(name.startswith(sp) for sp in skip_prefix) or p.grad is None or not p.requires_grad:
+            continue
+        gp, ref = grads[name], p.grad
+        scale = ref.abs().max().item()
+        if scale < 1e-12:
+            assert gp.abs().max().item() < 1e-9, name
+            continue
+        err = (gp - ref).abs().max().item() / scale
+        rows.append((err, name, scale))
+        checked += 1
+    rep = os.environ.get("JN_TEST_GRAD_REPORT")
+    if rep:
+        with open(rep, "a") as f:
+            for err, name, scale in sorted(rows, reverse=True)[:25]:
+                f.write(f"{tag}\t{name}\t{err:.3e}\t{scale:.3e}\n")
+    for err, name, scale in rows:
+        bar = loose_tol if any(k in name for k in loose) else tol
+        assert err < bar, (tag, name, err, scale, sorted(rows, reverse=True)[:5])
+    return checked
+
+
 def _oracle_reinforce_grads(oracle, images, bboxes, start, forced, P, Tn, stop, mean, std, ew):
     from oracle import env_ref, rollout_ref
     oracle.train()
@@ -456,7 +485,8 @@ def _oracle_reinforce_grads(oracle, images, bboxes, start, forced, P, Tn, stop, 
 
 @pytest.mark.parametrize("stop,B,P,Tn,grad_slots,arch", [
     (True, 3, 64, 4, None, {}), (False, 2, 96, 3, None, {}), (True, 3, 64, 4, 3, {}),
-    (True, 3, 96, 3, None, dict(model_type="gpt-mini", gpt_backbone="yolox-s"))])     # BASELINE config 5 topology
+    (True, 3, 96, 3, None, dict(model_type="gpt-mini", gpt_backbone="yolox-s")),      # BASELINE config 5 topology
+    (True, 2, 448, 20, None, {})])                                                     # BASELINE configs[2] patch / sequence sizes
 def test_reinforce_iteration_gradients_vs_oracle(stop, B, P, Tn, grad_slots, arch, monkeypatch):
     """loss.backward() of a whole REINFORCE iteration (train-mode BN per glimpse step, T backbone
     passes, causal GPT over the trajectory) against torch autograd on the CPU oracle.  The backward is
@@ -475,19 +505,7 @@ def test_reinforce_iteration_gradients_vs_oracle(stop, B, P, Tn, grad_slots, arc
     got_m = tr.train_iteration(env, forced_actions=forced, start_positions=start, optimizer_step=False)
     for k in ("action_loss", "entropy_loss", "loss", "returns", "episode_length"):
         assert abs(float(got_m[k]) - float(m[k])) < 2e-4, (k, float(got_m[k]), float(m[k]))
-    grads = product.engine_grads()
-    checked = 0
-    for name, p in oracle.named_parameters():
-        if name.startswith("yolox") or p.grad is None or not p.requires_grad:
-            continue
-        gp, ref = grads[name], p.grad
-        scale = ref.abs().max().item()
-        if scale < 1e-12:
-            assert gp.abs().max().item() < 1e-9, name
-            continue
-        err = (gp - ref).abs().max().item() / scale
-        assert err < 5e-3, (name, err, scale)
-        checked += 1
+    checked = _check_grads(product.engine_grads(), oracle, tol=GRAD_TOL, tag=f"reinforce P={P} T={Tn} {arch.get('gpt_backbone', 'nano')}")
     assert checked > 150
     # running statistics moved Tn times, as in the reference's train-mode rollout
     product.pull_bn_statistics()
@@ -843,7 +861,7 @@ def test_eval_on_batch_detection_metrics_vs_oracle():
 # --------------------------------------------------------------------------------------
 # supervised teacher-forced step (BASELINE configs 1-2)
 # --------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,T,P,stop_w", [(2, 4, 64, 0.1), (4, 8, 64, 1.0)])
+@pytest.mark.parametrize("B,T,P,stop_w", [(2, 4, 64, 0.1), (4, 8, 64, 1.0), (4, 8, 448, 1.0)])     # last: BASELINE configs[0]/[1] sizes
 def test_supervised_step_vs_oracle(B, T, P, stop_w):
     product, oracle = make_pair(13, patch_size=P, block_size=T, with_detector=False, image_processor=None,
                                 max_batch=B * T)
@@ -869,17 +887,7 @@ def test_supervised_step_vs_oracle(B, T, P, stop_w):
     assert abs(float(m["loss"]) - float(loss)) < 2e-4
     assert abs(float(m["action_accuracy"]) - float(acc)) < 1e-6
     assert abs(float(m["episode_length"]) - float(masks.sum(1).float().mean())) < 1e-6
-    grads = product.engine_grads()
-    n = 0
-    for name, p in oracle.named_parameters():
-        if p.grad is None or not p.requires_grad:
-            continue
-        scale = p.grad.abs().max().item()
-        if scale < 1e-12:
-            continue
-        err = (grads[name] - p.grad).abs().max().item() / scale
-        assert err < 5e-3, (name, err)
-        n += 1
+    n = _check_grads(product.engine_grads(), oracle, skip_prefix=(), tol=GRAD_TOL, tag=f"supervised B={B} T={T} P={P}")
     assert n > 150
 
 
@@ -920,6 +928,84 @@ def test_bf16_mode_logits_and_rollout_golden(golden):
     for b in range(4):                                     # the gather stays bit exact in every mode
         y, x = pos[b, 1].tolist()
         assert torch.equal(ro["patches"][b, 1].cpu(), images[b, :, y * P:(y + 1) * P, x * P:(x + 1) * P])
+
+
+def test_rollout_with_detection_shared_encoder_is_race_free():
+    """gpt_backbone=None (the reference's default, main.py --gpt-backbone): the detector's own PAFPN encodes the patches
+    (src/models/gpt.py:376-380), so the per-glimpse detector pass and the next encoder pass use the same workspace and
+    must stay in stream order.  Three identical rollouts must agree with each other bit for bit and with the oracle."""
+    from oracle import env_ref, rollout_ref
+    P, Tn, B = 64, 3, 2
+    images, bboxes, start = synth_batch(B, 3, 3, P, seed=8)
+    images = _blocky_images(B, 3 * P, 8)
+    calib = images[:, :, :P, :P].contiguous()
+    _, oracle0 = _detector_pair(P, 0.5, max_batch=B, calib=calib, gpt_backbone=None)
+    with torch.no_grad():
+        raw = oracle0.yolox.head(oracle0.yolox.backbone(images[:, :, :P, :P]))
+    thr = _gap_threshold(raw[..., 4] * raw[..., 5], 30)
+    product, oracle = _detector_pair(P, thr, max_batch=B, calib=calib, gpt_backbone=None)
+    forced = torch.tensor([[1, 3, 0], [3, 1, 2]])
+    with torch.no_grad():
+        ref = rollout_ref.rollout(oracle, env_ref.EnvRef(images, bboxes, P, Tn, 1, True), do_detection=True,
+                                  forced_actions=forced, start_positions=start)
+    runs = []
+    for _ in range(3):
+        env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True)
+        runs.append(ja.ReinforceTrainer(_cfg(T=Tn), product).rollout(env, do_detection=True, forced_actions=forced,
+                                                                      start_positions=start))
+    ro = runs[0]
+    assert torch.equal(ro["positions"].cpu(), ref["positions"])
+    assert (ro["logits"].cpu() - ref["logits"]).abs().max() < 1e-3
+    for other in runs[1:]:
+        assert torch.equal(other["logits"], ro["logits"])
+        assert torch.equal(other["det_counts"], ro["det_counts"])
+    for b in range(B):
+        for t in range(Tn + 1):
+            r, g = ref["bboxes"][b][t], ro["bboxes"][b][t]
+            assert (r is None) == (g is None), (b, t)
+            if r is not None:
+                _same_boxes(g.cpu(), r, 1e-3 * P)
+                for other in runs[1:]:
+                    assert torch.equal(other["bboxes"][b][t], g)
+
+
+def test_reinforce_gradients_stop_at_a_detached_detector_encoder():
+    """gpt_backbone=None: the reference detaches the detector's FPN maps ("Do not backpropagate through yolox",
+    src/models/gpt.py:376-380), so the policy gradient reaches embed_fpn and the transformer only and every yolox.*
+    gradient stays zero."""
+    P, Tn, B = 64, 3, 2
+    product, oracle = make_pair(5, patch_size=P, block_size=Tn, image_processor="yolox-nano", gpt_backbone=None)
+    images, bboxes, start = synth_batch(B, 3, 4, P, seed=41)
+    forced = torch.randint(0, 8, (B, Tn), generator=torch.Generator().manual_seed(3))
+    ro, m = _oracle_reinforce_grads(oracle, images, bboxes, start, forced, P, Tn, True, 0.25, 1.5, 0.01)
+    tr = ja.ReinforceTrainer(_cfg(T=Tn, learning_rate=1e-3, gradient_accumulation=1), product)
+    tr.last_return_mean, tr.last_return_std = 0.25, 1.5
+    env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True)
+    got_m = tr.train_iteration(env, forced_actions=forced, start_positions=start, optimizer_step=False)
+    assert abs(float(got_m["loss"]) - float(m["loss"])) < 2e-4
+    grads = product.engine_grads()
+    n = _check_grads(grads, oracle, tol=GRAD_TOL, tag="reinforce detached")
+    assert n > 30
+    for name, g in grads.items():
+        if name.startswith("yolox"):
+            assert float(g.abs().max()) == 0.0, name
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for n_, p in oracle.named_parameters() if n_.startswith("yolox"))
+
+
+def test_bf16_mode_supervised_forward_at_config2_size():
+    """BASELINE configs[1] ("same config on 1 x MI355X, bf16"): the teacher-forced forward of the supervised step at its
+    sizes (B=4, T=8, 448 px) in the bf16 inference mode — logits within 1e-3 of the fp32 CPU oracle (north star).  bf16
+    TRAINING is a refused deviation (test_bf16_mode_refuses_training)."""
+    B, T, P = 4, 8, 448
+    product, oracle = make_pair(13, patch_size=P, block_size=T, with_detector=False, image_processor=None,
+                                max_batch=B, act_dtype="bf16")
+    patches, cur, positions = synth_tokens(B, T, P, 9, 10, seed=23)
+    with torch.no_grad():
+        ref, ref_emb = oracle(patches, cur, torch.zeros(B, dtype=torch.long), positions)
+    lg, emb = product(patches, cur, torch.zeros(B, dtype=torch.long), positions)
+    assert lg.shape == (B, T, 9)
+    assert (lg.cpu() - ref).abs().max() < 1e-3
+    assert (emb.cpu() - ref_emb).abs().max() < 1e-3
 
 
 def test_bf16_mode_refuses_training():
