@@ -197,9 +197,9 @@ def _pick_threads(oracle, P):
 
 def cpu_baseline(P, T, seed, train):
     """CPU oracle (pure PyTorch fp32 restatement, oracle/) on the host cores: a bounded sample of the same workload —
-    B=4 agents x T glimpse steps, 1 warm-up + median of 3, thread count picked by a sweep.
-    4480x4480 images would need 1 GB/agent on the host, so the sample uses a 3x3 grid (the patch content is what costs;
-    the grid size does not)."""
+    B=4 agents x up to T glimpse steps, 1 warm-up + median of 3, thread count picked by a sweep; the
+    number of steps is cut so that the whole leg takes ~30 s (a short probe run sets it).  4480x4480 images would need
+    1 GB/agent on the host, so the sample uses a 3x3 grid (the patch content is what costs; the grid size does not)."""
     from oracle import env_ref, rollout_ref
     from oracle.gpt_ref import build_gpt_ref
     torch.manual_seed(seed)
@@ -211,11 +211,10 @@ def cpu_baseline(P, T, seed, train):
     opt = torch.optim.AdamW(params, lr=1e-4)
     images = torch.rand(B, 3, G * P, G * P)
     bboxes = torch.tensor([[[10, 10, 200, 200]]] * B)
-    forced = torch.randint(0, 8, (B, T))
     start = torch.randint(0, G, (B, 2))
-    times = []
-    for it in range(4):                                    # 1 warm-up + 3 timed
-        env = env_ref.EnvRef(images, bboxes, P, T, 1, True)
+
+    def one(Tc, forced):
+        env = env_ref.EnvRef(images, bboxes, P, Tc, 1, True)
         t0 = time.perf_counter()
         if train:
             opt.zero_grad()
@@ -228,16 +227,19 @@ def cpu_baseline(P, T, seed, train):
             with torch.no_grad():
                 ro = rollout_ref.rollout(oracle, env, forced_actions=forced, start_positions=start)
                 rollout_ref.reinforce_metrics(ro, 0.01, rollout_ref.ReturnNormaliser())
-        if it:
-            times.append(time.perf_counter() - t0)
-        if it == 0 and time.perf_counter() - t0 > 40.0:   # a slow host: keep the default run within minutes
-            times.append(time.perf_counter() - t0)
-            break
+        return time.perf_counter() - t0
+
+    probe = one(2, torch.randint(0, 8, (B, 2)))            # also the warm-up of the allocator / oneDNN primitives
+    probe = min(probe, one(2, torch.randint(0, 8, (B, 2))))
+    rate = 2 * B / probe
+    Tc = max(2, min(T, int(30.0 * rate / (4 * B))))
+    forced = torch.randint(0, 8, (B, Tc))
+    times = [one(Tc, forced) for _ in range(4)][1:]
     med = sorted(times)[len(times) // 2]
     what = "full REINFORCE iteration (fwd + bwd + clip + AdamW)" if train else "forward rollout + loss"
-    return {"value": round(B * T / med, 2), "unit": "glimpse-patches/s", "cores": threads,
-            "kind": "port", "sample": f"B={B} agents x T={T} steps, {P}px patches, 3x3-patch images, forced actions, "
-            f"{what}, 1 warm-up + median of {len(times)} ({med:.2f} s), {threads} torch threads picked by a sweep on a "
+    return {"value": round(B * Tc / med, 2), "unit": "glimpse-patches/s", "cores": threads,
+            "kind": "port", "sample": f"B={B} agents x T={Tc} steps (of {T}; cut to fit ~30 s), {P}px patches, 3x3-patch images, "
+            f"forced actions, {what}, 1 warm-up + median of 3 ({med:.2f} s), {threads} torch threads picked by a sweep on a "
             f"{ncpu}-CPU host"}
 
 

@@ -652,6 +652,61 @@ struct StemSrc {
   int pos_stride = 2;
 };
 
+// Descriptors of the deferred BatchNorm tables (ChanTab): which (sum, sumsq) pair, BatchNorm weight / bias and pixel
+// count stand behind every table channel, and the reverse map for the one finalize launch per pass.  Only the depthwise
+// fp32 PAFPN (the nano patch encoder) takes part: its consumers all read their table through jn_tab.h.
+static int ensure_defer_tables(jn_ctx* ctx, Net& net) {
+  if (net.defer_built) return JN_OK;
+  net.defer_built = true;
+  static const bool off = std::getenv("JN_NO_DEFER_BN") != nullptr;
+  bool ok = !off && net.depthwise && net.act_dtype == JN_F32 && ctx->params;
+  const int n_ops = net.n_backbone_ops < 0 ? (int)net.ops.size() : net.n_backbone_ops;
+  for (int oi = 0; ok && oi < n_ops; ++oi) {
+    const Op& op = net.ops[oi];
+    if (op.kind == OP_CONV3 || op.kind == OP_PRED) ok = false;
+    if (op.kind == OP_DW && op.in.C % 16 != 0) ok = false;
+    if (op.wslot >= 0 && !net.convs[op.wslot].has_bn) ok = false;
+  }
+  if (!ok) return JN_OK;
+  const int TC = net.tab_channels, SC = net.stat_channels;
+  std::vector<int> td_src(TC, -1), td_g(TC, 0), td_b(TC, 0), fd_g(SC, 0), fd_b(SC, 0), fd_t0(SC, 0), fd_t1(SC, -1);
+  std::vector<float> td_hw(TC, 0.0f), fd_hw(SC, 0.0f);
+  std::vector<float*> fd_rm(SC, nullptr), fd_rv(SC, nullptr);
+  for (int oi = 0; oi < n_ops; ++oi) {
+    const Op& op = net.ops[oi];
+    if (op.wslot < 0) continue;
+    const ConvW& cw = net.convs[op.wslot];
+    const float hw = (float)(op.out.H * op.out.W);
+    for (int j = 0; j < cw.cout; ++j) {
+      const int i = cw.stat_off + j;
+      const int g = (int)(cw.gamma_dev - ctx->params) + j, b = (int)(cw.beta_dev - ctx->params) + j;
+      fd_hw[i] = hw; fd_g[i] = g; fd_b[i] = b; fd_rm[i] = cw.rmean_dev + j; fd_rv[i] = cw.rvar_dev + j;
+      const View* vs[2] = {&op.out, op.alias.buf >= 0 ? &op.alias : nullptr};
+      for (int k = 0; k < 2; ++k) {
+        if (!vs[k]) continue;
+        const int tc = net.tab_off[vs[k]->buf] + vs[k]->coff + j;
+        (k == 0 ? fd_t0 : fd_t1)[i] = tc;
+        td_src[tc] = i; td_hw[tc] = hw; td_g[tc] = g; td_b[tc] = b;
+      }
+    }
+  }
+  int rc;
+  auto up = [&](auto** dst, const auto& host) -> int {
+    using T = typename std::remove_reference<decltype(host[0])>::type;
+    typename std::remove_const<T>::type* d = nullptr;
+    if ((rc = dev_alloc(ctx, &d, host.size()))) return rc;
+    JN_HIP(hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dst = d;
+    return JN_OK;
+  };
+  if ((rc = up(&net.td_src, td_src)) || (rc = up(&net.td_goff, td_g)) || (rc = up(&net.td_boff, td_b)) || (rc = up(&net.td_hw, td_hw)) ||
+      (rc = up(&net.fd_hw, fd_hw)) || (rc = up(&net.fd_goff, fd_g)) || (rc = up(&net.fd_boff, fd_b)) || (rc = up(&net.fd_t0, fd_t0)) ||
+      (rc = up(&net.fd_t1, fd_t1)) || (rc = up(&net.fd_rm, fd_rm)) || (rc = up(&net.fd_rv, fd_rv)))
+    return rc;
+  net.defer_ok = true;
+  return JN_OK;
+}
+
 // One pass of a PAFPN over N patches in workspace slot `slot`.  train != 0: batch-statistics
 // BatchNorm (stats accumulated by every conv, finalised per layer, running stats updated).
 static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int train, const int* skip_flag,
@@ -666,11 +721,24 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
   // (a train-mode rollout zeroes the statistics of all its slots with ONE memset up front)
   if (train && !ctx->stats_prezeroed) JN_HIP(hipMemsetAsync(stats, 0, (size_t)JN_NREP * 2 * net.stat_channels * sizeof(double), s));
   const long long rep_stride = 2LL * net.stat_channels;
+  // deferred tables: the small-map layers of the depthwise fp32 encoder get no finalize launch of their own; their
+  // consumers read the batch sums (ChanTab in jn_kernels.h), one finalize launch closes the pass
+  if (train && !with_head && (rc = ensure_defer_tables(ctx, net))) return rc;
+  const bool defer = train && !with_head && net.defer_ok;
+  auto deferred = [&](const Op& op) { return defer && (long long)N * op.out.H * op.out.W <= JN_DEFER_MAX_M; };
   auto ptr = [&](const View& v) { return view_ptr(net, slot, MB, v); };
-  auto tab = [&](const View& v) { return view_tab(net, slot, v); };
+  auto tab = [&](const View& v) {
+    ChanTab t = view_tab(net, slot, v);
+    if (defer) {
+      const int off = net.tab_off[v.buf] + v.coff;
+      t.dsrc = net.td_src + off; t.dhw = net.td_hw + off; t.dgoff = net.td_goff + off; t.dboff = net.td_boff + off;
+      t.dparams = ctx->params; t.dstats = stats; t.drep_stride = rep_stride; t.dN = N;
+    }
+    return t;
+  };
   auto ld = [&](const View& v) { return net.bufs[v.buf].C; };
   auto finalize = [&](const Op& op, const ConvW& cw) {
-    if (!train || !cw.has_bn) return;
+    if (!train || !cw.has_bn || deferred(op)) return;
     static const bool dbg_skip = std::getenv("JN_DBG_SKIP_FINALIZE") != nullptr;   // timing experiment only
     if (dbg_skip) return;
     ChanTab t1{nullptr, nullptr, nullptr};
@@ -694,7 +762,7 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
         const ConvW& cw = net.convs[op.wslot];
         StemArgs a{ss.src, ss.positions, ss.pos_stride, ss.sample_stride, ss.chan_stride, ss.row_stride, net.P, N, cw.cout,
                    cw.w_dev, ptr(op.out), ld(op.out), net.act_dtype, train ? stats + 2 * cw.stat_off : nullptr, rep_stride,
-                   skip_flag, skip_when};
+                   skip_flag, skip_when, deferred(op) ? JN_NREP_DEFER : JN_NREP};
         launch_stem(a, s);
         finalize(op, cw);
         break;
@@ -739,6 +807,7 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
         a.cin = op.in.C; a.cout = op.out.C; a.stride = op.stride; a.act = op.act;
         a.stats = (train && cw.has_bn) ? stats + 2 * cw.stat_off : nullptr;
         a.stats_rep_stride = rep_stride;
+        a.stats_nrep = deferred(op) ? JN_NREP_DEFER : JN_NREP;
         a.skip_flag = skip_flag; a.skip_when = skip_when;
         if (op.kind == OP_PW) launch_pw(a, s); else if (op.kind == OP_DW) launch_dw(a, s); else launch_conv3(a, s);
         finalize(op, cw);
@@ -786,6 +855,15 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
     }
     fprintf(stderr, "# total %.1f us, %.1f MB, %.0f GB/s\n", tot_us, tot_b / 1e6, tot_b / (tot_us * 1e-6) / 1e9);
     for (auto& e : lev) hipEventDestroy(e);
+  }
+  if (defer) {
+    BnAllArgs fa{};
+    fa.stats = stats; fa.rep_stride = rep_stride; fa.n_stat = net.stat_channels; fa.N = N; fa.hw = net.fd_hw;
+    fa.goff = net.fd_goff; fa.boff = net.fd_boff; fa.params = ctx->params; fa.t0 = net.fd_t0; fa.t1 = net.fd_t1;
+    fa.tab = net.tab + (size_t)slot * 3 * net.tab_channels; fa.tab_channels = net.tab_channels; fa.save = save;
+    fa.run_mean = net.fd_rm; fa.run_var = net.fd_rv; fa.eps = kBnEps; fa.momentum = kBnMomentum;
+    fa.skip_flag = skip_flag; fa.skip_when = skip_when;
+    launch_bn_finalize_all(fa, s);
   }
   JN_HIP(hipGetLastError());
   if (train) net.eval_tab_dirty = true;     // running statistics moved

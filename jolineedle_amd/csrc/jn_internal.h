@@ -119,6 +119,11 @@ struct Net {
   double* bred = nullptr;         // [g_slots][JN_NREP][2 * stat_channels] backward reductions (sum g_y, sum g_y * zhat)
   float* bconsts = nullptr;       // [g_slots][3 * stat_channels] per-channel backward constants
   bool eval_tab_dirty = true;     // slot-0 table must be rebuilt from the running statistics
+  // deferred BatchNorm tables (ChanTab in jn_kernels.h): per table channel / per BatchNorm channel descriptors
+  bool defer_ok = false, defer_built = false;
+  int *td_src = nullptr, *td_goff = nullptr, *td_boff = nullptr; float* td_hw = nullptr;      // [tab_channels]
+  float* fd_hw = nullptr; int *fd_goff = nullptr, *fd_boff = nullptr, *fd_t0 = nullptr, *fd_t1 = nullptr;   // [stat_channels]
+  float **fd_rm = nullptr, **fd_rv = nullptr;
 };
 
 struct ParamEntry {

@@ -23,7 +23,21 @@ constexpr int JN_WPART_MAX = 16384;   // floats per replica of the weight-gradie
 // Per-channel "normalize on read" table of a buffer view: a = fl ? silu(z * sc + sh) : z.
 struct ChanTab {
   float* sc; float* sh; float* fl;
+  // Deferred entries (train-mode forward, DESIGN.md §4 "consumer-side BatchNorm tables"): a layer whose output has at
+  // most JN_DEFER_MAX_M pixels in this launch gets NO bn_finalize launch; its consumers derive (scale, shift) of such a
+  // channel from the producer's batch sums in their prologue (jn_tab.h), and ONE bn_finalize_all launch at the end of the
+  // pass writes the table, the saved statistics and the running averages of all those layers.  All arrays below are
+  // indexed like sc / sh / fl (per view channel); dsrc == nullptr: a plain table.
+  const int* dsrc;         // index of the channel's (sum, sumsq) pair inside one replica of dstats, or -1 (never deferred)
+  const float* dhw;        // H * W of the layer that produced the channel (the count is dN * dhw)
+  const int* dgoff; const int* dboff;   // offsets of the channel's BatchNorm weight / bias in dparams
+  const float* dparams;    // parameter arena
+  const double* dstats;    // [JN_NREP_DEFER used][drep_stride] batch sums of the workspace slot
+  long long drep_stride;
+  int dN;                  // patches in this pass
 };
+constexpr long long JN_DEFER_MAX_M = 65536;   // output pixels (N * H * W) up to which a layer's table is deferred
+constexpr int JN_NREP_DEFER = 8;              // statistics replicas such a layer accumulates into (its consumers sum them)
 
 // Step batching of the backward: ONE launch covers `n` workspace slots (glimpse steps of a trajectory, each
 // with its own batch-statistics tables); slot j adds j * stride to the per-slot pointers.  The default is the
@@ -47,6 +61,7 @@ struct StemArgs {
   double* stats;                    // [JN_NREP][rep_stride]: [cout][2] sum / sumsq accumulators (train) or null
   long long stats_rep_stride;
   const int* skip_flag; int skip_when;
+  int stats_nrep;                   // replicas in use (0 -> JN_NREP)
 };
 
 struct ConvArgs {
@@ -59,6 +74,7 @@ struct ConvArgs {
   int accumulate;                        // out += (gradient buffers)
   int w_transposed;                      // pw: w is [cin][cout] and read transposed (data-gradient)
   double* stats; long long stats_rep_stride;
+  int stats_nrep;                        // replicas the workgroups spread their sums over (0 -> JN_NREP)
   const int* skip_flag; int skip_when;
   int n_slots;                           // pw: gridDim.z slots, pointers advance by the strides below (0 -> 1 slot)
   long long in_slot_stride, out_slot_stride, tab_slot_stride;
@@ -77,6 +93,8 @@ int launch_dwpw(const DwPwArgs& a, hipStream_t s);
 int launch_stem(const StemArgs& a, hipStream_t s);
 int launch_dw(const ConvArgs& a, hipStream_t s);
 int launch_pw(const ConvArgs& a, hipStream_t s);
+bool pw_res_supported(const ConvArgs& a);              // kernels_pwres.hip: resident-weight kernel for K, N >= 64
+int launch_pw_res(const ConvArgs& a, hipStream_t s);
 int launch_spp(void* cat, int dtype, int ld, int h, int H, int W, int N, ChanTab it, const int* skip_flag,
                int skip_when, hipStream_t s);
 int launch_upsample(const void* in, int in_ld, void* out, int out_ld, int dtype, int C, int H, int W, int N,
@@ -86,6 +104,20 @@ int launch_addact(const void* z, int z_ld, ChanTab zt, const void* res, int res_
 int launch_bn_finalize(const double* stats, long long rep_stride, double count, const float* gamma, const float* beta, float* run_mean,
                        float* run_var, float* save, ChanTab t0, ChanTab t1, int C, float eps, float momentum,
                        const int* skip_flag, int skip_when, hipStream_t s);
+// deferred BatchNorm tables: one finalize launch per pass (kernels_conv.hip); arrays are per BatchNorm ("stat") channel
+struct BnAllArgs {
+  const double* stats; long long rep_stride; int n_stat; int N;
+  const float* hw;                       // H * W of the channel's layer
+  const int* goff; const int* boff;      // BatchNorm weight / bias offsets in params
+  const float* params;
+  const int* t0; const int* t1;          // table channel of the layer output, and of its upsampled alias (-1: none)
+  float* tab; int tab_channels;          // the slot's table [3][tab_channels]
+  float* save;                           // [n_stat][2] (mean, invstd)
+  float* const* run_mean; float* const* run_var;   // per-channel addresses of the running statistics
+  float eps, momentum;
+  const int* skip_flag; int skip_when;
+};
+int launch_bn_finalize_all(const BnAllArgs& a, hipStream_t s);
 int launch_nhwc_to_nchw(const void* in, int dtype, int in_ld, ChanTab it, float* out, int C, int HW, int N,
                         hipStream_t s);
 int launch_efpn_linear(const float* e, const float* wt, float* part, int N, int K, int Co, int KS,

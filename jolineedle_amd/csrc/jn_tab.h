@@ -1,0 +1,69 @@
+// "Normalize on read" helpers shared by the forward kernels: a = flag ? silu(z * scale + shift) : z, and the
+// per-channel (scale, shift, flag) entries — from the table, or (deferred entries, see ChanTab in jn_kernels.h)
+// straight from the batch sums of the producing layer.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "jn_kernels.h"
+#include "jn_types.h"
+
+namespace jnr {
+
+__device__ __forceinline__ float silu_tab(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+__device__ __forceinline__ f32x4 tf4_tab(f32x4 z, f32x4 sc, f32x4 sh, f32x4 fl) {
+  f32x4 r;
+  r.x = fl.x != 0.0f ? silu_tab(fmaf(z.x, sc.x, sh.x)) : z.x;
+  r.y = fl.y != 0.0f ? silu_tab(fmaf(z.y, sc.y, sh.y)) : z.y;
+  r.z = fl.z != 0.0f ? silu_tab(fmaf(z.z, sc.z, sh.z)) : z.z;
+  r.w = fl.w != 0.0f ? silu_tab(fmaf(z.w, sc.w, sh.w)) : z.w;
+  return r;
+}
+
+// Train-mode BatchNorm (eps 1e-3) of one channel from its fp64 (sum, sumsq) replicas: the arithmetic of
+// bn_finalize_kernel / bn_finalize_all_kernel, so that a consumer that derives the entry itself and the table written
+// at the end of the pass agree bit for bit.
+__device__ __forceinline__ void bn_from_sums(const double* __restrict__ st, long long rep_stride, int nrep, int idx, double count,
+                                             float gamma, float beta, float eps, float& sc, float& sh, float& mean_f,
+                                             float& invstd_f, double& var_out) {
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < nrep; ++r) {
+    const double2 v = *reinterpret_cast<const double2*>(st + r * rep_stride + 2 * idx);
+    s1 += v.x; s2 += v.y;
+  }
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  sc = gamma * invstd;
+  sh = beta - (float)mean * sc;
+  mean_f = (float)mean; invstd_f = invstd; var_out = var;
+}
+
+// is channel c of the view a deferred entry in this launch?
+__device__ __forceinline__ bool tab_deferred(const ChanTab& t, int c) {
+  return t.dsrc && t.dsrc[c] >= 0 && (long long)t.dN * (long long)t.dhw[c] <= JN_DEFER_MAX_M;
+}
+
+__device__ __forceinline__ void tab_entry(const ChanTab& t, int c, float& sc, float& sh, float& fl) {
+  if (tab_deferred(t, c)) {
+    float m, is; double var;
+    bn_from_sums(t.dstats, t.drep_stride, JN_NREP_DEFER, t.dsrc[c], (double)t.dN * (double)t.dhw[c], t.dparams[t.dgoff[c]],
+                 t.dparams[t.dboff[c]], 1e-3f, sc, sh, m, is, var);
+    fl = 1.0f;
+  } else {
+    sc = t.sc[c]; sh = t.sh[c]; fl = t.fl[c];
+  }
+}
+
+// (scale, shift, flag) of channels [0, K) of the view -> Tb[3][K4] in LDS (entries K .. K4 are the identity).  The caller
+// synchronises.
+__device__ __forceinline__ void tab_to_lds(float* Tb, int K4, int K, const ChanTab& t, int tid, int nthreads) {
+  for (int c = tid; c < K4; c += nthreads) {
+    float sc = 1.0f, sh = 0.0f, fl = 0.0f;
+    if (c < K) tab_entry(t, c, sc, sh, fl);
+    Tb[c] = sc; Tb[K4 + c] = sh; Tb[2 * K4 + c] = fl;
+  }
+}
+
+}  // namespace jnr

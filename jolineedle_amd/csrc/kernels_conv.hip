@@ -23,10 +23,12 @@
 //   bn_finalize_kernel  batch statistics -> (scale, shift) table, running-stat update.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "jn_kernels.h"
 #include "jn_reduce.h"
+#include "jn_tab.h"
 #include "jn_types.h"
 
 namespace jnr {
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(
     const float* __restrict__ src, const long long* __restrict__ pos, int pos_stride, long long sample_stride,
     long long chan_stride, int row_stride, int P, const float* __restrict__ w, OT* __restrict__ out,
     int out_ld, int cout, int tiles_x, int tiles_y, int n_tiles, double* __restrict__ stats, long long rep_stride,
-    const int* __restrict__ skip_flag, int skip_when) {
+    const int* __restrict__ skip_flag, int skip_when, int nrep) {
   if (skip_flag && *skip_flag >= skip_when) return;
   __shared__ __attribute__((aligned(16))) float tile[3 * ST_IH * ST_IW];
   __shared__ float red[4 * 32];
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(
   if (stats) {
     wave_stats_to_lds<1>(s1, s2, red + 32 * wave, lane, 16);
     __syncthreads();
-    const int rep = (blockIdx.x + blockIdx.y) % JN_NREP;
+    const int rep = (blockIdx.x + blockIdx.y) % nrep;
     if (tid < 32)
       atomicAdd(&stats[rep * rep_stride + 2 * (og * 16) + tid], (double)(red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid]));
   }
@@ -153,14 +155,15 @@ int launch_stem(const StemArgs& a, hipStream_t s) {
   if (nwg < 1) nwg = 1;
   if (nwg > n_tiles) nwg = n_tiles;
   dim3 grid(nwg, ocg);
+  const int nrep = a.stats_nrep > 0 ? a.stats_nrep : JN_NREP;
   if (a.out_dtype == JN_BF16)
     hipLaunchKernelGGL(stem_mfma_kernel<bf16_t>, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.pos_stride,
                        a.sample_stride, a.chan_stride, a.row_stride, a.P, a.w, (bf16_t*)a.out, a.out_ld, a.cout, tiles_x,
-                       tiles_y, n_tiles, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when);
+                       tiles_y, n_tiles, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when, nrep);
   else
     hipLaunchKernelGGL(stem_mfma_kernel<float>, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.pos_stride,
                        a.sample_stride, a.chan_stride, a.row_stride, a.P, a.w, (float*)a.out, a.out_ld, a.cout, tiles_x,
-                       tiles_y, n_tiles, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when);
+                       tiles_y, n_tiles, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when, nrep);
   return 0;
 }
 
@@ -256,7 +259,7 @@ template <int S, int CB, int DW_TH, typename AT>
 __global__ __launch_bounds__(256) void dw3x3_lds_kernel(
     const AT* __restrict__ in, int in_ld, ChanTab it, const float* __restrict__ w, AT* __restrict__ out,
     int out_ld, int C, int H, int W, int OH, int OW, int tiles_x, int tiles_y, double* __restrict__ stats,
-    long long rep_stride, const int* __restrict__ skip_flag, int skip_when) {
+    long long rep_stride, const int* __restrict__ skip_flag, int skip_when, int nrep) {
   if (skip_flag && *skip_flag >= skip_when) return;
   constexpr int Q = CB / 4;                          // channel quads per workgroup
   constexpr int IH = S * (DW_TH - 1) + 3, IW = S * (DW_TW - 1) + 3;
@@ -275,8 +278,6 @@ __global__ __launch_bounds__(256) void dw3x3_lds_kernel(
   const int oy0 = ty * DW_TH, ox0 = tx * DW_TW;
   const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
   {
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(it.sc + c), sh = *reinterpret_cast<const f32x4*>(it.sh + c),
-                fl = *reinterpret_cast<const f32x4*>(it.fl + c);
     const AT* inb = in + (long long)n * H * W * in_ld + c;
     // all loads of the tile are issued back to back into registers, then transformed and stored (a load -> transform ->
     // store loop with a run-time trip count waited for one global round trip per iteration); 256 % Q == 0: the quad
@@ -289,6 +290,22 @@ __global__ __launch_bounds__(256) void dw3x3_lds_kernel(
       const int iy = iy0 + r, ix = ix0 + cx;
       rv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (i < IH * IW * Q && iy >= 0 && iy < H && ix >= 0 && ix < W) rv[j] = ld4(inb + ((long long)iy * W + ix) * in_ld);
+    }
+    f32x4 sc, sh, fl;
+    if (it.dsrc) {
+      // deferred entries: CB threads derive (scale, shift) of the workgroup's channels from the batch sums while the tile
+      // loads are in flight; the statistics slots are free until the epilogue
+      if (tid < CB) {
+        float a, b, f;
+        tab_entry(it, cb * CB + tid, a, b, f);
+        red[tid] = a; red[CB + tid] = b; red[2 * CB + tid] = f;
+      }
+      __syncthreads();
+      sc = *reinterpret_cast<const f32x4*>(red + 4 * q); sh = *reinterpret_cast<const f32x4*>(red + CB + 4 * q);
+      fl = *reinterpret_cast<const f32x4*>(red + 2 * CB + 4 * q);
+    } else {
+      sc = *reinterpret_cast<const f32x4*>(it.sc + c); sh = *reinterpret_cast<const f32x4*>(it.sh + c);
+      fl = *reinterpret_cast<const f32x4*>(it.fl + c);
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -352,7 +369,7 @@ __global__ __launch_bounds__(256) void dw3x3_lds_kernel(
       }
     }
     __syncthreads();
-    double* st = stats + ((blockIdx.x + 3 * blockIdx.y) % JN_NREP) * rep_stride + 2 * cb * CB;
+    double* st = stats + ((blockIdx.x + 3 * blockIdx.y) % nrep) * rep_stride + 2 * cb * CB;
     if (tid < 2 * CB) {
       float v = 0.0f;
 #pragma unroll
@@ -370,7 +387,7 @@ static void launch_dw_lds(const ConvArgs& a, hipStream_t s) {
   dim3 grid((unsigned)(tiles_x * tiles_y * (a.cin / CB)), (unsigned)a.N);
   hipLaunchKernelGGL((dw3x3_lds_kernel<S, CB, DW_TH, AT>), grid, dim3(256), smem, s, (const AT*)a.in, a.in_ld, a.itab, a.w,
                      (AT*)a.out, a.out_ld, a.cin, a.H, a.W, a.OH, a.OW, tiles_x, tiles_y, a.stats, a.stats_rep_stride,
-                     a.skip_flag, a.skip_when);
+                     a.skip_flag, a.skip_when, a.stats_nrep > 0 ? a.stats_nrep : JN_NREP);
 }
 
 // ------------------------------------------------------------------------------------
@@ -608,7 +625,7 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
     const IT* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, const float* __restrict__ bias,
     OT* __restrict__ out, int out_ld, long long M, int K, int Nc, int act, int accumulate,
     double* __restrict__ stats, long long rep_stride, const int* __restrict__ skip_flag, int skip_when,
-    long long x_slot, long long out_slot, long long tab_slot) {
+    long long x_slot, long long out_slot, long long tab_slot, int nrep) {
   if (skip_flag && *skip_flag >= skip_when) return;
   x += blockIdx.z * x_slot; out += blockIdx.z * out_slot;        // step-batched launches (gradients)
   it.sc += blockIdx.z * tab_slot; it.sh += blockIdx.z * tab_slot; it.fl += blockIdx.z * tab_slot;
@@ -627,10 +644,6 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
   float* Tb = red + WM * 32 * CT;                                 // [3][K4]
   const int K4 = (K + 3) & ~3;
   const int tid = threadIdx.x;
-  for (int c = tid; c < K4; c += 256) {
-    const bool in = c < K;
-    Tb[c] = in ? it.sc[c] : 1.0f; Tb[K4 + c] = in ? it.sh[c] : 0.0f; Tb[2 * K4 + c] = in ? it.fl[c] : 0.0f;
-  }
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM;
   const int lm = lane & 15, g = lane >> 4;
@@ -690,6 +703,7 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
   };
 
   fetch(0);
+  tab_to_lds(Tb, K4, K, it, tid, 256);    // after the first chunk's loads are in flight (deferred entries read the batch sums)
   __syncthreads();                        // Tb is in place
   for (int k0 = 0; k0 < K; k0 += PW_KC) {
     const int kc = chunk_q4(k0) << 2;     // multiple of KSTEP
@@ -762,7 +776,7 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
       float v = 0.0f;
 #pragma unroll
       for (int q = 0; q < WM; ++q) v += red[q * 32 * CT + tid];
-      atomicAdd(&stats[(blockIdx.x % JN_NREP) * rep_stride + 2 * n0 + tid], (double)v);
+      atomicAdd(&stats[(blockIdx.x % nrep) * rep_stride + 2 * n0 + tid], (double)v);
     }
 #endif
   }
@@ -777,7 +791,7 @@ template <int CT, int KC>
 __global__ __launch_bounds__(256) void pw_narrow_kernel(
     const float* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, float* __restrict__ out, int out_ld,
     long long M, int Nc, double* __restrict__ stats, long long rep_stride, const int* __restrict__ skip_flag,
-    int skip_when) {
+    int skip_when, int nrep) {
   if (skip_flag && *skip_flag >= skip_when) return;
   // waves along the pixel dimension: 2 (64-pixel tiles, wave pairs split the channel tiles) or, for a single channel
   // tile, 4 (128-pixel tiles)
@@ -802,8 +816,17 @@ __global__ __launch_bounds__(256) void pw_narrow_kernel(
     }
   }
   const int q = tid % Q4, r0 = tid / Q4;               // this thread's channel quad and first row of a tile (fixed)
-  const f32x4 t_sc = *reinterpret_cast<const f32x4*>(it.sc + 4 * q), t_sh = *reinterpret_cast<const f32x4*>(it.sh + 4 * q),
-              t_fl = *reinterpret_cast<const f32x4*>(it.fl + 4 * q);
+  f32x4 t_sc, t_sh, t_fl;
+  if (it.dsrc) {                                       // deferred entries (jn_tab.h): KC threads derive them, via the idle statistics slots
+    static_assert(WMW * 32 * CT >= 3 * KC, "statistics slots hold the table");
+    tab_to_lds(red, KC, KC, it, tid, 256);
+    __syncthreads();
+    t_sc = *reinterpret_cast<const f32x4*>(red + 4 * q); t_sh = *reinterpret_cast<const f32x4*>(red + KC + 4 * q);
+    t_fl = *reinterpret_cast<const f32x4*>(red + 2 * KC + 4 * q);
+  } else {
+    t_sc = *reinterpret_cast<const f32x4*>(it.sc + 4 * q); t_sh = *reinterpret_cast<const f32x4*>(it.sh + 4 * q);
+    t_fl = *reinterpret_cast<const f32x4*>(it.fl + 4 * q);
+  }
   const long long n_tiles = (M + BM - 1) / BM;
   f32x4 xr[NX];
   auto fetch = [&](long long m0) {
@@ -877,7 +900,7 @@ __global__ __launch_bounds__(256) void pw_narrow_kernel(
       float v = 0.0f;
 #pragma unroll
       for (int qq = 0; qq < WMW; ++qq) v += red[qq * 32 * CT + tid];
-      atomicAdd(&stats[(blockIdx.x % JN_NREP) * rep_stride + 2 * n0 + tid], (double)v);
+      atomicAdd(&stats[(blockIdx.x % nrep) * rep_stride + 2 * n0 + tid], (double)v);
     }
   }
 }
@@ -891,7 +914,8 @@ static void launch_pw_narrow_t(const ConvArgs& a, long long M, hipStream_t s) {
   dim3 grid(gx, (unsigned)((a.cout + 16 * CT - 1) / (16 * CT)));
   const size_t smem = (size_t)(BM + 16 * CT) * (KC + 4) * sizeof(float) + (BM / 32) * 32 * CT * sizeof(float);
   hipLaunchKernelGGL((pw_narrow_kernel<CT, KC>), grid, dim3(256), smem, s, (const float*)a.in, a.in_ld, a.itab, a.w,
-                     (float*)a.out, a.out_ld, M, a.cout, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when);
+                     (float*)a.out, a.out_ld, M, a.cout, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when,
+                     a.stats_nrep > 0 ? a.stats_nrep : JN_NREP);
 }
 
 // true when the persistent narrow kernel took the launch
@@ -920,7 +944,8 @@ static void launch_pw_kc(const ConvArgs& a, long long M, hipStream_t s) {
                       (size_t)3 * ((a.cin + 3) & ~3) * sizeof(float);
   hipLaunchKernelGGL((pw_mfma_kernel<CT, KC, WT, WM, IT, OT, BF>), grid, dim3(256), smem, s, (const IT*)a.in, a.in_ld,
                      a.itab, a.w, a.bias, (OT*)a.out, a.out_ld, M, a.cin, a.cout, a.act, a.accumulate, a.stats,
-                     a.stats_rep_stride, a.skip_flag, a.skip_when, a.in_slot_stride, a.out_slot_stride, a.tab_slot_stride);
+                     a.stats_rep_stride, a.skip_flag, a.skip_when, a.in_slot_stride, a.out_slot_stride, a.tab_slot_stride,
+                     a.stats_nrep > 0 ? a.stats_nrep : JN_NREP);
 }
 
 template <int CT, bool WT, int WM, typename IT, typename OT, bool BF>
@@ -973,6 +998,7 @@ static void launch_pw_types(const ConvArgs& a, hipStream_t s) {
 // embed_fpn.0 (bf16 -> f32) and gradients (f32 -> f32), all on the bf16 MFMA.
 int launch_pw(const ConvArgs& a, hipStream_t s) {
   if (launch_pw_narrow(a, s)) return 0;
+  if (pw_res_supported(a) && launch_pw_res(a, s) == 0) return 0;
   if (!a.bf16_mfma) {
     if (a.in_dtype == JN_F32 && a.out_dtype == JN_F32) { launch_pw_types<float, float, false>(a, s); return 0; }
     return -1;
@@ -996,13 +1022,20 @@ __global__ __launch_bounds__(256) void spp_kernel(AT* __restrict__ cat, int ld, 
   const int HW = H * W;
   float* A = sp;
   float* Bf = sp + HW * cb;
+  __shared__ float tb[3 * 64];                         // (scale, shift, flag) of the workgroup's channels (cb <= 64)
   const int n = blockIdx.y, c0 = blockIdx.x * cb;
   AT* base = cat + (long long)n * HW * ld + c0;
   const int tid = threadIdx.x;
+  if (tid < cb) {
+    float a, b, f;
+    tab_entry(it, c0 + tid, a, b, f);
+    tb[tid] = a; tb[64 + tid] = b; tb[128 + tid] = f;
+  }
+  __syncthreads();
   for (int e = tid; e < HW * cb; e += 256) {
     const int c = e % cb;
     const float z = ld1(base + (long long)(e / cb) * ld + c);
-    A[e] = it.fl[c0 + c] != 0.0f ? silu(fmaf(z, it.sc[c0 + c], it.sh[c0 + c])) : z;
+    A[e] = tb[128 + c] != 0.0f ? silu(fmaf(z, tb[c], tb[64 + c])) : z;
   }
   __syncthreads();
   for (int stage = 1; stage <= 3; ++stage) {
@@ -1034,7 +1067,7 @@ int launch_spp(void* cat, int dtype, int ld, int h, int H, int W, int N, ChanTab
                int skip_when, hipStream_t s) {
   // channels per block: 2 * HW * cb floats of LDS; 8 -> 1024 workgroups at B = 64 (measured 40.9 us with 32 or 16, 31.9 us with 8)
   static const int cb0 = std::getenv("JN_SPP_CB") ? std::atoi(std::getenv("JN_SPP_CB")) : 8;
-  int cb = cb0;
+  int cb = cb0 > 64 ? 64 : cb0;
   while (cb > 4 && (size_t)H * W * cb * 2 * sizeof(float) > 48 * 1024) cb >>= 1;
   dim3 grid(h / cb, N);
   const size_t smem = (size_t)H * W * cb * 2 * sizeof(float);
@@ -1076,34 +1109,46 @@ int launch_upsample(const void* in, int in_ld, void* out, int out_ld, int dtype,
   return 0;
 }
 
-// Bottleneck shortcut: out = T_res(res) + T_z(z), materialised (table flag 0 on the output).
+// Bottleneck shortcut: out = T_res(res) + T_z(z), materialised (table flag 0 on the output).  Both tables go through LDS
+// (deferred entries are derived from the batch sums once per workgroup), the workgroups stride over the elements.
 template <typename AT>
 __global__ __launch_bounds__(256) void addact_kernel(const AT* __restrict__ z, int z_ld, ChanTab zt,
                                                      const AT* __restrict__ res, int res_ld, ChanTab rt,
                                                      AT* __restrict__ out, int out_ld, int C, long long M,
                                                      const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
+  extern __shared__ __attribute__((aligned(16))) float tb[];      // [2][3][C]
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i >= C, c = which ? i - C : i;
+    float a, b, f;
+    tab_entry(which ? rt : zt, c, a, b, f);
+    float* t = tb + which * 3 * C;
+    t[c] = a; t[C + c] = b; t[2 * C + c] = f;
+  }
+  __syncthreads();
   const int C4 = C >> 2;
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= M * C4) return;
-  const int c = (int)(idx % C4) * 4;
-  const long long m = idx / C4;
-  const f32x4 a = tf4(ld4(z + m * z_ld + c), *reinterpret_cast<const f32x4*>(zt.sc + c),
-                      *reinterpret_cast<const f32x4*>(zt.sh + c), *reinterpret_cast<const f32x4*>(zt.fl + c));
-  const f32x4 r = tf4(ld4(res + m * res_ld + c), *reinterpret_cast<const f32x4*>(rt.sc + c),
-                      *reinterpret_cast<const f32x4*>(rt.sh + c), *reinterpret_cast<const f32x4*>(rt.fl + c));
-  st4(out + m * out_ld + c, a + r);
+  const long long total = M * C4;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % C4) * 4;
+    const long long m = idx / C4;
+    const f32x4 a = tf4(ld4(z + m * z_ld + c), *reinterpret_cast<const f32x4*>(tb + c),
+                        *reinterpret_cast<const f32x4*>(tb + C + c), *reinterpret_cast<const f32x4*>(tb + 2 * C + c));
+    const f32x4 r = tf4(ld4(res + m * res_ld + c), *reinterpret_cast<const f32x4*>(tb + 3 * C + c),
+                        *reinterpret_cast<const f32x4*>(tb + 4 * C + c), *reinterpret_cast<const f32x4*>(tb + 5 * C + c));
+    st4(out + m * out_ld + c, a + r);
+  }
 }
 
 int launch_addact(const void* z, int z_ld, ChanTab zt, const void* res, int res_ld, ChanTab rt, void* out, int out_ld,
                   int dtype, int C, long long M, const int* skip_flag, int skip_when, hipStream_t s) {
   const long long total = M * (C / 4);
-  const dim3 grid((unsigned)((total + 255) / 256));
+  const dim3 grid((unsigned)std::min<long long>((total + 255) / 256, 4096));
+  const size_t smem = (size_t)6 * C * sizeof(float);
   if (dtype == JN_BF16)
-    hipLaunchKernelGGL(addact_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)z, z_ld, zt, (const bf16_t*)res, res_ld,
+    hipLaunchKernelGGL(addact_kernel<bf16_t>, grid, dim3(256), smem, s, (const bf16_t*)z, z_ld, zt, (const bf16_t*)res, res_ld,
                        rt, (bf16_t*)out, out_ld, C, M, skip_flag, skip_when);
   else
-    hipLaunchKernelGGL(addact_kernel<float>, grid, dim3(256), 0, s, (const float*)z, z_ld, zt, (const float*)res, res_ld,
+    hipLaunchKernelGGL(addact_kernel<float>, grid, dim3(256), smem, s, (const float*)z, z_ld, zt, (const float*)res, res_ld,
                        rt, (float*)out, out_ld, C, M, skip_flag, skip_when);
   return 0;
 }
@@ -1150,6 +1195,34 @@ int launch_bn_finalize(const double* stats, long long rep_stride, double count, 
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((8 * C + 255) / 256), dim3(256), 0, s, stats, rep_stride, count, gamma, beta, run_mean,
                      run_var,
                      save, t0, t1, C, eps, momentum, skip_flag, skip_when);
+  return 0;
+}
+
+// One launch at the end of a train-mode pass for every layer whose table was deferred (ChanTab, jn_kernels.h): the same
+// arithmetic as bn_finalize_kernel per BatchNorm channel (thread = channel; layers above the deferral limit had their own
+// finalize launch and are skipped).
+__global__ __launch_bounds__(256) void bn_finalize_all_kernel(BnAllArgs a) {
+  if (a.skip_flag && *a.skip_flag >= a.skip_when) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n_stat) return;
+  const float hw = a.hw[i];
+  if ((long long)a.N * (long long)hw > JN_DEFER_MAX_M) return;
+  const double count = (double)a.N * (double)hw;
+  float sc, sh, mean, invstd; double var;
+  bn_from_sums(a.stats, a.rep_stride, JN_NREP_DEFER, i, count, a.params[a.goff[i]], a.params[a.boff[i]], a.eps, sc, sh, mean,
+               invstd, var);
+  const int t0 = a.t0[i], t1 = a.t1[i];
+  a.tab[t0] = sc; a.tab[a.tab_channels + t0] = sh; a.tab[2 * a.tab_channels + t0] = 1.0f;
+  if (t1 >= 0) { a.tab[t1] = sc; a.tab[a.tab_channels + t1] = sh; a.tab[2 * a.tab_channels + t1] = 1.0f; }
+  a.save[2 * i] = mean; a.save[2 * i + 1] = invstd;
+  const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+  float* rm = a.run_mean[i]; float* rv = a.run_var[i];
+  *rm = (1.0f - a.momentum) * *rm + a.momentum * mean;
+  *rv = (1.0f - a.momentum) * *rv + a.momentum * (float)unbiased;
+}
+
+int launch_bn_finalize_all(const BnAllArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_all_kernel, dim3((a.n_stat + 255) / 256), dim3(256), 0, s, a);
   return 0;
 }
 

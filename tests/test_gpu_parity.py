@@ -441,33 +441,49 @@ def test_full_size_c3_properties():
 # --------------------------------------------------------------------------------------
 # training: one REINFORCE iteration (src/reinforce.py:302-353)
 # --------------------------------------------------------------------------------------
-GRAD_TOL = 5e-3      # tightened once the per-tensor report of a GPU run is in
+GRAD_TOL = 1e-3
 
-# Gradient bar: max|got - ref| <= 1e-3 * max|ref| per tensor (north star: 1e-3).  `loose` names the tensors that are held to
-# 5e-3 instead, with the reason at the call site.  JN_TEST_GRAD_REPORT=<file> appends every tensor's error (a measuring aid).
-def _check_grads(grads, oracle, skip_prefix=("yolox",), tol=1e-3, loose=(), loose_tol=5e-3, tag=""):
+
+# Gradient bar: max|got - ref| <= 1e-3 * max|ref| per tensor (north star: 1e-3).  At the full patch size the fp32 CPU
+# oracle is itself further than that from its own fp64 evaluation on some tensors (train-mode BatchNorm of near-constant
+# deep feature maps amplifies fp32 rounding: 4.8e-3 on embed_fpn.0.weight at 448 px), so those cases pass `ref64`
+# (gradients of the fp64 oracle): the product is then compared with the fp64 values and held to
+# max(1e-3, NOISE_FACTOR x the fp32 oracle's own distance from fp64) — "as accurate as fp32 arithmetic allows".
+# JN_TEST_GRAD_REPORT=<file> appends the worst tensors of every call (a measuring aid).
+NOISE_FACTOR = 4.0
+
+
+def _check_grads(grads, oracle, skip_prefix=("yolox",), tol=GRAD_TOL, tag="", ref64=None):
     import os
     rows, checked = [], 0
     for name, p in oracle.named_parameters():
         if any(name.startswith(sp) for sp in skip_prefix) or p.grad is None or not p.requires_grad:
             continue
-        gp, ref = grads[name], p.grad
+        gp, ref = grads[name].double(), p.grad.double()
+        noise = 0.0
+        if ref64 is not None:
+            r64 = ref64[name]
+            noise = (ref - r64).abs().max().item() / max(r64.abs().max().item(), 1e-30)
+            ref = r64
         scale = ref.abs().max().item()
         if scale < 1e-12:
             assert gp.abs().max().item() < 1e-9, name
             continue
         err = (gp - ref).abs().max().item() / scale
-        rows.append((err, name, scale))
+        rows.append((err, name, scale, noise))
         checked += 1
     rep = os.environ.get("JN_TEST_GRAD_REPORT")
     if rep:
         with open(rep, "a") as f:
-            for err, name, scale in sorted(rows, reverse=True)[:25]:
-                f.write(f"{tag}\t{name}\t{err:.3e}\t{scale:.3e}\n")
-    for err, name, scale in rows:
-        bar = loose_tol if any(k in name for k in loose) else tol
-        assert err < bar, (tag, name, err, scale, sorted(rows, reverse=True)[:5])
+            for err, name, scale, noise in sorted(rows, reverse=True)[:25]:
+                f.write(f"{tag}\t{name}\t{err:.3e}\t{scale:.3e}\t{noise:.3e}\n")
+    for err, name, scale, noise in rows:
+        assert err < max(tol, NOISE_FACTOR * noise), (tag, name, err, scale, noise, sorted(rows, reverse=True)[:5])
     return checked
+
+
+def _grads64(oracle):
+    return {n: p.grad.detach().clone() for n, p in oracle.named_parameters() if p.grad is not None}
 
 
 def _oracle_reinforce_grads(oracle, images, bboxes, start, forced, P, Tn, stop, mean, std, ew):
@@ -497,6 +513,12 @@ def test_reinforce_iteration_gradients_vs_oracle(stop, B, P, Tn, grad_slots, arc
     product, oracle = make_pair(5, patch_size=P, block_size=Tn, nclasses=nA, with_detector=False, image_processor=None, **arch)
     images, bboxes, start = synth_batch(B, 3, 4, P, seed=41)
     forced = torch.randint(0, 8, (B, Tn), generator=torch.Generator().manual_seed(3))
+    ref64 = None
+    if P >= 448:                                         # see _check_grads: fp64 oracle + the fp32 oracle's own noise
+        import copy
+        o64 = copy.deepcopy(oracle).double()
+        _oracle_reinforce_grads(o64, images.double(), bboxes, start, forced, P, Tn, stop, 0.25, 1.5, 0.01)
+        ref64 = _grads64(o64)
     ro, m = _oracle_reinforce_grads(oracle, images, bboxes, start, forced, P, Tn, stop, 0.25, 1.5, 0.01)
     cfg = _cfg(T=Tn, stop=stop, learning_rate=1e-3, gradient_accumulation=1)
     tr = ja.ReinforceTrainer(cfg, product)
@@ -505,7 +527,7 @@ def test_reinforce_iteration_gradients_vs_oracle(stop, B, P, Tn, grad_slots, arc
     got_m = tr.train_iteration(env, forced_actions=forced, start_positions=start, optimizer_step=False)
     for k in ("action_loss", "entropy_loss", "loss", "returns", "episode_length"):
         assert abs(float(got_m[k]) - float(m[k])) < 2e-4, (k, float(got_m[k]), float(m[k]))
-    checked = _check_grads(product.engine_grads(), oracle, tol=GRAD_TOL, tag=f"reinforce P={P} T={Tn} {arch.get('gpt_backbone', 'nano')}")
+    checked = _check_grads(product.engine_grads(), oracle, tag=f"reinforce P={P} T={Tn} {arch.get('gpt_backbone', 'nano')}", ref64=ref64)
     assert checked > 150
     # running statistics moved Tn times, as in the reference's train-mode rollout
     product.pull_bn_statistics()
@@ -871,14 +893,24 @@ def test_supervised_step_vs_oracle(B, T, P, stop_w):
     nxt[0, 1] = 8                                             # a STOP target exercises the class weight
     masks = torch.ones((B, T), dtype=torch.long)
     masks[1, T - 2:] = 0                                      # padded tail
-    oracle.train()
-    oracle.zero_grad()
-    logits, _ = oracle(patches, cur, torch.zeros(B, dtype=torch.long), positions)
     w = torch.ones(9); w[8] = stop_w
-    ce = torch.nn.functional.cross_entropy(logits.reshape(B * T, 9), nxt.flatten(), weight=w, reduction="none")
     keep = masks.flatten() == 1
-    loss = ce[keep].mean()
-    loss.backward()
+
+    def run_oracle(o, dt):
+        o.train()
+        o.zero_grad()
+        lg, _ = o(patches.to(dt), cur, torch.zeros(B, dtype=torch.long), positions)
+        ce_ = torch.nn.functional.cross_entropy(lg.reshape(B * T, 9), nxt.flatten(), weight=w.to(dt), reduction="none")
+        ls = ce_[keep].mean()
+        ls.backward()
+        return lg, ls
+    ref64 = None
+    if P >= 448:                                         # see _check_grads
+        import copy
+        o64 = copy.deepcopy(oracle).double()
+        run_oracle(o64, torch.float64)
+        ref64 = _grads64(o64)
+    logits, loss = run_oracle(oracle, torch.float32)
     acc = (logits.reshape(B * T, 9).argmax(1)[keep] == nxt.flatten()[keep]).float().mean()
     cfg = ja.CfgNode(stop_enabled=True, stop_weight=stop_w, learning_rate=1e-3, gradient_accumulation=1)
     tr = ja.SupervisedTrainer(cfg, product)
@@ -887,7 +919,7 @@ def test_supervised_step_vs_oracle(B, T, P, stop_w):
     assert abs(float(m["loss"]) - float(loss)) < 2e-4
     assert abs(float(m["action_accuracy"]) - float(acc)) < 1e-6
     assert abs(float(m["episode_length"]) - float(masks.sum(1).float().mean())) < 1e-6
-    n = _check_grads(product.engine_grads(), oracle, skip_prefix=(), tol=GRAD_TOL, tag=f"supervised B={B} T={T} P={P}")
+    n = _check_grads(product.engine_grads(), oracle, skip_prefix=(), tag=f"supervised B={B} T={T} P={P}", ref64=ref64)
     assert n > 150
 
 
@@ -984,7 +1016,7 @@ def test_reinforce_gradients_stop_at_a_detached_detector_encoder():
     got_m = tr.train_iteration(env, forced_actions=forced, start_positions=start, optimizer_step=False)
     assert abs(float(got_m["loss"]) - float(m["loss"])) < 2e-4
     grads = product.engine_grads()
-    n = _check_grads(grads, oracle, tol=GRAD_TOL, tag="reinforce detached")
+    n = _check_grads(grads, oracle, tag="reinforce detached")
     assert n > 30
     for name, g in grads.items():
         if name.startswith("yolox"):
