@@ -176,8 +176,16 @@ def _pick_threads(oracle, P):
     """Thread count for the CPU oracle: a short sweep on the box (fwd + bwd of the patch encoder on 4 patches), because
     an oversubscribed MKL-DNN conv on a small batch is several times slower than the best count."""
     import os
-    ncpu = os.cpu_count() or 1
-    cands = sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu} or {ncpu})
+    # CPUs this process may actually use: the affinity mask and the cgroup quota (a GPU box hands a 1-GPU job a 16-CPU
+    # share of a much larger host; 128 threads on that share ran 10x slower than 16)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            ncpu = max(1, min(ncpu, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    cands = sorted({c for c in (4, 8, 16, 32) if c <= ncpu} | {min(ncpu, 32)})
     x = torch.rand(4, 3, P, P)
     best, best_t = cands[0], float("inf")
     for c in cands:

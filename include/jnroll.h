@@ -208,6 +208,25 @@ typedef struct jn_train_opts {
 int jn_reinforce_step(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev,
                       const int64_t* start_positions_dev, uint64_t seed, int stop_early,
                       const jn_train_opts* opts, const jn_rollout_out* out, float* metrics_dev, void* stream);
+/* Autograd bridge (SURVEY.md 8b "Ownership": in training, rollout's logprobs / entropies carry a graph).  The reference
+ * differentiates a loss built from the rollout dict (src/reinforce.py:326-341: rollout -> compute_metrics ->
+ * (loss / ga).backward()).  jn_reinforce_forward is the train-mode rollout alone (batch-statistics BatchNorm, every
+ * step's activations kept resident); jn_reinforce_backward is the backward of that rollout for GIVEN d loss / d logprobs
+ * and d loss / d entropies ([B, T] f32, either may be NULL = zero): what a torch.autograd.Function around the rollout
+ * receives.  Parameter gradients ACCUMULATE in the gradient arena.  jn_reinforce_backward synchronises once (step count). */
+int jn_reinforce_forward(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, const int64_t* start_positions_dev,
+                         uint64_t seed, int stop_early, const jn_rollout_out* out, void* stream);
+int jn_reinforce_backward(jn_ctx* ctx, const float* dlogprobs_dev, const float* dentropies_dev, void* stream);
+/* The arena keeps tensors in kernel-friendly layouts (transposed Linear weights, tap-major conv weights, ...).  These
+ * convert, ON THE DEVICE, between the arena and a caller-owned buffer of >= arena floats that holds every trainable
+ * tensor in the reference's (PyTorch) layout at the SAME offset as in the arena (jn_arena_segment): the Python module's
+ * param.data / param.grad are views of such buffers, so torch code (clip_grad_value_, an optimizer's state, a
+ * state_dict) sees real tensors.  what = 0 parameters, 1 gradients.  export: arena -> buffer (accumulate != 0: +=);
+ * import: buffer -> arena. */
+int jn_arena_segment(jn_ctx* ctx, const char* name, size_t* off, size_t* numel);
+int jn_export_arena(jn_ctx* ctx, int what, float* dst_dev, size_t numel, int accumulate, void* stream);
+int jn_import_arena(jn_ctx* ctx, int what, const float* src_dev, size_t numel, void* stream);
+
 /* One supervised (teacher-forced) step minus the optimiser: SupervisedTrainer.run body
  * (src/supervised.py:863-902) with the detector term off.  patches [B,T,3,P,P], current_actions /
  * next_actions [B,T] int64, positions [B,T,2] int64, masks [B,T] u8 (1 = token, 0 = padding); B*T <=

@@ -103,6 +103,12 @@ SIGNATURES = {
     "jn_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "jn_detector_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "jn_optimizer_step_group": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "jn_reinforce_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,
+                                       C.POINTER(JnRolloutOut), C.c_void_p]),
+    "jn_reinforce_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jn_arena_segment": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "jn_export_arena": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "jn_import_arena": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 

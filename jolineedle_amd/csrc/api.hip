@@ -703,6 +703,9 @@ static int ensure_defer_tables(jn_ctx* ctx, Net& net) {
       (rc = up(&net.fd_hw, fd_hw)) || (rc = up(&net.fd_goff, fd_g)) || (rc = up(&net.fd_boff, fd_b)) || (rc = up(&net.fd_t0, fd_t0)) ||
       (rc = up(&net.fd_t1, fd_t1)) || (rc = up(&net.fd_rm, fd_rm)) || (rc = up(&net.fd_rv, fd_rv)))
     return rc;
+  net.h_td_hw.assign(TC, 0.0f);
+  for (int tc = 0; tc < TC; ++tc) if (td_src[tc] >= 0) net.h_td_hw[tc] = td_hw[tc];
+  net.h_td_src = td_src; net.h_td_goff = td_g; net.h_td_boff = td_b;
   net.defer_ok = true;
   return JN_OK;
 }
@@ -729,10 +732,34 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
   auto ptr = [&](const View& v) { return view_ptr(net, slot, MB, v); };
   auto tab = [&](const View& v) {
     ChanTab t = view_tab(net, slot, v);
+    bool any = false;                       // does the view hold a channel whose table is deferred in this pass?
     if (defer) {
+      const int off = net.tab_off[v.buf] + v.coff;
+      for (int c = 0; c < v.C && !any; ++c) any = net.h_td_hw[off + c] > 0.0f && (double)N * net.h_td_hw[off + c] <= (double)JN_DEFER_MAX_M;
+    }
+    if (any) {
       const int off = net.tab_off[v.buf] + v.coff;
       t.dsrc = net.td_src + off; t.dhw = net.td_hw + off; t.dgoff = net.td_goff + off; t.dboff = net.td_boff + off;
       t.dparams = ctx->params; t.dstats = stats; t.drep_stride = rep_stride; t.dN = N;
+      // channel runs for the kernel arguments (at most four: a concat of a few producers); more: the arrays above
+      int ns = 0;
+      bool fits = true;
+      for (int c = 0; c < v.C && fits;) {
+        const int tc = off + c;
+        const bool d = net.h_td_hw[tc] > 0.0f && (double)N * net.h_td_hw[tc] <= (double)JN_DEFER_MAX_M;
+        int e = c + 1;
+        if (d) {
+          while (e < v.C && net.h_td_src[off + e] == net.h_td_src[tc] + (e - c) && net.h_td_goff[off + e] == net.h_td_goff[tc] + (e - c) &&
+                 net.h_td_boff[off + e] == net.h_td_boff[tc] + (e - c) && net.h_td_hw[off + e] == net.h_td_hw[tc])
+            ++e;
+        } else {
+          while (e < v.C && !(net.h_td_hw[off + e] > 0.0f && (double)N * net.h_td_hw[off + e] <= (double)JN_DEFER_MAX_M)) ++e;
+        }
+        if (ns == 4) { fits = false; break; }
+        t.seg[ns++] = ChanTab::Run{c, e, d ? net.h_td_src[tc] : -1, net.h_td_goff[tc], net.h_td_boff[tc], net.h_td_hw[tc]};
+        c = e;
+      }
+      t.nseg = fits ? ns : 0;
     }
     return t;
   };
@@ -1778,11 +1805,9 @@ static int build_grad_layer_table(jn_ctx* ctx) {
   return JN_OK;
 }
 
-int jn_reinforce_step(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, const int64_t* start_positions_dev,
-                      uint64_t seed, int stop_early, const jn_train_opts* opts, const jn_rollout_out* out,
-                      float* metrics_dev, void* stream) {
-  JN_CHECK(ctx && opts && out && metrics_dev, JN_EINVAL, "jn_reinforce_step: null argument");
-  JN_CHECK(opts->struct_size == (int)sizeof(jn_train_opts), JN_EINVAL, "jn_train_opts.struct_size mismatch");
+}  // extern "C"
+static int reinforce_backward_impl(jn_ctx* ctx, const jn_rollout_out* out, int S, int stop_early, hipStream_t s);
+static int check_train_outputs(jn_ctx* ctx, const jn_rollout_out* out) {
   JN_CHECK(out->logits_dev && out->actions_dev && out->returns_dev && out->logit_masks_dev && out->positions_dev &&
                out->final_emb_dev && out->rewards_dev && out->masks_dev,
            JN_EINVAL, "training needs logits/actions/returns/logit_masks/positions/final_emb/rewards/masks outputs");
@@ -1790,13 +1815,49 @@ int jn_reinforce_step(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, 
   JN_CHECK(ctx->cfg.block_size <= 62, JN_EINVAL, "training supports block_size <= 62");
   // batch-statistics BatchNorm on bf16-rounded pre-activations is ill-conditioned
   JN_CHECK(ctx->cfg.act_dtype == JN_F32, JN_ESTATE, "training needs act_dtype = fp32 (bf16 is the inference mode)");
+  return JN_OK;
+}
+extern "C" {
+
+// Autograd bridge (SURVEY.md §8b "jn_rollout_backward"): the train-mode rollout alone ...
+int jn_reinforce_forward(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, const int64_t* start_positions_dev,
+                         uint64_t seed, int stop_early, const jn_rollout_out* out, void* stream) {
+  JN_CHECK(ctx && out, JN_EINVAL, "jn_reinforce_forward: null argument");
+  int rc = check_train_outputs(ctx, out);
+  if (rc) return rc;
+  if ((rc = rollout_impl(ctx, mode, forced_actions_dev, start_positions_dev, seed, 0, stop_early, out, 1, stream))) return rc;
+  ctx->train_out = *out; ctx->train_out_valid = true;
+  return JN_OK;
+}
+
+// ... and its backward for GIVEN upstream gradients of the rollout's logprobs / entropies [B, T] (what torch autograd
+// hands to the rollout node when the caller differentiates any loss built from them, src/reinforce.py:217-265, 341).
+int jn_reinforce_backward(jn_ctx* ctx, const float* dlogprobs_dev, const float* dentropies_dev, void* stream) {
+  JN_CHECK(ctx && (dlogprobs_dev || dentropies_dev), JN_EINVAL, "jn_reinforce_backward: null argument");
+  JN_CHECK(ctx->train_out_valid, JN_ESTATE, "jn_reinforce_backward needs a preceding jn_reinforce_forward / jn_reinforce_step");
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  const jn_rollout_out* out = &ctx->train_out;
+  const EnvState& e = ctx->env;
+  int S = 0, rc;
+  if ((rc = jn_rollout_steps(ctx, &S, stream))) return rc;
+  launch_logits_grad(out->logits_dev, out->actions_dev, dlogprobs_dev, dentropies_dev, ctx->n_done, ctx->dlogits, e.B, e.T,
+                     ctx->cfg.n_actions, ctx->last_stop_early ? 1 : 0, s);
+  return reinforce_backward_impl(ctx, out, S, ctx->last_stop_early ? 1 : 0, s);
+}
+
+int jn_reinforce_step(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, const int64_t* start_positions_dev,
+                      uint64_t seed, int stop_early, const jn_train_opts* opts, const jn_rollout_out* out,
+                      float* metrics_dev, void* stream) {
+  JN_CHECK(ctx && opts && out && metrics_dev, JN_EINVAL, "jn_reinforce_step: null argument");
+  JN_CHECK(opts->struct_size == (int)sizeof(jn_train_opts), JN_EINVAL, "jn_train_opts.struct_size mismatch");
+  { int rc0 = check_train_outputs(ctx, out); if (rc0) return rc0; }
   hipStream_t s = (hipStream_t)stream;
   int rc = rollout_impl(ctx, mode, forced_actions_dev, start_positions_dev, seed, 0, stop_early, out, 1, stream);
   if (rc) return rc;
-  if ((rc = build_grad_layer_table(ctx))) return rc;
-  const jn_config& c = ctx->cfg;
+  ctx->train_out = *out; ctx->train_out_valid = true;
   const EnvState& e = ctx->env;
-  const int B = e.B, T = e.T, C = c.n_embd, nA = c.n_actions, P = c.patch_size;
+  const int B = e.B, T = e.T, nA = ctx->cfg.n_actions;
   int S = 0;
   if ((rc = jn_rollout_steps(ctx, &S, stream))) return rc;      // the one host sync of the iteration
 
@@ -1807,7 +1868,17 @@ int jn_reinforce_step(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev, 
   la.ret_mean = opts->ret_mean; la.ret_std = opts->ret_std; la.entropy_weight = opts->entropy_weight;
   la.scale = opts->loss_scale;
   launch_reinforce_loss(la, s);
+  return reinforce_backward_impl(ctx, out, S, stop_early, s);
+}
 
+// loss.backward() of a train-mode rollout given d loss / d logits in ctx->dlogits: causal GPT over the trajectory
+// (teacher-forced recompute), embed_fpn, then the patch encoder of all S executed glimpse steps, step-batched.
+static int reinforce_backward_impl(jn_ctx* ctx, const jn_rollout_out* out, int S, int stop_early, hipStream_t s) {
+  int rc;
+  if ((rc = build_grad_layer_table(ctx))) return rc;
+  const jn_config& c = ctx->cfg;
+  const EnvState& e = ctx->env;
+  const int B = e.B, T = e.T, C = c.n_embd, nA = c.n_actions, P = c.patch_size;
   const int L = T + 1, nL = c.n_layer, nh = c.n_head;
   const long long per_agent = (long long)(nL + 1) * L * C + (long long)nL * (11LL * L * C + (long long)nh * L * L) +
                               12LL * L * C + (long long)nh * L * L + 4LL * C + 64;
@@ -2026,6 +2097,56 @@ int jn_optimizer_step_group(jn_ctx* ctx, int group, float lr, float weight_decay
   for (int ni = 0; ni < 2; ++ni) if (ctx->has_net[ni]) ctx->nets[ni].eval_tab_dirty = true;   // BN affine moved
   JN_HIP(hipGetLastError());
   return JN_OK;
+}
+
+// ---- arena <-> reference layout on the device (autograd bridge: param.data / param.grad of the Python module are
+// views of ONE reference-layout buffer whose segment offsets equal the arena's) ---------------------------------------
+static int ensure_segs_dev(jn_ctx* ctx) {
+  if (ctx->segs_dev && ctx->segs_dev_n == (int)ctx->segs.size()) return JN_OK;
+  std::vector<ArenaSeg> h(ctx->segs.size());
+  for (size_t i = 0; i < h.size(); ++i) {
+    const ParamSeg& g = ctx->segs[i];
+    h[i] = ArenaSeg{(long long)g.off, (long long)g.numel, g.kind, g.d0, g.d1, g.d2};
+  }
+  ArenaSeg* d = nullptr;
+  int rc = dev_alloc(ctx, &d, h.size());
+  if (rc) return rc;
+  JN_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(ArenaSeg), hipMemcpyHostToDevice));
+  ctx->segs_dev = d; ctx->segs_dev_n = (int)h.size();
+  return JN_OK;
+}
+
+int jn_arena_segment(jn_ctx* ctx, const char* name, size_t* off, size_t* numel) {
+  JN_CHECK(ctx && name && ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
+  auto it = ctx->seg_index.find(name);
+  JN_CHECK(it != ctx->seg_index.end(), JN_ENOTFOUND, "jn_arena_segment: '%s' is not a trainable tensor", name);
+  if (off) *off = ctx->segs[it->second].off;
+  if (numel) *numel = ctx->segs[it->second].numel;
+  return JN_OK;
+}
+
+static int arena_copy(jn_ctx* ctx, int what, float* ref_dev, size_t numel, int to_ref, int accumulate, void* stream) {
+  JN_CHECK(ctx && ref_dev && ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
+  JN_CHECK(what == 0 || what == 1, JN_EINVAL, "what: 0 = parameters, 1 = gradients");
+  JN_CHECK(numel >= ctx->arena_used, JN_EINVAL, "reference-layout buffer needs %zu floats, got %zu", ctx->arena_used, numel);
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  int rc;
+  if (what == 1 && (rc = ensure_train_state(ctx))) return rc;
+  if ((rc = ensure_segs_dev(ctx))) return rc;
+  launch_arena_copy(ctx->segs_dev, ctx->segs_dev_n, what == 0 ? ctx->params : ctx->grads, ref_dev, (long long)ctx->arena_used,
+                    to_ref, accumulate, (hipStream_t)stream);
+  JN_HIP(hipGetLastError());
+  if (!to_ref && what == 0)
+    for (int ni = 0; ni < 2; ++ni) if (ctx->has_net[ni]) ctx->nets[ni].eval_tab_dirty = true;   // BN affine may have moved
+  return JN_OK;
+}
+
+int jn_export_arena(jn_ctx* ctx, int what, float* dst_dev, size_t numel, int accumulate, void* stream) {
+  return arena_copy(ctx, what, dst_dev, numel, 1, accumulate, stream);
+}
+
+int jn_import_arena(jn_ctx* ctx, int what, const float* src_dev, size_t numel, void* stream) {
+  return arena_copy(ctx, what, const_cast<float*>(src_dev), numel, 0, 0, stream);
 }
 
 int jn_read_param(jn_ctx* ctx, const char* name, float* host_out, size_t numel) {

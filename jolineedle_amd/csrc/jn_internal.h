@@ -124,6 +124,8 @@ struct Net {
   int *td_src = nullptr, *td_goff = nullptr, *td_boff = nullptr; float* td_hw = nullptr;      // [tab_channels]
   float* fd_hw = nullptr; int *fd_goff = nullptr, *fd_boff = nullptr, *fd_t0 = nullptr, *fd_t1 = nullptr;   // [stat_channels]
   float **fd_rm = nullptr, **fd_rv = nullptr;
+  std::vector<float> h_td_hw;     // host copies of the per-table-channel descriptors (td_hw: 0 where td_src < 0)
+  std::vector<int> h_td_src, h_td_goff, h_td_boff;
 };
 
 struct ParamEntry {
@@ -224,6 +226,9 @@ struct jn_ctx {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool profiling = false;
   bool bwd_timed = false;         // ev[2] / ev[3] bracket a conv-stack backward
+  jn_rollout_out train_out{};     // output buffers of the most recent train-mode rollout (jn_reinforce_backward reads them)
+  bool train_out_valid = false;
+  jnr::ArenaSeg* segs_dev = nullptr; int segs_dev_n = 0;   // device copy of `segs` for the layout-conversion kernel
   std::vector<hipEvent_t> conv_ev;   // pairs per step when profiling
   int conv_ev_used = 0;
 };

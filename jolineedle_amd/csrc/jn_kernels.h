@@ -35,6 +35,12 @@ struct ChanTab {
   const double* dstats;    // [JN_NREP_DEFER used][drep_stride] batch sums of the workspace slot
   long long drep_stride;
   int dN;                  // patches in this pass
+  // The same information as up to four channel runs in the kernel arguments (scalar registers, no memory round trip
+  // before the sums can be requested): channels [c0, c1) of the view are BatchNorm channels stat0 + (c - c0) with affine
+  // at g0 / b0 + (c - c0) and pixel count dN * hw — or, with stat0 < 0, plain table entries.  nseg == 0: use the arrays.
+  struct Run { int c0, c1, stat0, g0, b0; float hw; };
+  int nseg;
+  Run seg[4];
 };
 constexpr long long JN_DEFER_MAX_M = 65536;   // output pixels (N * H * W) up to which a layer's table is deferred
 constexpr int JN_NREP_DEFER = 8;              // statistics replicas such a layer accumulates into (its consumers sum them)
@@ -295,6 +301,14 @@ struct LossArgs {
   float ret_mean, ret_std, entropy_weight, scale;
 };
 int launch_reinforce_loss(const LossArgs& a, hipStream_t s);
+// autograd bridge: d loss / d logits [B][T][nA] from d loss / d logprobs and d loss / d entropies [B][T] (either may be null)
+int launch_logits_grad(const float* logits, const int64_t* actions, const float* dlogprobs, const float* dentropies,
+                       const int32_t* n_done, float* dlogits, int B, int T, int nA, int stop_early, hipStream_t s);
+// one trainable tensor of the flat arena: packing kind (api.hip PackKind) and dimensions; `off` is its offset both in the
+// packed arena and in a reference-layout buffer of the same size
+struct ArenaSeg { long long off, numel; int kind, d0, d1, d2; };
+int launch_arena_copy(const ArenaSeg* segs, int n_segs, float* arena, float* ref, long long total, int to_ref, int accumulate,
+                      hipStream_t s);
 
 struct GptBwdArgs {
   int C, n_head, n_layer, nA, B, T, stop_early;

@@ -40,20 +40,37 @@ __device__ __forceinline__ void bn_from_sums(const double* __restrict__ st, long
   mean_f = (float)mean; invstd_f = invstd; var_out = var;
 }
 
-// is channel c of the view a deferred entry in this launch?
-__device__ __forceinline__ bool tab_deferred(const ChanTab& t, int c) {
-  return t.dsrc && t.dsrc[c] >= 0 && (long long)t.dN * (long long)t.dhw[c] <= JN_DEFER_MAX_M;
-}
-
+// Entry of channel c of the view.  With deferred fields present, the four descriptor values are fetched together (one
+// round trip), then either the table entry or the batch sums + BatchNorm affine (a second one).
 __device__ __forceinline__ void tab_entry(const ChanTab& t, int c, float& sc, float& sh, float& fl) {
-  if (tab_deferred(t, c)) {
-    float m, is; double var;
-    bn_from_sums(t.dstats, t.drep_stride, JN_NREP_DEFER, t.dsrc[c], (double)t.dN * (double)t.dhw[c], t.dparams[t.dgoff[c]],
-                 t.dparams[t.dboff[c]], 1e-3f, sc, sh, m, is, var);
-    fl = 1.0f;
-  } else {
+  if (t.nseg > 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < t.nseg && c >= t.seg[i].c0 && c < t.seg[i].c1 && t.seg[i].stat0 >= 0) {
+        const int d = c - t.seg[i].c0;
+        const float gamma = t.dparams[t.seg[i].g0 + d], beta = t.dparams[t.seg[i].b0 + d];
+        float m, is; double var;
+        bn_from_sums(t.dstats, t.drep_stride, JN_NREP_DEFER, t.seg[i].stat0 + d, (double)t.dN * (double)t.seg[i].hw, gamma, beta,
+                     1e-3f, sc, sh, m, is, var);
+        fl = 1.0f;
+        return;
+      }
+    }
     sc = t.sc[c]; sh = t.sh[c]; fl = t.fl[c];
+    return;
   }
+  if (t.dsrc) {
+    const int src = t.dsrc[c], go = t.dgoff[c], bo = t.dboff[c];
+    const float hw = t.dhw[c];
+    if (src >= 0 && (long long)t.dN * (long long)hw <= JN_DEFER_MAX_M) {
+      const float gamma = t.dparams[go], beta = t.dparams[bo];
+      float m, is; double var;
+      bn_from_sums(t.dstats, t.drep_stride, JN_NREP_DEFER, src, (double)t.dN * (double)hw, gamma, beta, 1e-3f, sc, sh, m, is, var);
+      fl = 1.0f;
+      return;
+    }
+  }
+  sc = t.sc[c]; sh = t.sh[c]; fl = t.fl[c];
 }
 
 // (scale, shift, flag) of channels [0, K) of the view -> Tb[3][K4] in LDS (entries K .. K4 are the identity).  The caller

@@ -277,6 +277,11 @@ __global__ __launch_bounds__(256) void dw3x3_lds_kernel(
   const int c = cb * CB + 4 * q;
   const int oy0 = ty * DW_TH, ox0 = tx * DW_TW;
   const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+  // the taps are requested first, with the tile: fetched after the staging they were one more global round trip on every
+  // workgroup's critical path
+  f32x4 wv[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(w + t * C + c);
   {
     const AT* inb = in + (long long)n * H * W * in_ld + c;
     // all loads of the tile are issued back to back into registers, then transformed and stored (a load -> transform ->
@@ -318,9 +323,6 @@ __global__ __launch_bounds__(256) void dw3x3_lds_kernel(
       }
     }
   }
-  f32x4 wv[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(w + t * C + c);
   __syncthreads();
   const int x = (tid / Q) % DW_TW, grp = tid / (Q * DW_TW);
   const int j0 = grp * RPG;                           // first output row (within the tile) of this thread

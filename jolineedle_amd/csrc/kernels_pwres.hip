@@ -76,28 +76,51 @@ __global__ __launch_bounds__(256) void pw_res_kernel(
     if (u < n_it) fetch(xr[u]);
 
   // ---- prologue: table and weight slice -> LDS ----
-  tab_to_lds(Tb, K, K, it, tid, 256);
-  if (WT) {
-    // w is [K][w_ld] (the forward weight of the differentiated layer): Ws[n][k] = w[k][n0 + n]
-    const int NQ = 4 * CT;                                        // float4 columns of the slice
-    for (int i = tid; i < K * NQ; i += 256) {
-      const int k = i / NQ, nq = i - k * NQ;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (n0 + 4 * nq < Nc) v = *reinterpret_cast<const f32x4*>(w + (long long)k * w_ld + n0 + 4 * nq);
+  // The slice is fetched in batches of WB float4 per thread, all loads of a batch in flight before the first LDS store (a
+  // plain load -> store loop with a run-time trip count waits one global round trip per iteration: 16 of them for a
+  // 128 x 128 slice); the table (deferred entries: batch sums) is derived while the first batch is in flight.
+  {
+    constexpr int WB = 8;
+    const int NQ = 4 * CT, KQ = K / 4;
+    const int total = WT ? K * NQ : 16 * CT * KQ;
+    f32x4 wr[WB];
+    auto wload = [&](int base) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) Ws[(4 * nq + e) * LDW + k] = v[e];
-    }
-  } else {
-    const int KQ = K / 4;
-    for (int i = tid; i < 16 * CT * KQ; i += 256) {
-      const int r = i / KQ, kq = i - r * KQ;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (n0 + r < Nc) v = *reinterpret_cast<const f32x4*>(w + (long long)(n0 + r) * w_ld + 4 * kq);
-      *reinterpret_cast<f32x4*>(Ws + r * LDW + 4 * kq) = v;
-    }
+      for (int j = 0; j < WB; ++j) {
+        const int i = base + tid + 256 * j;
+        wr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < total) {
+          if (WT) {           // w is [K][w_ld] (the forward weight of the differentiated layer): Ws[n][k] = w[k][n0 + n]
+            const int k = i / NQ, nq = i - k * NQ;
+            if (n0 + 4 * nq < Nc) wr[j] = *reinterpret_cast<const f32x4*>(w + (long long)k * w_ld + n0 + 4 * nq);
+          } else {
+            const int r = i / KQ, kq = i - r * KQ;
+            if (n0 + r < Nc) wr[j] = *reinterpret_cast<const f32x4*>(w + (long long)(n0 + r) * w_ld + 4 * kq);
+          }
+        }
+      }
+    };
+    auto wstore = [&](int base) {
+#pragma unroll
+      for (int j = 0; j < WB; ++j) {
+        const int i = base + tid + 256 * j;
+        if (i < total) {
+          if (WT) {
+            const int k = i / NQ, nq = i - k * NQ;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Ws[(4 * nq + e) * LDW + k] = wr[j][e];
+          } else {
+            const int r = i / KQ, kq = i - r * KQ;
+            *reinterpret_cast<f32x4*>(Ws + r * LDW + 4 * kq) = wr[j];
+          }
+        }
+      }
+    };
+    wload(0);
+    tab_to_lds(Tb, K, K, it, tid, 256);
+    wstore(0);
+    for (int base = 256 * WB; base < total; base += 256 * WB) { wload(base); wstore(base); }
   }
-  // (the first __syncthreads of the loop below makes Tb / Ws visible before any wave reads them ... the staging of
-  // chunk 0 reads Tb, so one barrier here)
   __syncthreads();
 
   f32x4 acc[PT][CTW];

@@ -88,6 +88,88 @@ int launch_reinforce_loss(const LossArgs& a, hipStream_t s) {
   return 0;
 }
 
+// ---- autograd bridge: d loss / d logits from the upstream gradients of the rollout's log-probs and entropies --------
+// logp = log_softmax(logits), lp = logp[action], H = -sum p logp  (src/reinforce.py:73-90):
+//   d lp / d logits_j = [j == action] - p_j          d H / d logits_j = -p_j (logp_j + H)
+// Steps the rollout did not execute (t >= S) get zero rows.
+__global__ __launch_bounds__(TB) void logits_grad_kernel(const float* __restrict__ logits, const long long* __restrict__ actions,
+                                                         const float* __restrict__ dlogprobs, const float* __restrict__ dentropies,
+                                                         const int* __restrict__ n_done, float* __restrict__ dlogits, int B,
+                                                         int T, int nA, int stop_early) {
+  int S = T;
+  if (stop_early)
+    for (int t = 1; t <= T; ++t)
+      if (n_done[t] >= B) { S = t; break; }
+  const int i = blockIdx.x * TB + threadIdx.x;
+  if (i >= B * T) return;
+  const int t = i % T;
+  float* dl = dlogits + (long long)i * nA;
+  const float glp = dlogprobs ? dlogprobs[i] : 0.0f, gh = dentropies ? dentropies[i] : 0.0f;
+  if (t >= S || (glp == 0.0f && gh == 0.0f)) { for (int j = 0; j < nA; ++j) dl[j] = 0.0f; return; }
+  const float* lg = logits + (long long)i * nA;
+  float mx = -INFINITY;
+  for (int j = 0; j < nA; ++j) mx = fmaxf(mx, lg[j]);
+  float se = 0.0f;
+  for (int j = 0; j < nA; ++j) se += expf(lg[j] - mx);
+  const float lse = mx + logf(se);
+  float H = 0.0f;
+  for (int j = 0; j < nA; ++j) { const float lp = lg[j] - lse; H -= lp * expf(lp); }
+  const int act = (int)actions[i];
+  for (int j = 0; j < nA; ++j) {
+    const float lp = lg[j] - lse, pj = expf(lp);
+    dl[j] = glp * ((j == act ? 1.0f : 0.0f) - pj) - gh * pj * (lp + H);
+  }
+}
+
+int launch_logits_grad(const float* logits, const int64_t* actions, const float* dlogprobs, const float* dentropies,
+                       const int32_t* n_done, float* dlogits, int B, int T, int nA, int stop_early, hipStream_t s) {
+  hipLaunchKernelGGL(logits_grad_kernel, dim3((B * T + TB - 1) / TB), dim3(TB), 0, s, logits, (const long long*)actions, dlogprobs,
+                     dentropies, n_done, dlogits, B, T, nA, stop_early);
+  return 0;
+}
+
+// ---- packed arena <-> reference (PyTorch) layout, on the device --------------------------------------------------
+// One thread per element of the reference-layout buffer (same segment offsets as the arena): finds its segment by
+// bisection and maps the index by the segment's packing (api.hip: PackKind / unpack_param).
+__device__ __forceinline__ long long packed_index(const ArenaSeg& g, long long r) {
+  switch (g.kind) {
+    case 1: { const long long o = r / g.d1, i = r - o * g.d1; return i * g.d0 + o; }                       // PK_T [out][in] -> [in][out]
+    case 2: {                                                                                               // PK_STEM
+      const int kx = (int)(r % 3), ky = (int)((r / 3) % 3), ic = (int)((r / 9) % 12), oc = (int)(r / 108);
+      const int q = ic / 3, c = ic - 3 * q, py = q & 1, px = q >> 1;
+      return (long long)((c * 6 + 2 * ky + py) * 6 + 2 * kx + px) * g.d0 + oc;
+    }
+    case 3: { const long long c = r / 9, k = r - c * 9; return k * g.d0 + c; }                              // PK_DW [c][tap] -> [tap][c]
+    case 4: { const long long tp = r % 9, k = (r / 9) % g.d1, o = r / (9LL * g.d1); return (tp * g.d0 + o) * g.d1 + k; }   // PK_CONV3
+    case 5: {                                                                                               // PK_EFPN_LIN
+      const long long per_o = (long long)g.d1 * g.d2, o = r / per_o, rem = r - o * per_o, ch = rem / g.d1, q = rem - ch * g.d1;
+      return (q * g.d2 + ch) * g.d0 + o;
+    }
+    default: return r;
+  }
+}
+
+__global__ __launch_bounds__(256) void arena_copy_kernel(const ArenaSeg* __restrict__ segs, int n_segs, float* __restrict__ arena,
+                                                         float* __restrict__ ref, long long total, int to_ref, int accumulate) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  int lo = 0, hi = n_segs - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (segs[mid].off <= i) lo = mid; else hi = mid - 1; }
+  const ArenaSeg g = segs[lo];
+  const long long r = i - g.off;
+  if (r >= g.numel) return;                              // padding between segments
+  const long long pi = g.off + packed_index(g, r);
+  if (to_ref) ref[i] = accumulate ? ref[i] + arena[pi] : arena[pi];
+  else arena[pi] = ref[i];
+}
+
+int launch_arena_copy(const ArenaSeg* segs, int n_segs, float* arena, float* ref, long long total, int to_ref, int accumulate,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(arena_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, segs, n_segs, arena, ref, total,
+                     to_ref, accumulate);
+  return 0;
+}
+
 // ---- supervised loss (src/supervised.py:138-177): CrossEntropyLoss(weight, reduction="none") averaged over
 // the non-padding tokens; dlogits = w[y] * (softmax - onehot) / n_valid --------------------------------
 __global__ __launch_bounds__(TB) void ce_loss_kernel(const float* __restrict__ logits, const long long* __restrict__ target,

@@ -78,8 +78,15 @@ class GPT(nn.Module):
                                                  self._engine.cfg.n_embd)
         self._build_parameters()
         self._uploaded_version = None
+        self._engine_grads = None          # packed gradient arena (torch-owned: ONE RCCL all-reduce per optimiser step)
+        self._flat_params = self._flat_grads = None   # reference-layout mirrors behind param.data / param.grad (bind_flat)
+        self._rollout_gen = 0
         if self._engine.cfg.with_detector:
             object.__setattr__(self, "_yolox_view", NeedleYOLOX(self, config.detector_conf_threshold))
+        # Deviation from nn.Module's default: the model starts in eval mode (BatchNorm running statistics), the mode
+        # every compute entry point but the training step uses; the reference's loops call model.train() / .eval()
+        # themselves (src/reinforce.py:304, 366-370) and get the same modes here.
+        self.eval()
 
     # ---- parameters under the reference's names -------------------------------------
     def _build_parameters(self):
@@ -255,11 +262,69 @@ class GPT(nn.Module):
             out[name] = host
         return out
 
+    # ---- gradient arena and the reference-layout mirrors (autograd bridge) ------------------------------
+    def grad_arena(self):
+        """The engine's flat PACKED gradient arena as a torch tensor, owned by this model (one per engine, shared by every
+        trainer): torch-owned so that RCCL all-reduces it in ONE call per optimiser step."""
+        if self._engine_grads is None:
+            import ctypes as C
+            self.sync_weights()
+            eng = self._engine
+            tot, gpt = C.c_size_t(), C.c_size_t()
+            check(eng.lib.jn_arena_info(eng.handle, C.byref(tot), C.byref(gpt)), "jn_arena_info")
+            self._arena_numel, self._optim_gpt_numel = tot.value, gpt.value
+            self._engine_grads = torch.zeros(tot.value, device=self.device, dtype=torch.float32)
+            check(eng.lib.jn_set_grad_arena(eng.handle, ptr(self._engine_grads), tot.value), "jn_set_grad_arena")
+        return self._engine_grads
+
+    def bind_flat(self):
+        """Make every trainable parameter a view of ONE device buffer in the reference's layout, with ``param.grad`` a view of
+        a second one (same offsets as the engine's arena, jn_arena_segment).  After this, torch code sees real tensors:
+        ``clip_grad_value_(model.parameters(), 1)`` clamps the gradients the engine optimiser will use, ``state_dict()`` is
+        current after every ``optimizer.step()``.  Idempotent."""
+        if self._flat_params is not None:
+            return
+        import ctypes as C
+        self.grad_arena()
+        eng, stream = self._engine, _lib.current_stream(self.device)
+        n = self._arena_numel
+        self._flat_params = torch.zeros(n, device=self.device, dtype=torch.float32)
+        self._flat_grads = torch.zeros(n, device=self.device, dtype=torch.float32)
+        check(eng.lib.jn_export_arena(eng.handle, 0, ptr(self._flat_params), n, 0, stream), "jn_export_arena")
+        self._flat_names = []
+        for name, p in self.named_parameters():
+            off, num = C.c_size_t(), C.c_size_t()
+            if eng.lib.jn_arena_segment(eng.handle, name.encode(), C.byref(off), C.byref(num)) != 0:
+                continue                                  # not trainable in this configuration (e.g. wpe with sinusoid positions)
+            assert num.value == p.numel(), name
+            p.data = self._flat_params[off.value:off.value + num.value].view(p.shape)
+            p.grad = self._flat_grads[off.value:off.value + num.value].view(p.shape)
+            self._flat_names.append(name)
+        self._uploaded_version = self._weights_version()
+
+    def refresh_flat_params(self):
+        """After an optimiser step taken inside the engine (``train_iteration``): bring ``param.data`` of a bound model up to
+        date.  No-op for an unbound model (its parameters are pulled on demand, ``pull_parameters``)."""
+        if self._flat_params is None:
+            return
+        eng, stream = self._engine, _lib.current_stream(self.device)
+        check(eng.lib.jn_export_arena(eng.handle, 0, ptr(self._flat_params), self._arena_numel, 0, stream), "jn_export_arena")
+        self._uploaded_version = self._weights_version()
+
+    def publish_engine_grads(self):
+        """param.grad += the engine's (packed) gradient arena, then clear the arena: called after every engine backward
+        when the model is bound (bind_flat), so that ``.grad`` accumulates like torch's."""
+        eng, stream = self._engine, _lib.current_stream(self.device)
+        check(eng.lib.jn_export_arena(eng.handle, 1, ptr(self._flat_grads), self._arena_numel, 1, stream), "jn_export_arena")
+        self._engine_grads.zero_()
+
     def configure_optimizers(self, train_config):
-        """gpt.py:547-562: everything not under ``yolox`` vs the detector."""
-        optim_gpt = torch.optim.AdamW(
-            params=[p for pn, p in self.named_parameters() if not pn.startswith("yolox")],
-            lr=train_config.learning_rate)
+        """gpt.py:547-562: everything not under ``yolox`` vs the detector — as ``torch.optim.Optimizer`` objects whose
+        ``step()`` / ``zero_grad()`` drive the engine's AdamW on ``param.grad`` (EngineAdamW)."""
+        from .optim import EngineAdamW
+        gpt_params = [p for pn, p in self.named_parameters() if not pn.startswith("yolox")]
+        optim_gpt = EngineAdamW(self, 0, gpt_params, lr=train_config.learning_rate)
         yolo_params = [p for pn, p in self.named_parameters() if pn.startswith("yolox")]
-        optim_yolox = torch.optim.AdamW(params=yolo_params, lr=train_config.yolo_lr) if yolo_params else None
+        optim_yolox = EngineAdamW(self, 1, yolo_params, lr=getattr(train_config, "yolo_lr", train_config.learning_rate)) \
+            if yolo_params else None
         return optim_gpt, optim_yolox

@@ -11,6 +11,29 @@ from ._lib import JnRolloutOut, JnTrainOpts, check, ptr
 from .env import NeedleGeneralEnv
 
 
+class _RolloutGraph(torch.autograd.Function):
+    """Graph node behind ``rollout()["logprobs"]`` / ``["entropies"]`` of a train-mode rollout ("carry
+    autograd graph in training").  backward = ``jn_reinforce_backward`` with the upstream gradients torch hands over, then
+    the engine's packed gradients are added to ``param.grad`` (reference layout)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, gen, logprobs, entropies):
+        ctx.model, ctx.gen = model, gen
+        return logprobs.view_as(logprobs), entropies.view_as(entropies)
+
+    @staticmethod
+    def backward(ctx, dlp, dent):
+        model = ctx.model
+        if ctx.gen != model._rollout_gen:
+            raise RuntimeError("backward through a rollout whose activations were overwritten by a later train-mode rollout")
+        eng, dev = model.engine(), model.device
+        dlp = None if dlp is None else dlp.to(dev, torch.float32).contiguous()
+        dent = None if dent is None else dent.to(dev, torch.float32).contiguous()
+        check(eng.lib.jn_reinforce_backward(eng.handle, ptr(dlp), ptr(dent), _lib.current_stream(dev)), "jn_reinforce_backward")
+        model.publish_engine_grads()
+        return None, None, None, None, None
+
+
 class ReinforceTrainer:
     """Rollout / loss part of the reference trainer (dataset, Visdom, checkpoints are
     out of scope).  ``config`` needs max_seq_len, entropy_weight,
@@ -90,8 +113,20 @@ class ReinforceTrainer:
         self._rollouts += 1
         seed = (self.seed * 1000003 + self._rollouts) & 0xFFFFFFFFFFFFFFFF
         stream = _lib.current_stream(dev)
-        check(eng.lib.jn_rollout(eng.handle, mode, ptr(forced_actions), ptr(start_positions), seed,
-                                 int(do_detection), int(stop_early), C.byref(out), stream), "jn_rollout")
+        # model.train() + grad mode (the reference's training loop, src/reinforce.py:304, 326): batch-statistics BatchNorm,
+        # activations of every step kept resident, logprobs / entropies leave with a graph (autograd bridge)
+        graph = bool(model.training) and torch.is_grad_enabled() and not do_detection
+        if graph:
+            model.bind_flat()
+            model._rollout_gen += 1
+            check(eng.lib.jn_reinforce_forward(eng.handle, mode, ptr(forced_actions), ptr(start_positions), seed,
+                                               int(stop_early), C.byref(out), stream), "jn_reinforce_forward")
+            anchor = next(p for p in model.parameters() if p.requires_grad)
+            buf["logprobs"], buf["entropies"] = _RolloutGraph.apply(anchor, model, model._rollout_gen, buf["logprobs"],
+                                                                    buf["entropies"])
+        else:
+            check(eng.lib.jn_rollout(eng.handle, mode, ptr(forced_actions), ptr(start_positions), seed,
+                                     int(do_detection), int(stop_early), C.byref(out), stream), "jn_rollout")
         S = C.c_int()
         check(eng.lib.jn_rollout_steps(eng.handle, C.byref(S), stream), "jn_rollout_steps")
         S = S.value
@@ -111,6 +146,100 @@ class ReinforceTrainer:
                              for b in range(B)]
         return res
 
+    # ---- the reference's training loop on the autograd bridge (src/trainer.py:61-71, src/reinforce.py:267-362) --------
+    def ddp_setup(self, rank: int, world_size: int, port: int, backend: str = None):
+        """``Trainer.ddp_setup`` (src/trainer.py:61-71): one process per GPU, backend "nccl" (= RCCL over xGMI on ROCm).
+        Rendezvous on 127.0.0.1 (the reference's "localhost" may not resolve in a container); ``backend="gloo"`` is for
+        CPU-side rehearsals."""
+        import os
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        if not dist.is_initialized():
+            dist.init_process_group(backend=backend or "nccl", rank=rank, world_size=world_size)
+
+    def training_step(self, batch, optim_gpt, optim_yolox=None, sync_gradients: bool = True, **rollout_kw):
+        """The body of the reference's loop, statement for statement (src/reinforce.py:302-353): env -> rollout ->
+        compute_metrics -> [detector loss] -> (loss / ga).backward() -> every ga-th iteration clip_grad_value_ ->
+        optim.step() -> optim.zero_grad() -> reward-norm window.  Everything torch sees is real: ``loss`` has a graph (the
+        rollout node calls the engine's backward), ``param.grad`` are tensors, the optimisers are ``torch.optim.Optimizer``s."""
+        from torch.nn.utils import clip_grad
+        config, model = self.config, self.model
+        self.iter_num = getattr(self, "iter_num", 0) + 1
+        model.train()
+        images, bboxes = batch["image"].to(self.device), batch["bboxes"]
+        env = NeedleGeneralEnv(images, bboxes, self.patch_size, self.max_ep_len, self.n_glimps_levels, self.stop_enabled,
+                               engine=model.engine())
+        rollout = self.rollout(env, keep_patches=False, **rollout_kw)
+        metrics = self.compute_metrics(rollout)
+        loss = metrics["loss"]
+        ga = int(getattr(config, "gradient_accumulation", 1))
+        # (the policy loss is differentiated BEFORE the detector step: that step's loss is computed and differentiated
+        # inside the engine in one call and may reuse the workspace of the rollout's encoder when the detector's own PAFPN
+        # encodes the patches; the sum of the two gradients is the reference's `loss += total_loss; loss.backward()`)
+        (loss / ga).backward()
+        if getattr(config, "detection_enabled", False) and self.yolox_model() is not None:
+            patches_yolox, bboxes_yolox = env.get_detection_batch(int(getattr(config, "detection_sample_neg", 1)))
+            if getattr(self, "detection_augment", None) is not None:
+                with torch.no_grad():
+                    patches_yolox = self.detection_augment(patches_yolox)
+            # the engine computes the detector loss AND its backward in one call (gradients -> param.grad); the value joins
+            # the reported loss as a constant
+            _, _, yolo_loss = self.yolox_model()(patches_yolox, bboxes_yolox, loss_scale=1.0 / ga)
+            for k, v in yolo_loss.items():
+                metrics["yolo_" + k] = v
+            loss = loss + yolo_loss["total_loss"].detach()
+        if self.iter_num % ga == 0:
+            if sync_gradients:
+                # data-parallel ranks: ONE all-reduce of the flat gradient buffer (mean), before the clip as under DDP
+                from .dist import allreduce_gradients
+                sc = allreduce_gradients(model._flat_grads, model._arena_numel)
+                if sc != 1.0:
+                    model._flat_grads.mul_(sc)
+            clip_grad.clip_grad_value_(model.parameters(), 1)
+            optim_gpt.step()
+            optim_gpt.zero_grad()
+            if getattr(config, "detection_enabled", False) and optim_yolox is not None:
+                optim_yolox.step()
+                optim_yolox.zero_grad()
+            if config.reward_norm:
+                self._compute_last_returns_mean_std()
+        metrics["loss"] = loss.detach()
+        return metrics
+
+    def run(self, rank: int, world_size: int, ddp_port: int, batches=None, max_iters: int = None, backend: str = None):
+        """``ReinforceTrainer.run`` (src/reinforce.py:267-362) without the dataset / Visdom / test plumbing (out of scope,
+        SURVEY.md §8): `batches` is any iterable of collated batches ({"image": [B,3,H,W], "bboxes": [B,nb,4]}, the
+        ``padded_collate_fn`` layout; default: ``self.train_dataset``), re-iterated when exhausted.  Returns the metrics of
+        the last iteration."""
+        import torch.distributed as dist
+        if getattr(self.config, "detection_enabled", False) and getattr(self.config, "augment_detection", False):
+            self.init_detection()
+        self.rank = rank
+        if world_size > 1 or backend:
+            self.ddp_setup(rank, world_size, ddp_port, backend)
+        model = self.model
+        optim_gpt, optim_yolox = model.configure_optimizers(self.config)
+        for o in (optim_gpt, optim_yolox):
+            if o is not None:
+                o.sync_gradients = False                     # training_step averages the gradients before the clip
+        self.optim_gpt, self.optim_yolox = optim_gpt, optim_yolox
+        batches = batches if batches is not None else self.train_dataset
+        assert batches is not None, "run() needs an iterable of collated batches"
+        n_iters = int(max_iters if max_iters is not None else getattr(self.config, "max_iters", 1))
+        it = iter(batches)
+        metrics = None
+        for _ in range(n_iters):
+            try:
+                batch = next(it)
+            except StopIteration:
+                it = iter(batches)
+                batch = next(it)
+            metrics = self.training_step(batch, optim_gpt, optim_yolox, sync_gradients=world_size > 1)
+        if dist.is_available() and dist.is_initialized() and (world_size > 1 or backend):
+            dist.destroy_process_group()
+        return metrics
+
     def init_detection(self, **kw):
         """``Trainer.init_detection`` (src/trainer.py:176-186): installs the on-device augmentation of the detector
         patches.  Off until called (the parity tests compare un-augmented steps); keyword arguments go to
@@ -122,16 +251,10 @@ class ReinforceTrainer:
 
     # ---- training: one REINFORCE iteration (src/reinforce.py:302-353) ------------------------
     def _grad_arena(self):
-        """Flat fp32 gradient buffer shared with the engine (torch-owned so that RCCL can
-        all-reduce it in ONE call per optimiser step)."""
-        if getattr(self, "_flat_grads", None) is None:
-            eng = self.model.engine()
-            tot, gpt = C.c_size_t(), C.c_size_t()
-            check(eng.lib.jn_arena_info(eng.handle, C.byref(tot), C.byref(gpt)), "jn_arena_info")
-            self._flat_grads = torch.zeros(tot.value, device=self.device, dtype=torch.float32)
-            self._optim_numel = gpt.value
-            check(eng.lib.jn_set_grad_arena(eng.handle, ptr(self._flat_grads), tot.value), "jn_set_grad_arena")
-        return self._flat_grads
+        """The engine's flat fp32 gradient arena: owned by the MODEL (one per engine, shared by all trainers)."""
+        g = self.model.grad_arena()
+        self._optim_numel = self.model._optim_gpt_numel
+        return g
 
     def train_iteration(self, env: NeedleGeneralEnv, sample_actions: bool = True, forced_actions=None,
                         start_positions=None, stop_early: bool = True, optimizer_step: bool = True,
@@ -201,6 +324,7 @@ class ReinforceTrainer:
                 ylr = float(getattr(self.config, "yolo_lr", lr))
                 check(eng.lib.jn_optimizer_step_group(eng.handle, 1, ylr, 0.01, 1.0, scale, stream), "jn_optimizer_step_group")
             grads.zero_()
+            model.refresh_flat_params()
             if self.config.reward_norm:
                 self._compute_last_returns_mean_std()
         self._last_train_buffers = buf

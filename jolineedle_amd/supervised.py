@@ -22,14 +22,10 @@ class SupervisedTrainer:
         self._flat_grads = None
 
     def _grad_arena(self):
-        if self._flat_grads is None:
-            eng = self.model.engine()
-            tot, gpt = C.c_size_t(), C.c_size_t()
-            check(eng.lib.jn_arena_info(eng.handle, C.byref(tot), C.byref(gpt)), "jn_arena_info")
-            self._flat_grads = torch.zeros(tot.value, device=self.device, dtype=torch.float32)
-            self._optim_numel = gpt.value
-            check(eng.lib.jn_set_grad_arena(eng.handle, ptr(self._flat_grads), tot.value), "jn_set_grad_arena")
-        return self._flat_grads
+        """The engine's flat fp32 gradient arena: owned by the MODEL (one per engine, shared by all trainers)."""
+        g = self.model.grad_arena()
+        self._optim_numel = self.model._optim_gpt_numel
+        return g
 
     def init_detection(self, **kw):
         """``Trainer.init_detection`` (src/trainer.py:176-186): on-device augmentation of the trajectory patches and the
@@ -106,6 +102,7 @@ class SupervisedTrainer:
                 ylr = float(getattr(cfg, "yolo_lr", lr))
                 check(eng.lib.jn_optimizer_step_group(eng.handle, 1, ylr, 0.01, 0.0, scale, stream), "jn_optimizer_step_group")
             grads.zero_()
+            self.model.refresh_flat_params()
         res["trajectories"] = tr
         return res
 
@@ -135,5 +132,6 @@ class SupervisedTrainer:
             # the supervised loop does not clip gradients (src/supervised.py:897-902)
             check(eng.lib.jn_optimizer_step(eng.handle, lr, 0.01, 0.0, scale, stream), "jn_optimizer_step")
             grads.zero_()
+            self.model.refresh_flat_params()
         m = metrics.cpu()
         return {"loss": m[0], "action_loss": m[0], "action_accuracy": m[1], "episode_length": m[2], "logits": logits}

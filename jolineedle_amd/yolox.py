@@ -69,6 +69,8 @@ class NeedleYOLOX:
                   "jn_detector_step")
             for j, k in enumerate(names):
                 tot[k] = tot[k] + metrics[j] * (n / N)
+        if getattr(g, "_flat_grads", None) is not None and getattr(g, "_publish_detector_grads", True):
+            g.publish_engine_grads()                   # bound model (autograd bridge): yolox.*.grad follow at once
         return tot
 
     @staticmethod

