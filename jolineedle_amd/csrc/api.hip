@@ -756,7 +756,9 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
           while (e < v.C && !(net.h_td_hw[off + e] > 0.0f && (double)N * net.h_td_hw[off + e] <= (double)JN_DEFER_MAX_M)) ++e;
         }
         if (ns == 4) { fits = false; break; }
-        t.seg[ns++] = ChanTab::Run{c, e, d ? net.h_td_src[tc] : -1, net.h_td_goff[tc], net.h_td_boff[tc], net.h_td_hw[tc]};
+        const ChanTab::Run run{c, e, d ? net.h_td_src[tc] : -1, net.h_td_goff[tc], net.h_td_boff[tc], net.h_td_hw[tc]};
+        (ns == 0 ? t.r0 : ns == 1 ? t.r1 : ns == 2 ? t.r2 : t.r3) = run;
+        ++ns;
         c = e;
       }
       t.nseg = fits ? ns : 0;

@@ -42,20 +42,22 @@ __device__ __forceinline__ void bn_from_sums(const double* __restrict__ st, long
 
 // Entry of channel c of the view.  With deferred fields present, the four descriptor values are fetched together (one
 // round trip), then either the table entry or the batch sums + BatchNorm affine (a second one).
+__device__ __forceinline__ bool tab_run(const ChanTab& t, const ChanTab::Run& r, int c, float& sc, float& sh, float& fl) {
+  if (c < r.c0 || c >= r.c1 || r.stat0 < 0) return false;
+  const int d = c - r.c0;
+  const float gamma = t.dparams[r.g0 + d], beta = t.dparams[r.b0 + d];
+  float m, is; double var;
+  bn_from_sums(t.dstats, t.drep_stride, JN_NREP_DEFER, r.stat0 + d, (double)t.dN * (double)r.hw, gamma, beta, 1e-3f, sc, sh, m, is, var);
+  fl = 1.0f;
+  return true;
+}
+
 __device__ __forceinline__ void tab_entry(const ChanTab& t, int c, float& sc, float& sh, float& fl) {
   if (t.nseg > 0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (i < t.nseg && c >= t.seg[i].c0 && c < t.seg[i].c1 && t.seg[i].stat0 >= 0) {
-        const int d = c - t.seg[i].c0;
-        const float gamma = t.dparams[t.seg[i].g0 + d], beta = t.dparams[t.seg[i].b0 + d];
-        float m, is; double var;
-        bn_from_sums(t.dstats, t.drep_stride, JN_NREP_DEFER, t.seg[i].stat0 + d, (double)t.dN * (double)t.seg[i].hw, gamma, beta,
-                     1e-3f, sc, sh, m, is, var);
-        fl = 1.0f;
-        return;
-      }
-    }
+    if (tab_run(t, t.r0, c, sc, sh, fl)) return;
+    if (t.nseg > 1 && tab_run(t, t.r1, c, sc, sh, fl)) return;
+    if (t.nseg > 2 && tab_run(t, t.r2, c, sc, sh, fl)) return;
+    if (t.nseg > 3 && tab_run(t, t.r3, c, sc, sh, fl)) return;
     sc = t.sc[c]; sh = t.sh[c]; fl = t.fl[c];
     return;
   }

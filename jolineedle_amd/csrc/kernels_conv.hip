@@ -1120,13 +1120,8 @@ __global__ __launch_bounds__(256) void addact_kernel(const AT* __restrict__ z, i
                                                      const int* __restrict__ skip_flag, int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
   extern __shared__ __attribute__((aligned(16))) float tb[];      // [2][3][C]
-  for (int i = threadIdx.x; i < 2 * C; i += 256) {
-    const int which = i >= C, c = which ? i - C : i;
-    float a, b, f;
-    tab_entry(which ? rt : zt, c, a, b, f);
-    float* t = tb + which * 3 * C;
-    t[c] = a; t[C + c] = b; t[2 * C + c] = f;
-  }
+  tab_to_lds(tb, C, C, zt, threadIdx.x, 256);          // (two plain loops: selecting between the two by-value structs at run time
+  tab_to_lds(tb + 3 * C, C, C, rt, threadIdx.x, 256);  //  would send both to scratch memory)
   __syncthreads();
   const int C4 = C >> 2;
   const long long total = M * C4;
@@ -1208,7 +1203,7 @@ __global__ __launch_bounds__(256) void bn_finalize_all_kernel(BnAllArgs a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n_stat) return;
   const float hw = a.hw[i];
-  if ((long long)a.N * (long long)hw > JN_DEFER_MAX_M) return;
+  if (hw <= 0.0f || (long long)a.N * (long long)hw > JN_DEFER_MAX_M) return;   // hw == 0: not a layer of this pass (detection head)
   const double count = (double)a.N * (double)hw;
   float sc, sh, mean, invstd; double var;
   bn_from_sums(a.stats, a.rep_stride, JN_NREP_DEFER, i, count, a.params[a.goff[i]], a.params[a.boff[i]], a.eps, sc, sh, mean,
