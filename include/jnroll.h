@@ -227,6 +227,14 @@ int jn_arena_segment(jn_ctx* ctx, const char* name, size_t* off, size_t* numel);
 int jn_export_arena(jn_ctx* ctx, int what, float* dst_dev, size_t numel, int accumulate, void* stream);
 int jn_import_arena(jn_ctx* ctx, int what, const float* src_dev, size_t numel, void* stream);
 
+/* --dropout (main.py:123-128 -> embd_pdrop = attn_pdrop = resid_pdrop, src/models/gpt.py:178-179): active in the
+ * train-mode passes only (jn_reinforce_step / _forward, jn_supervised_step); eval entry points never drop.  The keep mask
+ * of an element is a pure function of (seed + number of train-mode forwards since this call, agent, token, layer, site,
+ * index) — Philox4x32-10, jn_device.h drop_scale — so the teacher-forced backward regenerates it and nothing is stored.
+ * Deviation from the reference: a token's masks are drawn once, when the token is processed (KV cache),
+ * whereas the reference re-draws the masks of the whole prefix at every glimpse step. */
+int jn_set_dropout(jn_ctx* ctx, float p, uint64_t seed);
+
 /* One supervised (teacher-forced) step minus the optimiser: SupervisedTrainer.run body
  * (src/supervised.py:863-902) with the detector term off.  patches [B,T,3,P,P], current_actions /
  * next_actions [B,T] int64, positions [B,T,2] int64, masks [B,T] u8 (1 = token, 0 = padding); B*T <=

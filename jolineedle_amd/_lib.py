@@ -109,6 +109,7 @@ SIGNATURES = {
     "jn_arena_segment": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "jn_export_arena": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "jn_import_arena": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "jn_set_dropout": (C.c_int, [C.c_void_p, C.c_float, C.c_uint64]),
 }
 
 

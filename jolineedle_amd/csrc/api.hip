@@ -1716,6 +1716,7 @@ static int rollout_impl(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev
       if ((rc = dev_alloc(ctx, &ctx->de_ws, MBt * ctx->efpn_h * ctx->efpn_w * C))) return rc;
     }
   }
+  if (train) ctx->drop_seed_used = ctx->drop_seed + ctx->drop_ctr++;   // dropout masks of this trajectory (regenerated in the backward)
   struct PrezeroGuard { jn_ctx* c; ~PrezeroGuard() { c->stats_prezeroed = false; } } prezero_guard{ctx};
   if (train && !c.no_patch_emb) {
     Net& tn = ctx->nets[ctx->enc_net];
@@ -1745,6 +1746,7 @@ static int rollout_impl(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev
     a.env = ep; a.out = r; a.n_done = ctx->n_done;
     a.skip_flag = flag; a.skip_when = B;
     a.tok_emb_out = train ? ctx->tok_emb_train : nullptr;
+    a.pdrop = train ? ctx->pdrop : 0.0f; a.drop_seed = ctx->drop_seed_used;
     launch_gpt_step(a, s);
     if (out->patches_dev)
       launch_gather(e.images, e.positions, out->patches_dev + (long long)(t + 1) * 3 * P * P, patch_stride, B, 3, e.H, e.W,
@@ -1904,6 +1906,7 @@ static int reinforce_backward_impl(jn_ctx* ctx, const jn_rollout_out* out, int S
   ba.g_proj_wt = g.proj_wt ? grad_of(ctx, g.proj_wt) : nullptr; ba.g_proj_b = g.proj_b ? grad_of(ctx, g.proj_b) : nullptr;
   ba.g_head_wt = grad_of(ctx, g.head_wt); ba.g_lnf_w = grad_of(ctx, g.lnf_w); ba.g_lnf_b = grad_of(ctx, g.lnf_b);
   ba.scratch = ctx->gpt_bwd_scratch; ba.scratch_per_agent = per_agent;
+  ba.pdrop = ctx->pdrop; ba.drop_seed = ctx->drop_seed_used; ba.Tmax = c.block_size + 1;
   launch_gpt_backward(ba, s);
 
   // patch-encoder side: all executed glimpse steps in ONE set of launches (chunks of net.g_slots steps
@@ -2005,8 +2008,10 @@ int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* cur
   hipLaunchKernelGGL(emb_finish_kernel, dim3((N * C + 255) / 256), dim3(256), 0, s, ctx->emb_part, ctx->gpt.efpn_lin_b,
                      ctx->tok_emb_train, (long long)C, N, ctx->KS, C);
   JN_HIP(hipMemsetAsync(ctx->cache_len, 0, (size_t)B * sizeof(int32_t), s));
+  ctx->drop_seed_used = ctx->drop_seed + ctx->drop_ctr++;
   GptStepArgs a{};
   fill_gpt_weights(ctx, a);
+  a.pdrop = ctx->pdrop; a.drop_seed = ctx->drop_seed_used;
   a.B = B; a.T = L; a.emb_stride = L; a.out.final_emb = ctx->sup_final_emb; a.logits_stride = T * nA;
   for (int tok = 0; tok < L; ++tok) {
     a.step = tok;
@@ -2047,6 +2052,7 @@ int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* cur
   ba.g_proj_wt = g.proj_wt ? grad_of(ctx, g.proj_wt) : nullptr; ba.g_proj_b = g.proj_b ? grad_of(ctx, g.proj_b) : nullptr;
   ba.g_head_wt = grad_of(ctx, g.head_wt); ba.g_lnf_w = grad_of(ctx, g.lnf_w); ba.g_lnf_b = grad_of(ctx, g.lnf_b);
   ba.scratch = ctx->gpt_bwd_scratch; ba.scratch_per_agent = per_agent;
+  ba.pdrop = ctx->pdrop; ba.drop_seed = ctx->drop_seed_used; ba.Tmax = c.block_size + 1;
   launch_gpt_backward(ba, s);
   const int MB = c.max_batch;
   const View& f2 = net.fpn[2];
@@ -2149,6 +2155,12 @@ int jn_export_arena(jn_ctx* ctx, int what, float* dst_dev, size_t numel, int acc
 
 int jn_import_arena(jn_ctx* ctx, int what, const float* src_dev, size_t numel, void* stream) {
   return arena_copy(ctx, what, const_cast<float*>(src_dev), numel, 0, 0, stream);
+}
+
+int jn_set_dropout(jn_ctx* ctx, float p, uint64_t seed) {
+  JN_CHECK(ctx && p >= 0.0f && p < 1.0f, JN_EINVAL, "dropout probability must be in [0, 1)");
+  ctx->pdrop = p; ctx->drop_seed = seed; ctx->drop_ctr = 0;
+  return JN_OK;
 }
 
 int jn_read_param(jn_ctx* ctx, const char* name, float* host_out, size_t numel) {

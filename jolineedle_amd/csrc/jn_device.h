@@ -25,6 +25,17 @@ __device__ inline uint4 philox4x32(uint64_t seed, uint32_t c0, uint32_t c1, uint
 }
 __device__ inline float u01(uint32_t x) { return (x >> 8) * (1.0f / 16777216.0f); }   // [0, 1)
 
+// Dropout of the decision transformer (src/models/gpt.py:65-66, 100, 107, 124, 314: embd / attn / resid, p = --dropout):
+// keep-scale (0 or 1 / (1 - p)) of element `idx` at `site` of `layer` for token `tok` of agent `b`, a pure function of the
+// rollout's dropout seed — the teacher-forced backward regenerates it, no mask is stored.  Sites: 0 embedding (after
+// final_emb), 1 attention probabilities (idx = head * Tmax + key), 2 residual after attn.c_proj, 3 residual after mlp.c_proj.
+__device__ inline float drop_scale(uint64_t seed, int b, int tok, int layer, int site, int idx, float p) {
+  const uint4 r = philox4x32(seed, (uint32_t)b, (uint32_t)tok, 0x44520000u | ((uint32_t)layer << 4) | (uint32_t)site, (uint32_t)(idx >> 2));
+  const int k = idx & 3;
+  const uint32_t w = k == 0 ? r.x : k == 1 ? r.y : k == 2 ? r.z : r.w;
+  return u01(w) >= p ? 1.0f / (1.0f - p) : 0.0f;
+}
+
 struct EnvStepResult { float reward; bool terminated, truncated; int y, x; };
 
 // One agent's NeedleGeneralEnv.step (src/env/general_env.py:172-233, 321-358, 235-246):

@@ -226,6 +226,8 @@ struct jn_ctx {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool profiling = false;
   bool bwd_timed = false;         // ev[2] / ev[3] bracket a conv-stack backward
+  float pdrop = 0.0f;             // --dropout (embd / attn / resid), train-mode passes only (jn_set_dropout)
+  uint64_t drop_seed = 0, drop_ctr = 0, drop_seed_used = 0;   // seed of the NEXT / the most recent train-mode forward
   jn_rollout_out train_out{};     // output buffers of the most recent train-mode rollout (jn_reinforce_backward reads them)
   bool train_out_valid = false;
   jnr::ArenaSeg* segs_dev = nullptr; int segs_dev_n = 0;   // device copy of `segs` for the layout-conversion kernel

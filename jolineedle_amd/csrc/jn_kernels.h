@@ -289,6 +289,7 @@ struct GptStepArgs {
   RolloutBuffers out;
   int32_t* n_done;                  // [T+1]
   float* tok_emb_out;               // [B][T][C] finished patch embedding of this step (training) or null
+  float pdrop; uint64_t drop_seed;  // train-mode dropout (0 = off), see drop_scale in jn_device.h
   const int* skip_flag; int skip_when;
 };
 int launch_gpt_step(const GptStepArgs& a, hipStream_t s);
@@ -331,6 +332,7 @@ struct GptBwdArgs {
   const GptLayerPtrs* g_layers;     // gradients (same layout, non-const use)
   float *g_wte, *g_wpe, *g_embed_class, *g_proj_wt, *g_proj_b, *g_head_wt, *g_lnf_w, *g_lnf_b;
   float* scratch; long long scratch_per_agent;
+  float pdrop; uint64_t drop_seed; int Tmax;   // dropout of the forward being differentiated (Tmax = block_size + 1)
 };
 int launch_gpt_backward(const GptBwdArgs& a, hipStream_t s);
 int launch_ce_loss(const float* logits, const int64_t* target, const uint8_t* masks, float stop_weight, float* dlogits,

@@ -178,6 +178,11 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
     if (a.out.final_emb)
       for (int i = tid; i < C; i += GPT_THREADS) a.out.final_emb[((long long)b * a.emb_stride + len) * C + i] = x[i];
     if (a.embed_only) { ++len; continue; }
+    const bool drop = a.pdrop > 0.0f;
+    if (drop) {                                           // x = transformer.drop(final_emb), gpt.py:525
+      for (int i = tid; i < C; i += GPT_THREADS) x[i] *= drop_scale(a.drop_seed, b, len, 0, 0, i, a.pdrop);
+      __syncthreads();
+    }
 
     // ---------------- transformer blocks ----------------
     for (int l = 0; l < a.n_layer; ++l) {
@@ -207,6 +212,8 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
         for (int s = 0; s < nk; ++s) { const float ev = expf(ap[s] - m); ap[s] = ev; sum += ev; }
         const float inv = 1.0f / sum;
         for (int s = 0; s < nk; ++s) ap[s] *= inv;
+        if (drop)                                         // attn_dropout on the probabilities, gpt.py:100
+          for (int s = 0; s < nk; ++s) ap[s] *= drop_scale(a.drop_seed, b, len, l, 1, tid * a.Tmax + s, a.pdrop);
       }
       __syncthreads();
       for (int i = tid; i < C; i += GPT_THREADS) {
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
       __syncthreads();
       linear_t(qkv, h, L.proj_wt, L.proj_b, C, C, part);      // qkv[0:C] reused as scratch
       __syncthreads();
-      for (int i = tid; i < C; i += GPT_THREADS) x[i] += qkv[i];
+      for (int i = tid; i < C; i += GPT_THREADS) x[i] += drop ? qkv[i] * drop_scale(a.drop_seed, b, len, l, 2, i, a.pdrop) : qkv[i];
       __syncthreads();
       layer_norm(h, x, L.ln2_w, L.ln2_b, C, red);
       linear_t(mlp, h, L.fc_wt, L.fc_b, C, 4 * C, part);
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
       __syncthreads();
       linear_t(qkv, mlp, L.fc2_wt, L.fc2_b, 4 * C, C, part);
       __syncthreads();
-      for (int i = tid; i < C; i += GPT_THREADS) x[i] += qkv[i];
+      for (int i = tid; i < C; i += GPT_THREADS) x[i] += drop ? qkv[i] * drop_scale(a.drop_seed, b, len, l, 3, i, a.pdrop) : qkv[i];
       __syncthreads();
     }
     ++len;

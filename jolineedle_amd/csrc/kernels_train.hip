@@ -7,6 +7,7 @@
 // each agent, which is what gpt_backward_kernel recomputes and differentiates.
 #include <hip/hip_runtime.h>
 
+#include "jn_device.h"
 #include "jn_kernels.h"
 #include "jn_types.h"
 
@@ -349,7 +350,13 @@ __global__ __launch_bounds__(GB) void gpt_backward_kernel(GptBwdArgs a) {
   float* PARTS = HF + L * C;       // [4C]
 
   // ---------------- forward recompute ----------------
-  for (int e = tid; e < L * C; e += GB) X[e] = a.final_emb[((long long)b * (a.T + 1)) * C + e];
+  const bool drop = a.pdrop > 0.0f;
+  const float pd = a.pdrop;
+  const uint64_t dseed = a.drop_seed;
+  for (int e = tid; e < L * C; e += GB) {
+    const float v = a.final_emb[((long long)b * (a.T + 1)) * C + e];
+    X[e] = drop ? v * drop_scale(dseed, b, e / C, 0, 0, e % C, pd) : v;
+  }
   __syncthreads();
   for (int l = 0; l < nL; ++l) {
     const GptLayerPtrs W = a.layers[l];
@@ -387,12 +394,16 @@ __global__ __launch_bounds__(GB) void gpt_backward_kernel(GptBwdArgs a) {
     for (int e = tid; e < L * C; e += GB) {
       const int i = e / C, c = e - i * C, h = c / hs;
       float acc = 0.0f;
-      for (int j = 0; j <= i; ++j) acc = fmaf(ATT[(h * L + i) * L + j], QKV[j * 3 * C + 2 * C + c], acc);
+      for (int j = 0; j <= i; ++j) {
+        float pij = ATT[(h * L + i) * L + j];
+        if (drop) pij *= drop_scale(dseed, b, i, l, 1, h * a.Tmax + j, pd);
+        acc = fmaf(pij, QKV[j * 3 * C + 2 * C + c], acc);
+      }
       Y[e] = acc;
     }
     __syncthreads();
     lin_fwd(XM, Y, W.proj_wt, W.proj_b, L, C, C);
-    for (int e = tid; e < L * C; e += GB) XM[e] += x[e];
+    for (int e = tid; e < L * C; e += GB) XM[e] = x[e] + (drop ? XM[e] * drop_scale(dseed, b, e / C, l, 2, e % C, pd) : XM[e]);
     __syncthreads();
     ln_fwd(H2, XM, W.ln2_w, W.ln2_b, mu, rs, L, C);
     lin_fwd(Fp, H2, W.fc_wt, W.fc_b, L, C, 4 * C);
@@ -401,7 +412,7 @@ __global__ __launch_bounds__(GB) void gpt_backward_kernel(GptBwdArgs a) {
     for (int e = tid; e < L * 4 * C; e += GB) dF[e] = gelu_f(Fp[e]);
     __syncthreads();
     lin_fwd(xo, dF, W.fc2_wt, W.fc2_b, L, 4 * C, C);
-    for (int e = tid; e < L * C; e += GB) xo[e] += XM[e];
+    for (int e = tid; e < L * C; e += GB) xo[e] = XM[e] + (drop ? xo[e] * drop_scale(dseed, b, e / C, l, 3, e % C, pd) : xo[e]);
     __syncthreads();
   }
   float* xl = X + nL * L * C;
@@ -439,18 +450,24 @@ __global__ __launch_bounds__(GB) void gpt_backward_kernel(GptBwdArgs a) {
     float* XM = Y + L * C;
     float* H2 = XM + L * C;
     float* Fp = H2 + L * C;
-    // mlp: xo = XM + fc2(gelu(fc(H2)))
-    lin_bwd_data(dF, dX, W.fc2_wt, L, 4 * C, C, false);                     // dA
+    // mlp: xo = XM + drop(fc2(gelu(fc(H2)))): dO = gradient at the fc2 output (dY is free here)
+    const float* dO = dX;
+    if (drop) {
+      for (int e = tid; e < L * C; e += GB) dY[e] = dX[e] * drop_scale(dseed, b, e / C, l, 3, e % C, pd);
+      __syncthreads();
+      dO = dY;
+    }
+    lin_bwd_data(dF, dO, W.fc2_wt, L, 4 * C, C, false);                     // dA
     // weight grad of fc2 needs gelu(F): recompute into dQKV/dY-sized temp is too small -> use dP? no: reuse Y? keep simple:
     for (int e = tid; e < 4 * C * C; e += GB) {
       const int k = e / C, c = e - k * C;
       float acc = 0.0f;
-      for (int i = 0; i < L; ++i) acc = fmaf(gelu_f(Fp[i * 4 * C + k]), dX[i * C + c], acc);
+      for (int i = 0; i < L; ++i) acc = fmaf(gelu_f(Fp[i * 4 * C + k]), dO[i * C + c], acc);
       atomicAdd(&G.fc2_wt[e], acc);
     }
     for (int c = tid; c < C; c += GB) {
       float acc = 0.0f;
-      for (int i = 0; i < L; ++i) acc += dX[i * C + c];
+      for (int i = 0; i < L; ++i) acc += dO[i * C + c];
       atomicAdd(&G.fc2_b[c], acc);
     }
     for (int e = tid; e < L * 4 * C; e += GB) dF[e] *= gelu_d(Fp[e]);
@@ -471,15 +488,23 @@ __global__ __launch_bounds__(GB) void gpt_backward_kernel(GptBwdArgs a) {
     for (int e = tid; e < L * C; e += GB) dXM[e] = dX[e];
     __syncthreads();
     ln_bwd(dXM, dH, XM, W.ln2_w, G.ln2_w, G.ln2_b, mu, rs, L, C, true, 0);
-    // attention output projection: XM = x + proj(Y)
-    lin_bwd_data(dY, dXM, W.proj_wt, L, C, C, false);
-    lin_bwd_weight(G.proj_wt, G.proj_b, Y, dXM, L, C, C, 0);
+    // attention output projection: XM = x + drop(proj(Y)); dPo = gradient at the proj output (dH is free here)
+    const float* dPo = dXM;
+    if (drop) {
+      for (int e = tid; e < L * C; e += GB) dH[e] = dXM[e] * drop_scale(dseed, b, e / C, l, 2, e % C, pd);
+      __syncthreads();
+      dPo = dH;
+    }
+    lin_bwd_data(dY, dPo, W.proj_wt, L, C, C, false);
+    lin_bwd_weight(G.proj_wt, G.proj_b, Y, dPo, L, C, C, 0);
     // dP[h][i][j] = sum_d dY[i][h,d] * v[j][h,d]
     for (int e = tid; e < nh * L * L; e += GB) {
       const int h = e / (L * L), i = (e / L) % L, j = e % L;
       float acc = 0.0f;
-      if (j <= i)
+      if (j <= i) {
         for (int q = 0; q < hs; ++q) acc = fmaf(dY[i * C + h * hs + q], QKV[j * 3 * C + 2 * C + h * hs + q], acc);
+        if (drop) acc *= drop_scale(dseed, b, i, l, 1, h * a.Tmax + j, pd);     // through attn_dropout
+      }
       dP[e] = acc;
     }
     __syncthreads();
@@ -487,7 +512,11 @@ __global__ __launch_bounds__(GB) void gpt_backward_kernel(GptBwdArgs a) {
     for (int e = tid; e < L * C; e += GB) {
       const int j = e / C, c = e - j * C, h = c / hs;
       float acc = 0.0f;
-      for (int i = j; i < L; ++i) acc = fmaf(ATT[(h * L + i) * L + j], dY[i * C + c], acc);
+      for (int i = j; i < L; ++i) {
+        float pij = ATT[(h * L + i) * L + j];
+        if (drop) pij *= drop_scale(dseed, b, i, l, 1, h * a.Tmax + j, pd);
+        acc = fmaf(pij, dY[i * C + c], acc);
+      }
       dQKV[j * 3 * C + 2 * C + c] = acc;
     }
     // softmax backward in place: dS = P * (dP - sum_j P*dP)
@@ -527,6 +556,10 @@ __global__ __launch_bounds__(GB) void gpt_backward_kernel(GptBwdArgs a) {
   }
 
   // ---------------- token embeddings ----------------
+  if (drop) {                                           // through transformer.drop(final_emb)
+    for (int e = tid; e < L * C; e += GB) dX[e] *= drop_scale(dseed, b, e / C, 0, 0, e % C, pd);
+    __syncthreads();
+  }
   for (int c = tid; c < C; c += GB) atomicAdd(&a.g_embed_class[c], dX[c]);          // class token id 0
   for (int i = 1; i < L; ++i) {
     const int t = i - 1;

@@ -60,8 +60,6 @@ class GPT(nn.Module):
         type_given = config.model_type is not None
         params_given = all(getattr(config, k, None) is not None for k in ("n_layer", "n_head", "n_embd"))
         assert type_given ^ params_given          # gpt.py:181-189
-        if getattr(config, "dropout", 0.0) != 0.0:
-            raise NotImplementedError("the HIP rollout engine implements the dropout=0 recipes (README.md:56-131)")
         self.config = config
         self.block_size = config.block_size
         self.patch_size = config.patch_size
@@ -76,6 +74,9 @@ class GPT(nn.Module):
         self._engine = Engine(make_jn_config(config, dev_index, max_batch, n_actions))
         self.n_layer, self.n_head, self.n_embd = (self._engine.cfg.n_layer, self._engine.cfg.n_head,
                                                  self._engine.cfg.n_embd)
+        # --dropout (main.py:123-128; embd / attn / resid of the decision transformer): train-mode passes only
+        self.dropout = float(getattr(config, "dropout", 0.0) or 0.0)
+        self.set_dropout_seed(int(getattr(config, "seed", 0)))
         self._build_parameters()
         self._uploaded_version = None
         self._engine_grads = None          # packed gradient arena (torch-owned: ONE RCCL all-reduce per optimiser step)
@@ -120,6 +121,10 @@ class GPT(nn.Module):
             _attach(self, name, t, is_buffer)
         if self.decoder_pos_encoding and "wpe" in self.transformer._modules:
             self.transformer.wpe.weight.requires_grad_(False)   # gpt.py:320-321
+
+    def set_dropout_seed(self, seed: int):
+        """(Re)start the dropout mask stream: the n-th train-mode forward after this call uses `seed + n`."""
+        check(self._engine.lib.jn_set_dropout(self._engine.handle, self.dropout, int(seed) & 0xFFFFFFFFFFFFFFFF), "jn_set_dropout")
 
     @property
     def yolox(self):

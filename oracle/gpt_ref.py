@@ -40,6 +40,7 @@ class _Attn(nn.Module):
         self.register_buffer(
             "bias", torch.tril(torch.ones(block_size, block_size)).view(1, 1, block_size, block_size))
         self.n_head, self.n_embd = n_head, n_embd
+        self.drop, self.layer = None, 0          # injected dropout masks (oracle/dropout_ref.py), None = no dropout
 
     def forward(self, x):
         B, T, C = x.shape
@@ -48,8 +49,12 @@ class _Attn(nn.Module):
                    for t in self.c_attn(x).split(C, dim=2))
         att = (q @ k.transpose(-2, -1)) / math.sqrt(hs)
         att = att.masked_fill(self.bias[:, :, :T, :T] == 0, float("-inf")).softmax(dim=-1)
-        y = (att @ v).transpose(1, 2).reshape(B, T, C)
-        return self.c_proj(y)
+        if self.drop is not None and self.training:
+            att = att * self.drop.att(B, self.n_head, T, self.layer, att.dtype)           # attn_dropout, gpt.py:100
+        y = self.c_proj((att @ v).transpose(1, 2).reshape(B, T, C))
+        if self.drop is not None and self.training:
+            y = y * self.drop.vec(B, T, C, self.layer, 2, y.dtype)                         # resid_dropout, gpt.py:107
+        return y
 
 
 class _Block(nn.Module):
@@ -60,10 +65,14 @@ class _Block(nn.Module):
         self.ln_2 = nn.LayerNorm(n_embd)
         self.mlp = nn.ModuleDict(dict(c_fc=nn.Linear(n_embd, 4 * n_embd),
                                       c_proj=nn.Linear(4 * n_embd, n_embd)))
+        self.drop, self.layer = None, 0
 
     def forward(self, x):
         x = x + self.attn(self.ln_1(x))
-        return x + self.mlp["c_proj"](gelu_tanh(self.mlp["c_fc"](self.ln_2(x))))
+        m = self.mlp["c_proj"](gelu_tanh(self.mlp["c_fc"](self.ln_2(x))))
+        if self.drop is not None and self.training:
+            m = m * self.drop.vec(x.shape[0], x.shape[1], x.shape[2], self.layer, 3, m.dtype)   # mlp dropout, gpt.py:124
+        return x + m
 
 
 class _ActionHead(nn.Module):
@@ -94,11 +103,11 @@ def default_model_config(**kw) -> SimpleNamespace:
 class GPTRef(nn.Module):
     """Only the configuration the hot path uses is restated: single categorical
     action, ``concat_emb`` or mean merge, optional patch / position embeddings,
-    optional standalone ``gpt_backbone``.  Dropout must be 0 (BASELINE recipes)."""
+    optional standalone ``gpt_backbone``.  Dropout: masks injected by ``enable_dropout`` (the engine's Philox masks)."""
 
     def __init__(self, cfg):
         super().__init__()
-        assert cfg.dropout == 0.0, "oracle restates the dropout=0 recipes only"
+        # cfg.dropout is carried for the config surface only: the oracle drops with INJECTED masks (enable_dropout)
         self.cfg = cfg
         n_layer, n_head, C = GPT_ZOO[cfg.model_type]
         self.n_embd, self.n_head, self.n_layer = C, n_head, n_layer
@@ -189,8 +198,18 @@ class GPTRef(nn.Module):
             return torch.cat((prev_embeddings, emb), dim=1)
         return torch.cat((self.embed_class(classes).unsqueeze(1), emb), dim=1)
 
+    def enable_dropout(self, p: float, seed: int):
+        """Dropout with the engine's masks injected (oracle/dropout_ref.py); train mode only; p = 0 switches it off."""
+        from .dropout_ref import DropoutMasks
+        self.drop = DropoutMasks(p, seed, self.block_size + 1) if p > 0 else None
+        for l, blk in enumerate(self.transformer["h"]):
+            blk.drop = blk.attn.drop = self.drop
+            blk.layer = blk.attn.layer = l
+
     def decode(self, final_emb):
         x = final_emb
+        if getattr(self, "drop", None) is not None and self.training:
+            x = x * self.drop.vec(x.shape[0], x.shape[1], x.shape[2], 0, 0, x.dtype)      # transformer.drop, gpt.py:525
         for blk in self.transformer["h"]:
             x = blk(x)
         return self.transformer["ln_f"](x)

@@ -544,6 +544,67 @@ def test_reinforce_iteration_gradients_vs_oracle(stop, B, P, Tn, grad_slots, arc
     assert torch.allclose(product.state_dict()[k], oracle.state_dict()[k], atol=1e-5, rtol=1e-3)
 
 
+@pytest.mark.parametrize("mode", ["reinforce", "supervised"])
+def test_dropout_training_with_injected_masks_vs_oracle(mode):
+    """--dropout 0.1 (the reference's default, main.py:123-128): embd / attn / resid dropout of the decision transformer
+    in the train-mode passes.  The engine's keep masks are a pure function of (seed, agent, token, layer, site, index)
+    (Philox4x32-10, regenerated in the backward); the oracle applies the same masks (oracle/dropout_ref.py) at the
+    reference's four sites: logits, loss and every gradient agree; eval-mode passes do not drop."""
+    P, Tn, B, pdrop, seed = 64, 4, 3, 0.1, 77
+    product, oracle = make_pair(5, patch_size=P, block_size=Tn, with_detector=False, image_processor=None, dropout=pdrop)
+    assert product.dropout == pdrop
+    oracle.enable_dropout(pdrop, seed)
+    product.set_dropout_seed(seed)
+    if mode == "reinforce":
+        images, bboxes, start = synth_batch(B, 3, 4, P, seed=41)
+        forced = torch.randint(0, 8, (B, Tn), generator=torch.Generator().manual_seed(3))
+        ro, m = _oracle_reinforce_grads(oracle, images, bboxes, start, forced, P, Tn, True, 0.25, 1.5, 0.01)
+        tr = ja.ReinforceTrainer(_cfg(T=Tn, learning_rate=1e-3, gradient_accumulation=1), product)
+        tr.last_return_mean, tr.last_return_std = 0.25, 1.5
+        env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True)
+        got = tr.train_iteration(env, forced_actions=forced, start_positions=start, optimizer_step=False)
+        assert (tr._last_train_buffers["logits"].cpu() - ro["logits"].detach()).abs().max() < 1e-3
+        for k in ("action_loss", "entropy_loss", "loss"):
+            assert abs(float(got[k]) - float(m[k])) < 2e-4, k
+        # the masks matter: the same iteration without dropout gives other logits
+        oracle.enable_dropout(0.0, 0)
+        ro0, _ = _oracle_reinforce_grads(build_like(oracle), images, bboxes, start, forced, P, Tn, True, 0.25, 1.5, 0.01)
+        assert (ro0["logits"] - ro["logits"]).abs().max() > 1e-3
+        # eval-mode rollout: no dropout
+        product.eval()
+        ev = tr.rollout(ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True), forced_actions=forced, start_positions=start)
+        oracle.eval()
+        from oracle import env_ref, rollout_ref
+        with torch.no_grad():
+            ref_ev = rollout_ref.rollout(oracle, env_ref.EnvRef(images, bboxes, P, Tn, 1, True), forced_actions=forced,
+                                         start_positions=start)
+        assert (ev["logits"].cpu() - ref_ev["logits"]).abs().max() < 1e-3
+    else:
+        patches, cur, positions = synth_tokens(B, Tn, P, 9, 5, seed=21)
+        nxt = torch.randint(0, 9, (B, Tn), generator=torch.Generator().manual_seed(4))
+        masks = torch.ones((B, Tn), dtype=torch.long)
+        oracle.train()
+        oracle.zero_grad()
+        logits, _ = oracle(patches, cur, torch.zeros(B, dtype=torch.long), positions)
+        torch.nn.functional.cross_entropy(logits.reshape(B * Tn, 9), nxt.flatten()).backward()
+        product2, _ = make_pair(5, patch_size=P, block_size=Tn, with_detector=False, image_processor=None, dropout=pdrop,
+                                max_batch=B * Tn)
+        product2.set_dropout_seed(seed)
+        cfg = ja.CfgNode(stop_enabled=True, stop_weight=1.0, learning_rate=1e-3, gradient_accumulation=1)
+        mm = ja.SupervisedTrainer(cfg, product2).train_step(patches, cur, nxt, positions, masks, optimizer_step=False)
+        assert (mm["logits"].cpu() - logits.detach()).abs().max() < 1e-3
+        product = product2
+    assert _check_grads(product.engine_grads(), oracle, tag=f"dropout {mode}") > 150
+
+
+def build_like(oracle):
+    """A copy of the oracle (same weights, no dropout) — a fresh autograd leaf set."""
+    import copy
+    o = copy.deepcopy(oracle)
+    o.enable_dropout(0.0, 0)
+    return o
+
+
 def test_reference_training_loop_on_the_autograd_bridge():
     """The reference's loop body, statement for statement (src/reinforce.py:326-353): rollout -> compute_metrics ->
     (loss / ga).backward() -> clip_grad_value_ -> optim_gpt.step() -> zero_grad(), on the package's objects.  The rollout's

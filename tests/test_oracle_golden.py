@@ -194,3 +194,21 @@ def test_simota_known_answers():
     fg3, matched3, _ = simota_assign(gt2, boxes, torch.zeros(16), torch.zeros(16), grid, stride)
     assert len(matched3) == int(fg3.sum()) and set(matched3.tolist()) <= {0, 1}
     assert torch.allclose(iou_loss(gt, gt), torch.zeros(1)) and float(pairwise_iou_cxcywh(gt, gt2)[0, 1]) == pytest.approx(0.6)
+
+
+def test_philox_known_answers_and_dropout_masks():
+    """Philox4x32-10 (the engine's counter-based generator: action sampling, env reset, dropout masks) against the
+    known-answer vectors of Random123 (kat_vectors: philox4x32_10), and the keep-scale statistics of the dropout mask."""
+    import numpy as np
+    from oracle.dropout_ref import drop_scale, philox4x32
+
+    def kat(ctr, key):
+        r = philox4x32(key[0] | (key[1] << 32), *[np.array([c], dtype=np.uint32) for c in ctr])
+        return [int(x[0]) for x in r]
+    assert kat((0, 0, 0, 0), (0, 0)) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert kat((0xffffffff,) * 4, (0xffffffff, 0xffffffff)) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert kat((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0)) == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    m = drop_scale(9, np.arange(8)[:, None, None], np.arange(21)[None, :, None], 2, 3, np.arange(192)[None, None, :], 0.1)
+    assert set(np.unique(m).tolist()) == {0.0, np.float32(1.0 / 0.9).item()}
+    assert abs((m == 0).mean() - 0.1) < 0.01
+    assert not np.array_equal(m[0], m[1]) and not np.array_equal(m[:, 0], m[:, 1])
