@@ -28,12 +28,20 @@
 
 namespace jnr {
 
+#ifdef JN_PWRES_STAMPS
+__device__ long long* g_pwres_dbg = nullptr;      // [workgroups][32] wall-clock stamps (10 ns ticks), tools/pwbench.hip
+#define JN_STAMP(i) do { if (g_pwres_dbg && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (i) < 32) g_pwres_dbg[blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
+#else
+#define JN_STAMP(i) do { } while (0)
+#endif
+
 template <int CT, int KC, int BM, int PD, bool WT>
 __global__ __launch_bounds__(256) void pw_res_kernel(
     const float* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, int w_ld, float* __restrict__ out,
     int out_ld, long long M, int K, int Nc, int accumulate, double* __restrict__ stats, long long rep_stride, int nrep,
     const int* __restrict__ skip_flag, int skip_when, long long x_slot, long long out_slot, long long tab_slot) {
   if (skip_flag && *skip_flag >= skip_when) return;
+  JN_STAMP(0);
   x += blockIdx.z * x_slot; out += blockIdx.z * out_slot;        // step-batched launches (gradients)
   it.sc += blockIdx.z * tab_slot; it.sh += blockIdx.z * tab_slot; it.fl += blockIdx.z * tab_slot;
   constexpr int WN = (CT >= 2) ? 2 : 1, WM = 4 / WN;             // waves along the channels / the pixels
@@ -121,7 +129,10 @@ __global__ __launch_bounds__(256) void pw_res_kernel(
     wstore(0);
     for (int base = 256 * WB; base < total; base += 256 * WB) { wload(base); wstore(base); }
   }
+  JN_STAMP(1);
   __syncthreads();
+  JN_STAMP(2);
+  int stamp_i = 3;
 
   f32x4 acc[PT][CTW];
 #pragma unroll
@@ -151,7 +162,9 @@ __global__ __launch_bounds__(256) void pw_res_kernel(
           *reinterpret_cast<f32x4*>(Xb + r * LDX + 4 * q) = v;
         }
       }
+      JN_STAMP(stamp_i); ++stamp_i;
       __syncthreads();
+      JN_STAMP(stamp_i); ++stamp_i;
       if (f + u + PD < n_it) fetch(xr[u]);
       {
         const float* xrow = Xb + (wm * PT * 16 + lm) * LDX + 4 * g;
@@ -172,6 +185,7 @@ __global__ __launch_bounds__(256) void pw_res_kernel(
                 acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][j], xb[p][j], acc[p][c], 0, 0, 0);
         }
       }
+      JN_STAMP(stamp_i); ++stamp_i;
       if (++cur_chunk == nchunks) {
         cur_chunk = 0;
 #pragma unroll
@@ -191,9 +205,12 @@ __global__ __launch_bounds__(256) void pw_res_kernel(
           }
         }
         cur_tile += gridDim.x;
+        JN_STAMP(stamp_i); ++stamp_i;
       }
     }
   }
+  JN_STAMP(30);
+  (void)stamp_i;
   if (stats) {
     __syncthreads();
     wave_stats_to_lds<CTW>(s1, s2, red + wm * 32 * CT + 2 * (wn * CTW * 16), lane, Nc - n0 - wn * CTW * 16);
@@ -205,9 +222,10 @@ __global__ __launch_bounds__(256) void pw_res_kernel(
       atomicAdd(&stats[(blockIdx.x % nrep) * rep_stride + 2 * n0 + tid], (double)v);
     }
   }
+  JN_STAMP(31);
 }
 
-struct PwResCfg { int ct, kc, bm, pd; };
+const char* g_pw_res_force = nullptr;   // tools/pwbench.hip: forced "ct,kc,bm,pd"
 
 template <int CT, int KC, int BM, int PD, bool WT>
 static void launch_pw_res_t(const ConvArgs& a, long long M, int max_wg_per_cu, hipStream_t s) {
@@ -258,7 +276,8 @@ int launch_pw_res(const ConvArgs& a, hipStream_t s) {
   // small problems: more, narrower slices so that >= ~256 workgroups exist
   const long long tiles64 = (M + 63) / 64;
   while (ct > 2 && tiles64 * nz * ((N + 16 * ct - 1) / (16 * ct)) < 320) ct >>= 1;
-  static const char* force = std::getenv("JN_PW_RES_CFG");           // "ct,kc,bm,pd": tuning aid
+  static const char* force_env = std::getenv("JN_PW_RES_CFG");       // "ct,kc,bm,pd": tuning aid
+  const char* force = g_pw_res_force ? g_pw_res_force : force_env;
   int bm = 64, pd = 2, kcc = kc;
   if (force) { int f_ct, f_kc, f_bm, f_pd; if (sscanf(force, "%d,%d,%d,%d", &f_ct, &f_kc, &f_bm, &f_pd) == 4) { if (f_ct) ct = f_ct; if (f_kc && K % f_kc == 0) kcc = f_kc; if (f_bm) bm = f_bm; if (f_pd) pd = f_pd; } }
   const bool wt = a.w_transposed != 0;

