@@ -103,6 +103,8 @@ int launch_dw(const ConvArgs& a, hipStream_t s);
 int launch_pw(const ConvArgs& a, hipStream_t s);
 bool pw_res_supported(const ConvArgs& a);              // kernels_pwres.hip: resident-weight kernel for K, N >= 64
 int launch_pw_res(const ConvArgs& a, hipStream_t s);
+int launch_pw_dir(const ConvArgs& a, int ctw, int split, hipStream_t s);
+int launch_pw_wide(const ConvArgs& a, hipStream_t s);   // production route: 0 when taken
 int launch_spp(void* cat, int dtype, int ld, int h, int H, int W, int N, ChanTab it, const int* skip_flag,
                int skip_when, hipStream_t s);
 int launch_upsample(const void* in, int in_ld, void* out, int out_ld, int dtype, int C, int H, int W, int N,

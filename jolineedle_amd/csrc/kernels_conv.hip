@@ -999,8 +999,10 @@ static void launch_pw_types(const ConvArgs& a, hipStream_t s) {
 // Type combinations in use: fp32 mode (f32, f32, fp32 MFMA); bf16 mode: activations (bf16 -> bf16),
 // embed_fpn.0 (bf16 -> f32) and gradients (f32 -> f32), all on the bf16 MFMA.
 int launch_pw(const ConvArgs& a, hipStream_t s) {
+  if (launch_pw_wide(a, s) == 0) return 0;                // K, N >= 64: weight-stationary kernel (kernels_pwres.hip)
   if (launch_pw_narrow(a, s)) return 0;
-  if (pw_res_supported(a) && launch_pw_res(a, s) == 0) return 0;
+  static const bool use_res = std::getenv("JN_PW_RES") != nullptr;    // the LDS-pipelined predecessor (tuning / comparison only)
+  if (use_res && pw_res_supported(a) && launch_pw_res(a, s) == 0) return 0;
   if (!a.bf16_mfma) {
     if (a.in_dtype == JN_F32 && a.out_dtype == JN_F32) { launch_pw_types<float, float, false>(a, s); return 0; }
     return -1;

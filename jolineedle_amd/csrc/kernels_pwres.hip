@@ -35,7 +35,22 @@ __device__ long long* g_pwres_dbg = nullptr;      // [workgroups][32] wall-clock
 #define JN_STAMP(i) do { } while (0)
 #endif
 
-template <int CT, int KC, int BM, int PD, bool WT>
+// fp32 value -> three bf16 terms whose sum carries its 24 significant bits (round-to-nearest at every step)
+__device__ __forceinline__ void split3(const f32x4& v, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bf16_t a = (bf16_t)v[e];
+    const float r = v[e] - (float)a;
+    const bf16_t b = (bf16_t)r;
+    const float r2 = r - (float)b;
+    h[e] = a; m[e] = b; l[e] = (bf16_t)r2;
+  }
+}
+
+// SP: operands split into three bf16 terms each, six v_mfma_f32_16x16x32_bf16 per product block (all cross terms down
+// to 2^-24 of the product: the accuracy of an fp32 multiply-add chain) — 96 matrix-pipe cycles per 16 x 16 x 32 block
+// instead of the 256 of eight v_mfma_f32_16x16x4_f32.  SP = false: exact fp32 (JN_PW_EXACT=1).
+template <int CT, int KC, int BM, int PD, bool WT, bool SP>
 __global__ __launch_bounds__(256) void pw_res_kernel(
     const float* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, int w_ld, float* __restrict__ out,
     int out_ld, long long M, int K, int Nc, int accumulate, double* __restrict__ stats, long long rep_stride, int nrep,
@@ -49,11 +64,16 @@ __global__ __launch_bounds__(256) void pw_res_kernel(
   static_assert(PT >= 1 && CTW >= 1 && PT * 16 * WM == BM && CTW * WN == CT, "pw_res tile mapping");
   constexpr int LDX = KC + 8, Q4 = KC / 4, RPP = 256 / Q4, NX = BM * Q4 / 256;
   static_assert(NX >= 1 && 256 % Q4 == 0, "pw_res staging mapping");
+  static_assert(!SP || KC % 32 == 0, "split path consumes 32 k per MFMA");
   const int LDW = K + 8;
+  constexpr int LDXh = KC + 16;                                   // split path: bf16 rows (40 dwords mod 64 for KC = 64)
+  const int LDWh = K + 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* Ws = reinterpret_cast<float*>(smem_raw);                 // [16*CT][LDW]   resident weight slice
   float* Xs = Ws + 16 * CT * LDW;                                 // [2][BM][LDX]   pixel chunks
-  float* Tb = Xs + 2 * BM * LDX;                                  // [3][K]         input table
+  bf16_t* Wh = reinterpret_cast<bf16_t*>(smem_raw);               // split path: [3][16*CT][LDWh]
+  bf16_t* Xh = Wh + 3 * 16 * CT * LDWh;                           //             [2][3][BM][LDXh]
+  float* Tb = SP ? reinterpret_cast<float*>(Xh + 6 * BM * LDXh) : Xs + 2 * BM * LDX;   // [3][K] input table
   float* red = Tb + 3 * K;                                        // [WM][16*CT][2] statistics slots
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM;
@@ -88,7 +108,7 @@ __global__ __launch_bounds__(256) void pw_res_kernel(
   // plain load -> store loop with a run-time trip count waits one global round trip per iteration: 16 of them for a
   // 128 x 128 slice); the table (deferred entries: batch sums) is derived while the first batch is in flight.
   {
-    constexpr int WB = 8;
+    constexpr int WB = 16;        // 16 float4 per thread cover a 128 x 128 slice in ONE round trip
     const int NQ = 4 * CT, KQ = K / 4;
     const int total = WT ? K * NQ : 16 * CT * KQ;
     f32x4 wr[WB];
@@ -113,7 +133,23 @@ __global__ __launch_bounds__(256) void pw_res_kernel(
       for (int j = 0; j < WB; ++j) {
         const int i = base + tid + 256 * j;
         if (i < total) {
-          if (WT) {
+          if constexpr (SP) {
+            bf16x4 h, m, l;
+            split3(wr[j], h, m, l);
+            const int plane = 16 * CT * LDWh;
+            if (WT) {
+              const int k = i / NQ, nq = i - k * NQ;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                bf16_t* d = Wh + (4 * nq + e) * LDWh + k;
+                d[0] = h[e]; d[plane] = m[e]; d[2 * plane] = l[e];
+              }
+            } else {
+              const int r = i / KQ, kq = i - r * KQ;
+              bf16_t* d = Wh + r * LDWh + 4 * kq;
+              *reinterpret_cast<bf16x4*>(d) = h; *reinterpret_cast<bf16x4*>(d + plane) = m; *reinterpret_cast<bf16x4*>(d + 2 * plane) = l;
+            }
+          } else if (WT) {
             const int k = i / NQ, nq = i - k * NQ;
 #pragma unroll
             for (int e = 0; e < 4; ++e) Ws[(4 * nq + e) * LDW + k] = wr[j][e];
@@ -150,7 +186,9 @@ __global__ __launch_bounds__(256) void pw_res_kernel(
       if (f + u >= n_it) break;
       const long long m0 = cur_tile * BM;
       const int k0 = cur_chunk * KC;
-      float* Xb = Xs + ((PD % 2 == 0) ? u % 2 : (int)((f + u) & 1)) * (BM * LDX);
+      const int bsel = (PD % 2 == 0) ? u % 2 : (int)((f + u) & 1);
+      float* Xb = Xs + bsel * (BM * LDX);
+      bf16_t* Xbh = Xh + bsel * (3 * BM * LDXh);
       {   // stage: raw chunk -> activated operand tile
         const f32x4 t_sc = *reinterpret_cast<const f32x4*>(Tb + k0 + 4 * q), t_sh = *reinterpret_cast<const f32x4*>(Tb + K + k0 + 4 * q),
                     t_fl = *reinterpret_cast<const f32x4*>(Tb + 2 * K + k0 + 4 * q);
@@ -159,14 +197,52 @@ __global__ __launch_bounds__(256) void pw_res_kernel(
           const int r = r0 + RPP * j;
           f32x4 v = {0.f, 0.f, 0.f, 0.f};
           if (m0 + r < M) v = tf4_tab(xr[u][j], t_sc, t_sh, t_fl);
-          *reinterpret_cast<f32x4*>(Xb + r * LDX + 4 * q) = v;
+          if constexpr (SP) {
+            bf16x4 h, m, l;
+            split3(v, h, m, l);
+            bf16_t* d = Xbh + r * LDXh + 4 * q;
+            *reinterpret_cast<bf16x4*>(d) = h; *reinterpret_cast<bf16x4*>(d + BM * LDXh) = m;
+            *reinterpret_cast<bf16x4*>(d + 2 * BM * LDXh) = l;
+          } else {
+            *reinterpret_cast<f32x4*>(Xb + r * LDX + 4 * q) = v;
+          }
         }
       }
       JN_STAMP(stamp_i); ++stamp_i;
       __syncthreads();
       JN_STAMP(stamp_i); ++stamp_i;
       if (f + u + PD < n_it) fetch(xr[u]);
-      {
+      if constexpr (SP) {
+        const bf16_t* xrow = Xbh + (wm * PT * 16 + lm) * LDXh + 8 * g;
+        const bf16_t* wrow = Wh + (wn * CTW * 16 + lm) * LDWh + k0 + 8 * g;
+        const int wplane = 16 * CT * LDWh;
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 32) {
+          bf16x8 xb[PT][3], wa[CTW][3];
+#pragma unroll
+          for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) xb[p][t] = *reinterpret_cast<const bf16x8*>(xrow + t * (BM * LDXh) + p * 16 * LDXh + kk);
+#pragma unroll
+          for (int c = 0; c < CTW; ++c)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) wa[c][t] = *reinterpret_cast<const bf16x8*>(wrow + t * wplane + c * 16 * LDWh + kk);
+          // smallest terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+#pragma unroll
+          for (int c = 0; c < CTW; ++c)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+              f32x4 d = acc[p][c];
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[c][2], xb[p][0], d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[c][0], xb[p][2], d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[c][1], xb[p][1], d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[c][1], xb[p][0], d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[c][0], xb[p][1], d, 0, 0, 0);
+              d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[c][0], xb[p][0], d, 0, 0, 0);
+              acc[p][c] = d;
+            }
+        }
+      } else {
         const float* xrow = Xb + (wm * PT * 16 + lm) * LDX + 4 * g;
         const float* wrow = Ws + (wn * CTW * 16 + lm) * LDW + k0 + 4 * g;
 #pragma unroll
@@ -227,11 +303,272 @@ __global__ __launch_bounds__(256) void pw_res_kernel(
 
 const char* g_pw_res_force = nullptr;   // tools/pwbench.hip: forced "ct,kc,bm,pd"
 
-template <int CT, int KC, int BM, int PD, bool WT>
+// ------------------------------------------------------------------------------------------------------------------
+// Weight-stationary, barrier-free form for slices of at most 128 output channels: the pixel operand never goes through
+// LDS.  A wave owns 16-pixel tiles; it fetches its tile's values straight into registers IN MFMA FRAGMENT LAYOUT (lane
+// (pixel lm, group g) reads the 4 — split path: 8 — consecutive input channels its k-steps need), applies the
+// "normalize on read" transform there, and multiplies against weight fragments read from the resident LDS copy.  After
+// the one barrier behind the weight load the waves never synchronise again: loads of the next step, transform VALU,
+// MFMAs and stores of different waves overlap freely (two workgroups per CU).  The in-kernel stamps of pw_res_kernel
+// showed why this matters on these shapes: with one 4-wave workgroup per CU its stage -> barrier -> MFMA -> store
+// phases ran back to back and the matrix pipe was busy a third of the time.
+// A step = KH = 64 input channels of one tile; steps are prefetched PF ahead in registers.
+template <int CTW, bool WT, bool SP>
+__global__ __launch_bounds__(256, 2) void pw_dir_kernel(
+    const float* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, int w_ld, float* __restrict__ out,
+    int out_ld, long long M, int K, int Nc, int accumulate, double* __restrict__ stats, long long rep_stride, int nrep,
+    const int* __restrict__ skip_flag, int skip_when, long long x_slot, long long out_slot, long long tab_slot) {
+  if (skip_flag && *skip_flag >= skip_when) return;
+  x += blockIdx.z * x_slot; out += blockIdx.z * out_slot;
+  it.sc += blockIdx.z * tab_slot; it.sh += blockIdx.z * tab_slot; it.fl += blockIdx.z * tab_slot;
+  constexpr int KH = 64, NF = KH / 16, PF = 2;                   // frags (float4 per lane) per step, prefetch depth
+  constexpr int NCH = 16 * CTW;                                   // output channels of the slice
+  const int LDW = K + 8, LDWh = K + 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* Ws = reinterpret_cast<float*>(smem_raw);                 // [NCH][LDW]
+  bf16_t* Wh = reinterpret_cast<bf16_t*>(smem_raw);               // split: [3][NCH][LDWh]
+  float* Tb = SP ? reinterpret_cast<float*>(Wh + 3 * NCH * LDWh) : Ws + NCH * LDW;    // [3][K]
+  float* red = Tb + 3 * K;                                        // [4 waves][NCH][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.y * NCH;
+  const int nsteps = K / KH;
+  const long long n_tiles = (M + 15) / 16;
+  const long long wid = (long long)blockIdx.x * 4 + wave, wstride = (long long)gridDim.x * 4;
+  const long long my_tiles = wid < n_tiles ? (n_tiles - wid + wstride - 1) / wstride : 0;
+  const long long n_it = my_tiles * nsteps;
+
+  f32x4 xr[PF][NF];
+  long long pf_tile = wid; int pf_step = 0;
+  auto fetch = [&](f32x4 (&dst)[NF]) {
+    const long long m = pf_tile * 16 + lm;
+    const float* xp = x + m * x_ld + pf_step * KH;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+      dst[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // fp32 MFMA: k-steps 16 j .. 16 j + 15, this lane the quad 4 g;  split path: k 32 (j / 2) + 8 g + 4 (j & 1)
+      const int k = SP ? 32 * (j >> 1) + 8 * g + 4 * (j & 1) : 16 * j + 4 * g;
+      if (m < M) dst[j] = *reinterpret_cast<const f32x4*>(xp + k);
+    }
+    if (++pf_step == nsteps) { pf_step = 0; pf_tile += wstride; }
+  };
+#pragma unroll
+  for (int u = 0; u < PF; ++u)
+    if (u < n_it) fetch(xr[u]);
+
+  {   // weight slice -> LDS (all loads of a batch in flight before the first store), table meanwhile
+    constexpr int WB = 16;
+    const int NQ = NCH / 4, KQ = K / 4;
+    const int total = WT ? K * NQ : NCH * KQ;
+    f32x4 wr[WB];
+    auto wload = [&](int base) {
+#pragma unroll
+      for (int j = 0; j < WB; ++j) {
+        const int i = base + tid + 256 * j;
+        wr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < total) {
+          if (WT) {
+            const int k = i / NQ, nq = i - k * NQ;
+            if (n0 + 4 * nq < Nc) wr[j] = *reinterpret_cast<const f32x4*>(w + (long long)k * w_ld + n0 + 4 * nq);
+          } else {
+            const int r = i / KQ, kq = i - r * KQ;
+            if (n0 + r < Nc) wr[j] = *reinterpret_cast<const f32x4*>(w + (long long)(n0 + r) * w_ld + 4 * kq);
+          }
+        }
+      }
+    };
+    auto wstore = [&](int base) {
+#pragma unroll
+      for (int j = 0; j < WB; ++j) {
+        const int i = base + tid + 256 * j;
+        if (i >= total) continue;
+        if constexpr (SP) {
+          bf16x4 h, m, l;
+          split3(wr[j], h, m, l);
+          const int plane = NCH * LDWh;
+          if (WT) {
+            const int k = i / NQ, nq = i - k * NQ;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bf16_t* d = Wh + (4 * nq + e) * LDWh + k; d[0] = h[e]; d[plane] = m[e]; d[2 * plane] = l[e]; }
+          } else {
+            const int r = i / KQ, kq = i - r * KQ;
+            bf16_t* d = Wh + r * LDWh + 4 * kq;
+            *reinterpret_cast<bf16x4*>(d) = h; *reinterpret_cast<bf16x4*>(d + plane) = m; *reinterpret_cast<bf16x4*>(d + 2 * plane) = l;
+          }
+        } else if (WT) {
+          const int k = i / NQ, nq = i - k * NQ;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) Ws[(4 * nq + e) * LDW + k] = wr[j][e];
+        } else {
+          const int r = i / KQ, kq = i - r * KQ;
+          *reinterpret_cast<f32x4*>(Ws + r * LDW + 4 * kq) = wr[j];
+        }
+      }
+    };
+    wload(0);
+    tab_to_lds(Tb, K, K, it, tid, 256);
+    wstore(0);
+    for (int base = 256 * WB; base < total; base += 256 * WB) { wload(base); wstore(base); }
+  }
+  __syncthreads();                                                // the only barrier before the statistics epilogue
+
+  f32x4 acc[CTW], s1[CTW], s2[CTW];
+#pragma unroll
+  for (int c = 0; c < CTW; ++c) { acc[c] = f32x4{0.f, 0.f, 0.f, 0.f}; s1[c] = acc[c]; s2[c] = acc[c]; }
+  long long cur_tile = wid; int cur_step = 0;
+  for (long long f = 0; f < n_it; f += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      if (f + u >= n_it) break;
+      const int k0 = cur_step * KH;
+      // ---- transform in registers ----
+      f32x4 xa[NF];
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        const int k = k0 + (SP ? 32 * (j >> 1) + 8 * g + 4 * (j & 1) : 16 * j + 4 * g);
+        xa[j] = tf4_tab(xr[u][j], *reinterpret_cast<const f32x4*>(Tb + k), *reinterpret_cast<const f32x4*>(Tb + K + k),
+                        *reinterpret_cast<const f32x4*>(Tb + 2 * K + k));
+      }
+      if (cur_tile * 16 + lm >= M) {                              // rows past the end contribute nothing (and store nothing)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) xa[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (f + u + PF < n_it) fetch(xr[u]);
+      // ---- MFMAs against the resident weights ----
+      if constexpr (SP) {
+        const int plane = NCH * LDWh;
+#pragma unroll
+        for (int kk = 0; kk < KH / 32; ++kk) {
+          bf16x4 h0, m0, l0, h1, m1, l1;
+          split3(xa[2 * kk], h0, m0, l0);
+          split3(xa[2 * kk + 1], h1, m1, l1);
+          const bf16x8 xh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+          const bf16x8 xm = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+          const bf16x8 xl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+          const bf16_t* wrow = Wh + lm * LDWh + k0 + 32 * kk + 8 * g;
+#pragma unroll
+          for (int c = 0; c < CTW; ++c) {
+            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wrow + c * 16 * LDWh);
+            const bf16x8 wm = *reinterpret_cast<const bf16x8*>(wrow + c * 16 * LDWh + plane);
+            const bf16x8 wl = *reinterpret_cast<const bf16x8*>(wrow + c * 16 * LDWh + 2 * plane);
+            f32x4 d = acc[c];
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, d, 0, 0, 0);
+            acc[c] = d;
+          }
+        }
+      } else {
+        const float* wrow = Ws + lm * LDW + k0 + 4 * g;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+#pragma unroll
+          for (int c = 0; c < CTW; ++c) {
+            const f32x4 wa = *reinterpret_cast<const f32x4*>(wrow + c * 16 * LDW + 16 * j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[e], xa[j][e], acc[c], 0, 0, 0);
+          }
+        }
+      }
+      if (++cur_step == nsteps) {
+        cur_step = 0;
+        const long long m = cur_tile * 16 + lm;
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) {
+          const int n = n0 + c * 16 + 4 * g;
+          f32x4 v = acc[c];
+          acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (m >= M || n >= Nc) continue;
+          float* op = out + m * out_ld + n;
+          if (accumulate) v += *reinterpret_cast<const f32x4*>(op);
+          *reinterpret_cast<f32x4*>(op) = v;
+          s1[c] += v;
+          s2[c] += v * v;
+        }
+        cur_tile += wstride;
+      }
+    }
+  }
+  if (stats) {
+    wave_stats_to_lds<CTW>(s1, s2, red + wave * 2 * NCH, lane, Nc - n0);
+    __syncthreads();
+    if (tid < 2 * NCH && n0 + (tid >> 1) < Nc)
+      atomicAdd(&stats[(blockIdx.x % nrep) * rep_stride + 2 * n0 + tid],
+                (double)(red[tid] + red[2 * NCH + tid] + red[4 * NCH + tid] + red[6 * NCH + tid]));
+  }
+}
+
+static size_t pw_dir_lds(int ctw, int K, bool split) {
+  const size_t tail = ((size_t)3 * K + 8 * 16 * ctw) * sizeof(float);
+  return (split ? (size_t)6 * 16 * ctw * (K + 16) : (size_t)4 * 16 * ctw * (K + 8)) + tail;
+}
+
+template <int CTW, bool WT, bool SP>
+static void launch_pw_dir_t(const ConvArgs& a, long long M, hipStream_t s) {
+  const int K = a.cin;
+  const size_t smem = pw_dir_lds(CTW, K, SP);
+  auto kern = pw_dir_kernel<CTW, WT, SP>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const long long n_tiles = (M + 15) / 16;
+  const int ny = (a.cout + 16 * CTW - 1) / (16 * CTW), nz = a.n_slots > 1 ? a.n_slots : 1;
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / smem));
+  long long gx = (256LL * per_cu + (long long)ny * nz - 1) / ((long long)ny * nz);
+  if (ny > 1) gx = std::max<long long>(8, (gx + 7) / 8 * 8);
+  gx = std::min<long long>(gx, (n_tiles + 3) / 4);
+  dim3 grid((unsigned)gx, (unsigned)ny, (unsigned)nz);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const float*)a.in, a.in_ld, a.itab, a.w, WT ? a.cout : a.cin,
+                     (float*)a.out, a.out_ld, M, K, a.cout, a.accumulate, a.stats, a.stats_rep_stride,
+                     a.stats_nrep > 0 ? a.stats_nrep : JN_NREP, a.skip_flag, a.skip_when, a.in_slot_stride, a.out_slot_stride,
+                     a.tab_slot_stride);
+}
+
+// ctw = channel tiles per workgroup slice (0: automatic — the widest slice <= 128 channels whose weights leave room for two
+// workgroups per CU); returns -1 when the shape does not fit (K % 64, slice too large).
+int launch_pw_dir(const ConvArgs& a, int ctw, int split, hipStream_t s) {
+  const long long M = (long long)a.N * a.H * a.W;
+  const int K = a.cin, N = a.cout;
+  if (K % 64 != 0) return -1;
+  if (!ctw) {
+    // 64-channel slices measured best on every shape of the nano PAFPN (tools/pwbench.hip: 28x28 128 -> 128 28.4 us
+    // against 29.3 with 128-channel and 32.1 with 32-channel slices); narrower only where the weights would not leave
+    // room for two workgroups per CU (K = 512)
+    for (int c : {4, 2}) {
+      if (16 * c > N && c > 2) continue;
+      if (pw_dir_lds(c, K, split != 0) <= 78 * 1024) { ctw = c; break; }
+    }
+    if (!ctw) return -1;
+  }
+  if (pw_dir_lds(ctw, K, split != 0) > 160 * 1024) return -1;
+  const bool wt = a.w_transposed != 0;
+#define JN_PD(C_)                                                                                   \
+  if (ctw == C_) {                                                                                  \
+    if (split) { if (wt) launch_pw_dir_t<C_, true, true>(a, M, s); else launch_pw_dir_t<C_, false, true>(a, M, s); }     \
+    else { if (wt) launch_pw_dir_t<C_, true, false>(a, M, s); else launch_pw_dir_t<C_, false, false>(a, M, s); }         \
+    return 0;                                                                                       \
+  }
+  JN_PD(8) JN_PD(4) JN_PD(2)
+#undef JN_PD
+  return -1;
+}
+
+static size_t pw_res_lds(int ct, int kc, int bm, int K, bool split) {
+  const size_t tail = ((size_t)3 * K + 32 * ct * 4) * sizeof(float);
+  if (split) return (size_t)6 * 16 * ct * (K + 16) + (size_t)12 * bm * (kc + 16) + tail;
+  return ((size_t)16 * ct * (K + 8) + 2 * bm * (kc + 8)) * sizeof(float) + tail;
+}
+
+template <int CT, int KC, int BM, int PD, bool WT, bool SP>
 static void launch_pw_res_t(const ConvArgs& a, long long M, int max_wg_per_cu, hipStream_t s) {
   const int K = a.cin;
-  const size_t smem = ((size_t)16 * CT * (K + 8) + 2 * BM * (KC + 8) + 3 * K + 32 * CT * 4) * sizeof(float);
-  auto kern = pw_res_kernel<CT, KC, BM, PD, WT>;
+  const size_t smem = pw_res_lds(CT, KC, BM, K, SP);
+  auto kern = pw_res_kernel<CT, KC, BM, PD, WT, SP>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -242,8 +579,8 @@ static void launch_pw_res_t(const ConvArgs& a, long long M, int max_wg_per_cu, h
   int per_cu = (int)std::min<size_t>((size_t)max_wg_per_cu, (160 * 1024) / smem);
   if (per_cu < 1) per_cu = 1;
   const int nz = a.n_slots > 1 ? a.n_slots : 1;
-  long long gx = (256LL * per_cu) / ((long long)ny * nz);
-  gx = std::max<long long>(8, gx / 8 * 8);
+  long long gx = (256LL * per_cu + (long long)ny * nz - 1) / ((long long)ny * nz);
+  if (ny > 1) gx = std::max<long long>(8, (gx + 7) / 8 * 8);     // the N slices of a pixel tile on one XCD (shared L2)
   if (gx > n_tiles) gx = n_tiles;
   dim3 grid((unsigned)gx, (unsigned)ny, (unsigned)nz);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const float*)a.in, a.in_ld, a.itab, a.w,
@@ -261,37 +598,72 @@ bool pw_res_supported(const ConvArgs& a) {
   return true;
 }
 
-// Picks the weight slice (CT channel tiles per workgroup) so that the slice fits LDS with the two pixel buffers, and
-// enough slices / tiles exist to occupy the chip.
+// The production route for wide 1x1 layers (forward and data gradient): the barrier-free weight-stationary kernel with
+// split-bf16 products (JN_PW_EXACT=1: fp32 MFMA).  Shapes it measured no better on stay with their old kernels:
+// 64 -> 64 on fewer than 65536 pixels (pw_mfma_kernel, 14.3 against 14.6 us at 28x28).
+int launch_pw_wide(const ConvArgs& a, hipStream_t s) {
+  static const bool off = std::getenv("JN_NO_PW_DIR") != nullptr;
+  static const bool exact = std::getenv("JN_PW_EXACT") != nullptr;
+  if (off || !pw_res_supported(a) || a.cin % 64 != 0) return -1;
+  const long long M = (long long)a.N * a.H * a.W * (a.n_slots > 1 ? a.n_slots : 1);
+  if (a.cin == 64 && a.cout == 64 && M < 65536) return -1;
+  return launch_pw_dir(a, 0, exact ? 0 : 1, s);
+}
+
+// Picks the configuration: the weight slice (CT channel tiles per workgroup) must fit LDS with the two pixel buffers;
+// two workgroups per CU whenever a slice allows it (one workgroup's staging / stores run under the other's MFMAs); more,
+// narrower slices when the problem has too few pixel tiles to occupy the chip.
 int launch_pw_res(const ConvArgs& a, hipStream_t s) {
   const long long M = (long long)a.N * a.H * a.W;
   const int K = a.cin, N = a.cout;
   const int nz = a.n_slots > 1 ? a.n_slots : 1;
-  // largest CT in {8, 4, 2} whose slice + buffers fit 160 KB (leaving room for two workgroups when the slice is small)
-  auto lds = [&](int ct, int kc, int bm) { return ((size_t)16 * ct * (K + 8) + 2 * bm * (kc + 8) + 3 * K + 128 * ct) * sizeof(float); };
-  const int kc = (K % 64 == 0) ? 64 : 32;
-  int ct = 8;
-  while (ct > 2 && (16 * ct > N || lds(ct, kc, 64) > 150 * 1024)) ct >>= 1;
-  if (lds(ct, kc, 64) > 150 * 1024) return -1;
-  // small problems: more, narrower slices so that >= ~256 workgroups exist
-  const long long tiles64 = (M + 63) / 64;
-  while (ct > 2 && tiles64 * nz * ((N + 16 * ct - 1) / (16 * ct)) < 320) ct >>= 1;
-  static const char* force_env = std::getenv("JN_PW_RES_CFG");       // "ct,kc,bm,pd": tuning aid
+  static const bool exact = std::getenv("JN_PW_EXACT") != nullptr;     // fp32 MFMA instead of the split-bf16 products
+  static const char* force_env = std::getenv("JN_PW_RES_CFG");         // "ct,kc,bm,pd,split": tuning aid (0 = automatic)
   const char* force = g_pw_res_force ? g_pw_res_force : force_env;
-  int bm = 64, pd = 2, kcc = kc;
-  if (force) { int f_ct, f_kc, f_bm, f_pd; if (sscanf(force, "%d,%d,%d,%d", &f_ct, &f_kc, &f_bm, &f_pd) == 4) { if (f_ct) ct = f_ct; if (f_kc && K % f_kc == 0) kcc = f_kc; if (f_bm) bm = f_bm; if (f_pd) pd = f_pd; } }
-  const bool wt = a.w_transposed != 0;
-#define JN_PR(CT_, KC_, BM_, PD_)                                                                          \
-  if (ct == CT_ && kcc == KC_ && bm == BM_ && pd == PD_) {                                                 \
-    if (wt) launch_pw_res_t<CT_, KC_, BM_, PD_, true>(a, M, 2, s); else launch_pw_res_t<CT_, KC_, BM_, PD_, false>(a, M, 2, s); \
-    return 0;                                                                                              \
+  int sp = exact ? 0 : 1;
+  int kc = (K % 64 == 0) ? 64 : 32, bm = 32, pd = 2, ct = 0;
+  if (force) {
+    int f_ct = 0, f_kc = 0, f_bm = 0, f_pd = 0, f_sp = -1;
+    if (sscanf(force, "%d,%d,%d,%d,%d", &f_ct, &f_kc, &f_bm, &f_pd, &f_sp) >= 4) {
+      if (f_ct) ct = f_ct;
+      if (f_kc && K % f_kc == 0) kc = f_kc;
+      if (f_bm) bm = f_bm;
+      if (f_pd) pd = f_pd;
+      if (f_sp >= 0) sp = f_sp;
+    }
   }
-  JN_PR(8, 64, 64, 2) JN_PR(4, 64, 64, 2) JN_PR(2, 64, 64, 2)
-  JN_PR(8, 32, 64, 2) JN_PR(4, 32, 64, 2) JN_PR(2, 32, 64, 2)
-  JN_PR(8, 64, 64, 1) JN_PR(4, 64, 64, 1) JN_PR(2, 64, 64, 1)
-  JN_PR(8, 64, 32, 2) JN_PR(4, 64, 32, 2) JN_PR(2, 64, 32, 2)
-  JN_PR(8, 64, 128, 2) JN_PR(4, 64, 128, 2)
+  if (!ct) {
+    const long long tiles = (M + bm - 1) / bm;
+    for (int c : {8, 4, 2}) {                  // widest slice that leaves room for two workgroups per CU
+      if (16 * c > N && c > 2) continue;
+      if (pw_res_lds(c, kc, bm, K, sp) <= 78 * 1024) { ct = c; break; }
+    }
+    if (!ct)
+      for (int c : {8, 4, 2}) {
+        if (16 * c > N && c > 2) continue;
+        if (pw_res_lds(c, kc, bm, K, sp) <= 156 * 1024) { ct = c; break; }
+      }
+    if (!ct) return -1;
+    while (ct > 2 && tiles * nz * ((N + 16 * ct - 1) / (16 * ct)) < 400) ct >>= 1;
+  }
+  if (pw_res_lds(ct, kc, bm, K, sp) > 160 * 1024) return -1;
+  const bool wt = a.w_transposed != 0;
+#define JN_PR2(CT_, KC_, BM_, SP_)                                                                                            \
+  if (ct == CT_ && kc == KC_ && bm == BM_ && sp == SP_ && pd == 2) {                                                          \
+    if (wt) launch_pw_res_t<CT_, KC_, BM_, 2, true, SP_ != 0>(a, M, 2, s); else launch_pw_res_t<CT_, KC_, BM_, 2, false, SP_ != 0>(a, M, 2, s); \
+    return 0;                                                                                                                 \
+  }
+#define JN_PR(CT_, KC_, BM_) JN_PR2(CT_, KC_, BM_, 0) JN_PR2(CT_, KC_, BM_, 1)
+  JN_PR(8, 64, 64) JN_PR(4, 64, 64) JN_PR(2, 64, 64)
+  JN_PR(8, 64, 32) JN_PR(4, 64, 32) JN_PR(2, 64, 32)
+  JN_PR(8, 32, 64) JN_PR(4, 32, 64) JN_PR(2, 32, 64)
+  JN_PR(8, 32, 32) JN_PR(4, 32, 32) JN_PR(2, 32, 32)
 #undef JN_PR
+#undef JN_PR2
+  if (ct == 8 && kc == 64 && bm == 64 && pd == 1) {
+    if (wt) launch_pw_res_t<8, 64, 64, 1, true, false>(a, M, 2, s); else launch_pw_res_t<8, 64, 64, 1, false, false>(a, M, 2, s);
+    return 0;
+  }
   return -1;
 }
 

@@ -4,6 +4,7 @@
 // of its phases for a few workgroups.   build: hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/pwbench.hip -o tools/pwbench
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -65,9 +66,9 @@ int main(int argc, char** argv) {
     ConvArgs a2 = a; a2.stats = nullptr;
     const float t_old_ns = time_it([&] { launch_pw_types<float, float, false>(a2, s); });
     printf("%2dx%2d K=%3d N=%3d  %6.1f MB %5.2f GF | stream %6.1f us | pw_mfma %6.1f (no stats %6.1f)", sh.hw, sh.hw, sh.K, sh.N, mb, gf, t_stream, t_old, t_old_ns);
-    const char* cfgs[] = {"0,0,64,2", "0,0,32,2", "0,0,128,2", "0,0,64,1", "8,0,64,2", "4,0,64,2", "2,0,64,2", "4,0,32,2", "2,0,32,2"};
+    const char* cfgs[] = {"0,0,0,2,0", "0,0,0,2,1"};
     for (const char* c : cfgs) {
-      int ct, kc, bm, pd; sscanf(c, "%d,%d,%d,%d", &ct, &kc, &bm, &pd);
+      int ct, kc, bm, pd, sp; sscanf(c, "%d,%d,%d,%d,%d", &ct, &kc, &bm, &pd, &sp);
       if (ct && 16 * ct > sh.N) { printf(" | %s  skip", c); continue; }
       g_pw_res_force = c;
       hipError_t pre = hipGetLastError(); (void)pre;
@@ -77,6 +78,43 @@ int main(int argc, char** argv) {
       const float tt = time_it([&] { launch_pw_res(a, s); });
       printf(" | %s %6.1f", c, tt);
     }
+    for (int sp = 0; sp < 2; ++sp)
+      for (int ctw : {8, 4, 2}) {
+        if (16 * ctw > sh.N) { printf(" | dir%d/%d skip", ctw, sp); continue; }
+        int rc = launch_pw_dir(a, ctw, sp, s);
+        hipError_t e = hipDeviceSynchronize();
+        if (rc != 0 || e != hipSuccess || hipGetLastError() != hipSuccess) { printf(" | dir%d/%d  n/a", ctw, sp); continue; }
+        const float tt = time_it([&] { launch_pw_dir(a, ctw, sp, s); });
+        printf(" | dir%d/%d %6.1f", ctw, sp, tt);
+      }
+    {
+      std::vector<float> ref((size_t)M * sh.N), got((size_t)M * sh.N);
+      launch_pw_types<float, float, false>(a2, s); CK(hipDeviceSynchronize());
+      CK(hipMemcpy(ref.data(), out, ref.size() * 4, hipMemcpyDeviceToHost));
+      for (int sp = 0; sp < 2; ++sp) {
+        CK(hipMemset(out, 0, ref.size() * 4));
+        if (launch_pw_dir(a2, 0, sp, s) != 0) { printf(" | dir-err[%d] n/a", sp); continue; }
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(got.data(), out, got.size() * 4, hipMemcpyDeviceToHost));
+        double md = 0;
+        for (size_t i = 0; i < ref.size(); ++i) md = std::max(md, (double)std::fabs(ref[i] - got[i]));
+        printf(" | dir-err[%d] %.2e", sp, md);
+      }
+    }
+    {   // accuracy of the automatic configurations against pw_mfma_kernel (exact fp32 fma chain)
+      std::vector<float> ref((size_t)M * sh.N), got((size_t)M * sh.N);
+      launch_pw_types<float, float, false>(a2, s); CK(hipDeviceSynchronize());
+      CK(hipMemcpy(ref.data(), out, ref.size() * 4, hipMemcpyDeviceToHost));
+      for (const char* c : {"0,0,0,2,0", "0,0,0,2,1"}) {
+        g_pw_res_force = c;
+        CK(hipMemset(out, 0, ref.size() * 4));
+        launch_pw_res(a2, s); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(got.data(), out, got.size() * 4, hipMemcpyDeviceToHost));
+        double md = 0, mr = 0;
+        for (size_t i = 0; i < ref.size(); ++i) { md = std::max(md, (double)std::fabs(ref[i] - got[i])); mr = std::max(mr, (double)std::fabs(ref[i])); }
+        printf(" | err[%s] %.2e (max |ref| %.2f)", c, md, mr);
+      }
+    }
     g_pw_res_force = nullptr;
     printf("\n");
     fflush(stdout);
@@ -85,7 +123,7 @@ int main(int argc, char** argv) {
   {   // phase stamps of the 28x28 128 -> 128 layer: entry, prologue issued, barrier, then per chunk (staged, barrier, MFMAs done[, tile stored])
     long long* dbg; const int NW = 256;
     CK(hipMalloc(&dbg, NW * 32 * 8));
-    for (const char* c : {"0,0,64,2", "0,0,32,2"}) {
+    for (const char* c : {"4,0,32,2,0", "4,0,32,2,1", "8,0,32,2,1"}) {
       for (int hw : {28, 14}) {
         CK(hipMemset(dbg, 0, NW * 32 * 8));
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_pwres_dbg), &dbg, sizeof(dbg)));
