@@ -161,13 +161,15 @@ int jn_gather_patches_indexed(const float* images_dev, const int64_t* image_inde
 /* ---- detection augmentation ------------------------------------- */
 /* Trainer.init_detection's on-device chain (src/trainer.py:176-186, applied at src/reinforce.py:332-333 and
  * src/supervised.py:855-861, 884-885) fused into one pass: RandomPlanckianJitter (per-patch red / blue gains,
- * clamp to [0,1]) -> RandomGrayscale -> RandomGaussianBlur 3x3 (reflect border) -> RandomGaussianNoise ->
- * RandomMotionBlur 3x3 (zero border).  RandomPlasmaShadow is not implemented (kornia's fractal generator is not in
- * the reference).  patches [N,3,P,P] f32 -> out (must not alias); params [N,16] f32 per patch = r_gain, b_gain,
- * gray flag, Gaussian centre weight, Gaussian side weight, noise std, motion kernel k[3][3] row-major, pad; an op
- * a patch did not draw is encoded as the identity (1, 1, 0, 1, 0, 0, delta).  noise_dev: optional [N,3,P,P]
+ * clamp to [0,1]) -> RandomGrayscale -> RandomGaussianBlur 3x3 (reflect border) -> RandomPlasmaShadow (shade where a
+ * value-noise fractal of the patch falls below `quantity`: kornia's diamond-square map restated as a counter-based
+ * fractal, csrc/kernels_aug.hip) -> RandomGaussianNoise -> RandomMotionBlur 3x3 (zero border).  patches [N,3,P,P]
+ * f32 -> out (must not alias); params [N,JN_AUG_NPARAM] f32 per patch = r_gain, b_gain, gray flag, Gaussian centre
+ * weight, Gaussian side weight, noise std, motion kernel k[3][3] row-major, shade intensity, shade quantity,
+ * roughness, fractal stretch, pad; an op a patch did not draw is encoded as the identity
+ * (1, 1, 0, 1, 0, 0, delta, 0, ...).  noise_dev: optional [N,3,P,P]
  * standard-normal field (parity runs); NULL = counter-based generator seeded by `seed`. */
-#define JN_AUG_NPARAM 16
+#define JN_AUG_NPARAM 20
 int jn_augment_patches(const float* in_dev, float* out_dev, const float* params_dev, const float* noise_dev,
                        uint64_t seed, int N, int P, void* stream);
 

@@ -10,8 +10,11 @@ fused HIP pass (``jn_augment_patches``): one read and one write of every element
 kornia is not part of the reference tree, so its parameter conventions are restated from its documentation
 (parity unpinned, oracle/augment_ref.py is the checker of the arithmetic, not of kornia):
 * PlanckianJitter multiplies red and blue by a (r/g, b/g) pair drawn from a table of illuminants and clamps to [0, 1];
-  the CIED table itself is data of kornia — pass it as ``planckian_coeffs`` [K, 2]; without it the op is skipped.
-* PlasmaShadow needs kornia's diamond-square fractal generator and is not implemented.
+  the CIED table is regenerated from the CIE D-series formulas (``planckian_cied_table``; kornia's own numbers are data of
+  kornia) and can be overridden with ``planckian_coeffs`` [K, 2].
+* PlasmaShadow multiplies the (blurred) patch by 1 + shade_intensity wherever a per-patch fractal falls below
+  shade_quantity.  kornia's recursive diamond-square generator is restated as counter-based fractional-Brownian value
+  noise with the same octave structure (csrc/kernels_aug.hip ``aug_plasma``), which every pixel evaluates independently.
 """
 import math
 from typing import Optional
@@ -21,7 +24,38 @@ import torch
 from . import _lib
 from ._lib import check, ptr
 
-NPARAM = 16
+NPARAM = 20
+PLASMA_OCTAVES = 7          # csrc/kernels_aug.hip AUG_OCT
+
+
+def planckian_cied_table() -> torch.Tensor:
+    """(r/g, b/g) white-balance gains of the CIE D-series daylight illuminants 4000 K .. 15000 K in 500 K steps: the
+    illuminant family of kornia's RandomPlanckianJitter(mode="CIED") (src/trainer.py:177).  kornia's own table is data
+    of a package that is not in the reference tree, so it is regenerated here from the published CIE formulas
+    (chromaticity x_D(T), y_D = -3 x_D^2 + 2.87 x_D - 0.275; XYZ -> linear sRGB, D65 matrix), normalised to green."""
+    rows = []
+    for T in range(4000, 15001, 500):
+        t = float(T)
+        if t <= 7000.0:
+            x = -4.6070e9 / t ** 3 + 2.9678e6 / t ** 2 + 0.09911e3 / t + 0.244063
+        else:
+            x = -2.0064e9 / t ** 3 + 1.9018e6 / t ** 2 + 0.24748e3 / t + 0.237040
+        y = -3.0 * x * x + 2.870 * x - 0.275
+        X, Y, Z = x / y, 1.0, (1.0 - x - y) / y
+        r = 3.2406 * X - 1.5372 * Y - 0.4986 * Z
+        g = -0.9689 * X + 1.8758 * Y + 0.0415 * Z
+        b = 0.0557 * X - 0.2040 * Y + 1.0570 * Z
+        rows.append((r / g, b / g))
+    return torch.tensor(rows, dtype=torch.float32)
+
+
+def plasma_stretch(roughness: torch.Tensor) -> torch.Tensor:
+    """1 / (5 sigma) of the value-noise fractal (octave weights roughness^o): stands in for the per-sample min-max
+    normalisation of kornia's plasma map.  A bilinearly interpolated uniform lattice has variance ~ (1/12) (2/3)^2."""
+    o = torch.arange(PLASMA_OCTAVES, dtype=torch.float32)
+    w = roughness[:, None] ** o[None, :]
+    sigma = torch.sqrt((w * w).sum(1) * (1.0 / 12.0) * (4.0 / 9.0)) / w.sum(1)
+    return 1.0 / (5.0 * sigma)
 
 
 def gaussian_weights3(sigma: torch.Tensor):
@@ -60,9 +94,12 @@ class DetectionAugment:
 
     def __init__(self, planckian_coeffs: Optional[torch.Tensor] = None, p_planckian: float = 0.5, p_gray: float = 0.2,
                  p_blur: float = 0.5, sigma=(0.1, 2.0), p_noise: float = 0.5, noise_std: float = 0.05,
-                 p_motion: float = 0.3, angle=(-180.0, 180.0), seed: Optional[int] = None):
-        self.planckian = planckian_coeffs
+                 p_motion: float = 0.3, angle=(-180.0, 180.0), p_shadow: float = 0.5, shade_intensity=(-0.2, 0.0),
+                 shade_quantity=(0.0, 0.4), roughness=(0.1, 0.7), seed: Optional[int] = None):
+        # the CIED table is embedded (planckian_cied_table); pass another [K, 2] table of (r/g, b/g) gains to override it
+        self.planckian = planckian_cied_table() if planckian_coeffs is None else planckian_coeffs
         self.p = (p_planckian, p_gray, p_blur, p_noise, p_motion)
+        self.p_shadow, self.shade_intensity, self.shade_quantity, self.roughness = p_shadow, shade_intensity, shade_quantity, roughness
         self.sigma, self.noise_std, self.angle = sigma, noise_std, angle
         self.gen = torch.Generator()
         if seed is not None:
@@ -70,7 +107,8 @@ class DetectionAugment:
         self.calls = 0
 
     def sample_params(self, n: int) -> torch.Tensor:
-        """[n, NPARAM] = r_gain, b_gain, gray, w0, w1, noise_std, k[9], pad — identity where an op was not drawn."""
+        """[n, NPARAM] = r_gain, b_gain, gray, w0, w1, noise_std, k[9], shade intensity, shade quantity, roughness, fractal
+        stretch, pad — identity where an op was not drawn."""
         g = self.gen
         u = torch.rand((n, 5), generator=g)
         prm = torch.zeros((n, NPARAM))
@@ -90,6 +128,15 @@ class DetectionAugment:
         ang = self.angle[0] + (self.angle[1] - self.angle[0]) * torch.rand(n, generator=g)
         for i in torch.nonzero(u[:, 4] < self.p[4]).flatten().tolist():
             prm[i, 6:15] = motion_kernel3(float(ang[i])).flatten()
+        # RandomPlasmaShadow(shade_intensity=(-0.2, 0), shade_quantity=(0, 0.4), p=0.5), roughness kornia's default (0.1, 0.7)
+        us = torch.rand((n, 4), generator=g)
+        on = us[:, 0] < self.p_shadow
+        lerp = lambda r, t: r[0] + (r[1] - r[0]) * t
+        rough = lerp(self.roughness, us[:, 3])
+        prm[on, 15] = lerp(self.shade_intensity, us[on, 1])
+        prm[on, 16] = lerp(self.shade_quantity, us[on, 2])
+        prm[on, 17] = rough[on]
+        prm[on, 18] = plasma_stretch(rough)[on]
         return prm
 
     def __call__(self, patches: torch.Tensor, params: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -107,6 +154,7 @@ class DetectionAugment:
             return out
         self.calls += 1
         seed = (int(self.gen.initial_seed()) * 1000003 + self.calls) & 0xFFFFFFFFFFFFFFFF
+        self.last_seed = seed                      # seeds the device noise field and the plasma fractals of this call
         lib = _lib.load_library()
         check(lib.jn_augment_patches(ptr(x), ptr(out), ptr(prm), ptr(nz), seed, n, P, _lib.current_stream(x.device)),
               "jn_augment_patches")

@@ -228,7 +228,7 @@ int launch_nchw_to_nhwc_grad(const float* in, float* out, int out_ld, int C, int
 #define JN_DW_S2_PAD 4      // LDS pixel-stride padding (floats) of the stride-2 depthwise tiles; 8 removes the bank
                             // conflicts the PMC shows (0.3-0.4 of the LDS-active cycles) but not a microsecond: 126.9 vs 127.3 ms
 #endif
-constexpr int AUG_NPARAM = 16;
+constexpr int AUG_NPARAM = 20;   // ... + shade intensity, shade quantity, roughness, stretch (plasma shadow), 1 pad
 int launch_augment(const float* in, float* out, const float* params, const float* noise, unsigned long long seed, int N, int P,
                    hipStream_t s);
 int launch_gather(const float* images, const int64_t* positions, float* out, long long out_sample_stride,

@@ -1,6 +1,6 @@
 // On-device detection augmentation (Trainer.init_detection, src/trainer.py:176-186): the per-patch
-// chain  colour gains -> grayscale -> 3x3 Gaussian blur (reflect border) -> additive Gaussian noise -> 3x3 motion blur
-// (zero border)  in ONE pass over the patches: 4 B read + 4 B written per element instead of five kornia ops (>= 40 B).
+// chain  colour gains -> grayscale -> 3x3 Gaussian blur (reflect border) -> plasma shadow -> additive Gaussian noise ->
+// 3x3 motion blur (zero border)  in ONE pass over the patches: 4 B read + 4 B written per element instead of five kornia ops (>= 40 B).
 // Every patch carries its own parameters (AUG_NPARAM floats, sampled by the host mirror); an op a patch did not draw is
 // the identity (gains 1, centre weight 1, delta kernel, std 0).  HBM-bound stencil: 16x64 output tile per workgroup,
 // input tile + 2-pixel halo staged in LDS with the colour ops applied, the blurred + noised tile in a second LDS tile.
@@ -27,6 +27,36 @@ __device__ __forceinline__ float aug_normal(unsigned long long seed, unsigned lo
   return sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530718f * u2);
 }
 
+// RandomPlasmaShadow (src/trainer.py:180-182): kornia shades the image where a plasma fractal (diamond-square) falls
+// below `shade_quantity`.  A recursive generator does not fit a tiled one-pass kernel, so the fractal is restated as
+// fractional-Brownian value noise with the same octave structure: lattice spacing P/2, P/4, ... (AUG_OCT octaves),
+// octave o weighted roughness^o, every lattice value a counter-based hash of (patch seed, octave, iy, ix) — any pixel
+// of any tile evaluates it independently.  f in [0, 1]; the per-sample min-max normalisation of kornia's map becomes a
+// fixed stretch about 0.5 by the field's analytic spread (host side: params[18] = 1 / (5 sigma)).
+constexpr int AUG_OCT = 7;
+__device__ __forceinline__ float aug_lattice(unsigned seed, int o, int iy, int ix) {
+  const unsigned h = aug_hash(aug_hash((unsigned)ix * 0x9E3779B1u ^ (unsigned)iy * 0x85EBCA77u ^ (unsigned)(o + 1) * 0xC2B2AE3Du) ^ seed);
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float aug_plasma(unsigned seed, int y, int x, int P, float rough, float stretch) {
+  float f = 0.0f, wsum = 0.0f, wgt = 1.0f;
+#pragma unroll
+  for (int o = 0; o < AUG_OCT; ++o) {
+    const float cell = (float)P / (float)(2 << o);          // lattice spacing of the octave
+    const float fy = (float)y / cell, fx = (float)x / cell;
+    const int iy = (int)fy, ix = (int)fx;
+    const float ty = fy - (float)iy, tx = fx - (float)ix;
+    const float a = aug_lattice(seed, o, iy, ix), b = aug_lattice(seed, o, iy, ix + 1);
+    const float c = aug_lattice(seed, o, iy + 1, ix), d = aug_lattice(seed, o, iy + 1, ix + 1);
+    const float top = a + (b - a) * tx, bot = c + (d - c) * tx;
+    f += wgt * (top + (bot - top) * ty);
+    wsum += wgt;
+    wgt *= rough;
+  }
+  f = 0.5f + (f / wsum - 0.5f) * stretch;
+  return fminf(fmaxf(f, 0.0f), 1.0f);
+}
+
 __device__ __forceinline__ int reflect(int i, int n) {      // kornia / F.pad "reflect": -1 -> 1, n -> n - 2
   if (i < 0) i = -i;
   if (i >= n) i = 2 * n - 2 - i;
@@ -38,6 +68,7 @@ __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ 
                                                       unsigned long long seed, int P, int tiles_x) {
   __shared__ float Xs[3][AUG_XH][AUG_XW + 1];
   __shared__ float Gs[3][AUG_GH][AUG_GW + 1];
+  __shared__ float Sh[AUG_GH][AUG_GW + 1];                  // plasma-shadow multiplier of the tile + halo 1
   __shared__ float prm[AUG_NPARAM];
   const int n = blockIdx.y, tile = blockIdx.x, ty0 = (tile / tiles_x) * AUG_TH, tx0 = (tile % tiles_x) * AUG_TW;
   const int tid = threadIdx.x;
@@ -62,6 +93,18 @@ __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ 
     }
     Xs[0][yy][xx] = r; Xs[1][yy][xx] = g; Xs[2][yy][xx] = b;
   }
+  // ---- plasma shadow multiplier (after the blur, before the noise: the reference's op order) ----
+  const float sh_int = prm[15], sh_qty = prm[16], sh_rough = prm[17], sh_stretch = prm[18];
+  if (sh_int != 0.0f) {
+    const unsigned pseed = aug_hash((unsigned)seed ^ (unsigned)(seed >> 32) ^ ((unsigned)n * 0x9E3779B9u + 0x7F4A7C15u));
+    for (int i = tid; i < AUG_GH * AUG_GW; i += 256) {
+      const int yy = i / AUG_GW, xx = i - yy * AUG_GW;
+      const int y = ty0 - 1 + yy, x = tx0 - 1 + xx;
+      float m = 1.0f;
+      if (y >= 0 && y < P && x >= 0 && x < P && aug_plasma(pseed, y, x, P, sh_rough, sh_stretch) < sh_qty) m = 1.0f + sh_int;
+      Sh[yy][xx] = m;
+    }
+  }
   __syncthreads();
   // ---- Gaussian 3x3 (separable weights w1 w0 w1) + noise on tile + halo 1; outside the image = 0 (motion-blur border) ----
   for (int i = tid; i < 3 * AUG_GH * AUG_GW; i += 256) {
@@ -78,6 +121,7 @@ __global__ __launch_bounds__(256) void augment_kernel(const float* __restrict__ 
         const float bot = w1 * X[yy + 2][xx] + w0 * X[yy + 2][xx + 1] + w1 * X[yy + 2][xx + 2];
         v = w1 * top + w0 * mid + w1 * bot;
       }
+      if (sh_int != 0.0f) v *= Sh[yy][xx];
       if (nstd != 0.0f) {
         const int e = c * P * P + y * P + x;
         v += nstd * (noise ? noise[patch0 + e] : aug_normal(seed, (unsigned long long)(patch0 + e)));

@@ -459,9 +459,10 @@ NOISE_FACTOR = 4.0
 # rounded to fp32) where torch centres first ((z - mean) * invstd): on the near-constant deep maps of a random-init net
 # (|mean| >> std) the affine form loses ~log10(|mean| / std) digits.  Measured 2.2e-3 (448 px, T = 20).
 LOOSE_AT_FULL_SIZE = {"embed_fpn.0.weight": 5e-3}
-# The stem weight is the end of the longest backward chain (77 BatchNorm layers); depending on the seed its error lands
-# between 6e-4 and 2.3e-3 (fp32 oracle's own distance from fp64 on it: 3e-4 .. 1.6e-3): held to 5e-3 at every size.
-LOOSE_ALWAYS = {"gpt_backbone.backbone.stem.conv.conv.weight": 5e-3}
+# The stem's tensors are the end of the longest backward chain (77 BatchNorm layers); depending on the seed their error
+# lands between 6e-4 and 2.6e-3 (fp32 oracle's own distance from fp64 on it: 3e-4 .. 1.6e-3): held to 5e-3 at every size.
+LOOSE_ALWAYS = {"gpt_backbone.backbone.stem.conv.conv.weight": 5e-3, "gpt_backbone.backbone.stem.conv.bn.weight": 5e-3,
+                "gpt_backbone.backbone.stem.conv.bn.bias": 5e-3}
 
 
 def _check_grads(grads, oracle, skip_prefix=("yolox",), tol=GRAD_TOL, tag="", ref64=None):
@@ -1323,9 +1324,18 @@ def test_augment_fused_pass_vs_oracle(N, P):
     prm[0, 3], prm[0, 4], prm[0, 5] = 0.5, 0.25, 0.05                  # make sure every op is exercised at least once
     prm[0, 6:15] = torch.tensor([0.2, 0.1, 0.0, 0.1, 0.2, 0.1, 0.0, 0.1, 0.2])
     prm[-1, 0], prm[-1, 1], prm[-1, 2] = 1.4, 0.6, 1.0
+    from jolineedle_amd.augment import plasma_stretch
+    prm[0, 15], prm[0, 16], prm[0, 17] = -0.15, 0.45, 0.6              # plasma shadow on the first patch
+    prm[0, 18] = plasma_stretch(prm[0:1, 17])[0]
     got = aug(x.to(DEV), params=prm, noise=noise.to(DEV)).cpu()
-    want = augment_ref(x, prm, noise)
-    assert (got - want).abs().max() < 2e-6
+    want = augment_ref(x, prm, noise, seed=aug.last_seed)
+    bad = (got - want).abs() > 2e-6
+    # the shadow mask is a threshold on a fractal: a pixel whose value is within an fp32 rounding of the quantity may fall
+    # on the other side on the device (fma contraction) — at most a handful per patch
+    assert int(bad.sum()) <= max(3, int(1e-4 * got.numel())), int(bad.sum())
+    if P >= 37:
+        sh = (got[0] - augment_ref(x[:1], torch.cat((prm[:1, :15], torch.zeros(1, 5)), 1), noise[:1])[0]).abs() > 1e-4
+        assert 0.02 < float(sh.float().mean()) < 0.9                   # the shadow really darkened part of the patch
     ident = torch.zeros_like(prm); ident[:, 0] = ident[:, 1] = ident[:, 3] = ident[:, 10] = 1.0
     assert torch.equal(aug(x.to(DEV), params=ident).cpu(), x)          # undrawn ops are exact identities
 

@@ -191,9 +191,19 @@ def test_augment_parameter_sampling_and_kernels():
     assert abs(frac(prm[:, 10] != 1.0) - 0.3) < 0.04
     assert torch.allclose(prm[:, 3] + 2 * prm[:, 4], torch.ones(4000), atol=1e-6)
     assert torch.allclose(prm[:, 6:15].sum(1), torch.ones(4000), atol=1e-5)
-    no_table = DetectionAugment(seed=5).sample_params(100)
-    assert (no_table[:, :2] == 1.0).all()                               # Planckian jitter needs the caller's table
-    assert (DetectionAugment(p_planckian=0, p_gray=0, p_blur=0, p_noise=0, p_motion=0).sample_params(7) == ident).all()
+    assert abs(frac(prm[:, 15] != 0) - 0.5) < 0.04                      # RandomPlasmaShadow(p=0.5)
+    on = prm[:, 15] != 0
+    assert (prm[on, 15] >= -0.2).all() and (prm[on, 15] < 0).all() and (prm[on, 16] >= 0).all() and (prm[on, 16] <= 0.4).all()
+    assert (prm[on, 17] >= 0.1).all() and (prm[on, 17] <= 0.7).all() and (prm[on, 18] > 0.5).all()
+    # the embedded CIE D-series table (kornia's "CIED" mode): warm illuminants boost red, cold ones blue, ~neutral at D65
+    from jolineedle_amd.augment import planckian_cied_table
+    tab = planckian_cied_table()
+    assert tab.shape == (23, 2) and (tab[:, 0].diff() < 0).all() and (tab[:, 1].diff() > 0).all()
+    assert abs(float(tab[5, 0]) - 1.0) < 0.03 and abs(float(tab[5, 1]) - 1.0) < 0.03       # 6500 K
+    assert float(tab[0, 0]) > 1.2 and float(tab[0, 1]) < 0.7 and float(tab[-1, 1]) > 1.2
+    dflt = DetectionAugment(seed=5).sample_params(400)
+    assert abs(frac(dflt[:, 0] != 1.0) - 0.5) < 0.1                       # Planckian jitter works out of the box
+    assert (DetectionAugment(p_planckian=0, p_gray=0, p_blur=0, p_noise=0, p_motion=0, p_shadow=0).sample_params(7) == ident).all()
 
 
 def test_augment_oracle_identities():
@@ -211,6 +221,22 @@ def test_augment_oracle_identities():
     assert torch.allclose(augment_ref(x, p, nz), x + 0.05 * nz, atol=1e-6)
     p = ident.clone(); p[:, 3], p[:, 4] = 0.5, 0.25                      # blur keeps a constant image constant (reflect border)
     assert torch.allclose(augment_ref(torch.full_like(x, 0.3), p, nz), torch.full_like(x, 0.3), atol=1e-6)
+    # plasma shadow: a smooth fractal in [0, 1] around 0.5; the shaded fraction grows with the quantity; patches differ
+    from oracle.augment_ref import plasma_ref
+    from jolineedle_amd.augment import plasma_stretch
+    st = float(plasma_stretch(torch.tensor([0.5]))[0])
+    f0, f1 = plasma_ref(123, 0, 128, 0.5, st), plasma_ref(123, 1, 128, 0.5, st)
+    assert f0.min() >= 0 and f0.max() <= 1 and not (f0 == f1).all()
+    mean8 = np.mean([plasma_ref(7, k, 64, 0.5, st).mean() for k in range(8)])     # one patch is dominated by its 3 x 3 coarse lattice
+    assert abs(float(mean8) - 0.5) < 0.12
+    assert float(abs(f0[:, 1:] - f0[:, :-1]).mean()) < 0.05             # spatially smooth
+    assert (f0 < 0.2).mean() < (f0 < 0.4).mean() < (f0 < 0.6).mean()
+    xs = torch.full((1, 3, 128, 128), 0.5)
+    p = torch.zeros((1, NPARAM)); p[:, 0] = p[:, 1] = p[:, 3] = p[:, 10] = 1.0
+    p[:, 15], p[:, 16], p[:, 17], p[:, 18] = -0.2, 0.4, 0.5, st
+    y = augment_ref(xs, p, torch.zeros_like(xs), seed=123)
+    dark = (y - 0.4).abs() < 1e-6
+    assert bool((dark | ((y - 0.5).abs() < 1e-6)).all()) and 0.02 < float(dark.float().mean()) < 0.9
 
 
 # --------------------------------------------------------------------------------------
