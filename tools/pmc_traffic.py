@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter CSVs of the conv stack into HBM bytes per pass.
 
-usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <glimpse steps in the run> <batch> [train]
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <glimpse steps in the run> <batch> [train|eval] [json to update]
 (train: counters of a `--mode train` run — only the FORWARD conv-stack kernels are summed: the data-gradient launches
 of pw_mfma_kernel carry `true` as their third template argument and are left out)
 
@@ -13,8 +13,8 @@ import csv
 import re
 import sys
 
-CONV = ("stem_mfma_kernel", "dw3x3", "dwpw_eval_kernel", "pw_mfma_kernel", "pw_narrow_kernel", "addact_kernel", "spp_kernel", "upsample_kernel",
-        "conv3_mfma")
+CONV = ("stem_mfma_kernel", "dw3x3", "dwpw_eval_kernel", "pw_mfma_kernel", "pw_narrow_kernel", "pw_dir_kernel", "pw_res_kernel", "addact_kernel",
+        "spp_kernel", "upsample_kernel", "conv3_mfma", "bn_finalize_all_kernel")
 
 
 def short(name):
@@ -35,6 +35,8 @@ def load(path, counter):
         if not any(c in k for c in CONV + (("bn_finalize_kernel",) if TRAIN else ())):
             continue
         if TRAIN and k.startswith("pw_mfma_kernel") and ", true," in k:
+            continue
+        if TRAIN and re.match(r"pw_(dir|res)_kernel<\d+(, \d+, \d+, \d+)?, true", k):      # WT = true: data gradients
             continue
         tot[k] += float(r["Counter_Value"])
         calls[k] += 1
@@ -58,6 +60,12 @@ def main():
           f"writes {wr / 1e9:.3f} GB, total {(rd + wr) / 1e9:.3f} GB")
     print(f"# algorithmic (SURVEY 8d, fp32): 17.44 M elems * 4 B * {batch} = {algo / 1e9:.3f} GB -> traffic / algorithmic = "
           f"{(rd + wr) / algo:.2f}")
+    if len(sys.argv) > 6:                  # bench.py reads the per-pass bytes of the latest committed PMC passes from here
+        import json, os
+        path = sys.argv[6]
+        cur = json.load(open(path)) if os.path.exists(path) else {}
+        cur["train" if TRAIN else "rollout"] = rd + wr
+        json.dump(cur, open(path, "w"))
 
 
 if __name__ == "__main__":
