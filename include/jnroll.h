@@ -223,8 +223,9 @@ int jn_reinforce_backward(jn_ctx* ctx, const float* dlogprobs_dev, const float* 
  * convert, ON THE DEVICE, between the arena and a caller-owned buffer of >= arena floats that holds every trainable
  * tensor in the reference's (PyTorch) layout at the SAME offset as in the arena (jn_arena_segment): the Python module's
  * param.data / param.grad are views of such buffers, so torch code (clip_grad_value_, an optimizer's state, a
- * state_dict) sees real tensors.  what = 0 parameters, 1 gradients.  export: arena -> buffer (accumulate != 0: +=);
- * import: buffer -> arena. */
+ * state_dict) sees real tensors.  what = 0 parameters, 1 gradients, 2 / 3 AdamW exp_avg / exp_avg_sq (the optimiser
+ * state of a checkpoint, torch.optim.AdamW.state_dict() layout per tensor).  export: arena -> buffer (accumulate != 0:
+ * +=); import: buffer -> arena. */
 int jn_arena_segment(jn_ctx* ctx, const char* name, size_t* off, size_t* numel);
 int jn_export_arena(jn_ctx* ctx, int what, float* dst_dev, size_t numel, int accumulate, void* stream);
 int jn_import_arena(jn_ctx* ctx, int what, const float* src_dev, size_t numel, void* stream);
@@ -236,6 +237,12 @@ int jn_import_arena(jn_ctx* ctx, int what, const float* src_dev, size_t numel, v
  * Deviation from the reference: a token's masks are drawn once, when the token is processed (KV cache),
  * whereas the reference re-draws the masks of the whole prefix at every glimpse step. */
 int jn_set_dropout(jn_ctx* ctx, float p, uint64_t seed);
+/* --freeze-image-processor (src/models/gpt.py:264-268: requires_grad = False on yolox.backbone.*): the optim_yolox
+ * group (jn_optimizer_step_group(1)) then updates the detection head only. */
+int jn_set_freeze(jn_ctx* ctx, int freeze_detector_backbone);
+/* AdamW step counter of a parameter group (bias correction): read (set = 0) or restore (set != 0) — the "step" entry of
+ * a torch optimizer state_dict, so that a resumed run continues where the checkpoint stopped. */
+int jn_optimizer_steps(jn_ctx* ctx, int group, int* steps, int set);
 
 /* One supervised (teacher-forced) step minus the optimiser: SupervisedTrainer.run body
  * (src/supervised.py:863-902) with the detector term off.  patches [B,T,3,P,P], current_actions /

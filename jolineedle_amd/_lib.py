@@ -110,6 +110,8 @@ SIGNATURES = {
     "jn_export_arena": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "jn_import_arena": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "jn_set_dropout": (C.c_int, [C.c_void_p, C.c_float, C.c_uint64]),
+    "jn_set_freeze": (C.c_int, [C.c_void_p, C.c_int]),
+    "jn_optimizer_steps": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]),
 }
 
 

@@ -3,8 +3,9 @@
 (infer.py:58-73) for the accelerated model — same file names (``config.json``, ``checkpoint.pt``, ``checkpoint_best.pt``),
 same dictionary keys (``model`` with optional DDP ``module.`` prefixes), so a directory written by the reference loads.
 
-Deviation: AdamW moments live inside the engine and are not part of the C ABI; ``optimizer-gpt`` / ``optimizer-yolox``
-entries of a reference checkpoint are ignored (the moments restart) and checkpoints written here carry empty ones."""
+``optimizer-gpt`` / ``optimizer-yolox`` hold ``torch.optim.AdamW`` state dicts in both directions: the engine's moments
+and step counters are exported in the reference's tensor layout (``EngineAdamW.state_dict``), and a reference
+checkpoint's moments are imported on resume, so a resumed run continues with the bias correction it stopped at."""
 import json
 from copy import deepcopy
 from pathlib import Path
@@ -57,12 +58,19 @@ def _strip_ddp(sd):
     return {k.replace("module.", ""): v for k, v in sd.items()}
 
 
-def save_checkpoint(model, folder, best: bool = False, extra: dict = None) -> Path:
+def save_checkpoint(model, folder, best: bool = False, extra: dict = None, optim_gpt=None, optim_yolox=None) -> Path:
+    """main.py:436-449's checkpoint dict.  `optim_gpt` / `optim_yolox`: the optimisers of ``model.configure_optimizers``
+    (default: fresh front ends onto the engine's state, which is where the moments live)."""
     folder = Path(folder)
     folder.mkdir(parents=True, exist_ok=True)
     if hasattr(model, "pull_parameters") and getattr(model, "_engine", None) is not None:
         model.pull_parameters()            # optimiser-updated weights and BN statistics live in the engine
-    ck = {"model": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "optimizer-gpt": {}, "optimizer-yolox": {}}
+    if optim_gpt is None and hasattr(model, "configure_optimizers") and torch.cuda.is_available():
+        from .config import CfgNode as _C
+        optim_gpt, optim_yolox = model.configure_optimizers(_C(learning_rate=0.0, yolo_lr=0.0))
+    ck = {"model": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+          "optimizer-gpt": optim_gpt.state_dict() if optim_gpt is not None else {},
+          "optimizer-yolox": optim_yolox.state_dict() if optim_yolox is not None else {}}
     ck.update(extra or {})
     path = folder / ("checkpoint_best.pt" if best else "checkpoint.pt")
     torch.save(ck, path)
@@ -75,6 +83,17 @@ def load_checkpoint(train_config, trainer_or_model, best: bool = False) -> None:
     folder = Path(train_config.resume_training)
     ck = torch.load(folder / ("checkpoint_best.pt" if best else "checkpoint.pt"), map_location="cpu", weights_only=False)
     model.load_state_dict(_strip_ddp(ck["model"]))
+    # optimiser states (main.py:548-556): the trainer's own optimisers when it has them, else front ends onto the engine
+    og, oy = getattr(trainer_or_model, "optim_gpt", None), getattr(trainer_or_model, "optim_yolox", None)
+    if og is None and torch.cuda.is_available() and (ck.get("optimizer-gpt") or ck.get("optimizer-yolox")):
+        from .config import CfgNode as _C
+        og, oy = model.configure_optimizers(_C(learning_rate=float(getattr(train_config, "learning_rate", 0.0) or 0.0),
+                                               yolo_lr=float(getattr(train_config, "yolo_lr", 0.0) or 0.0)))
+    model.sync_weights()
+    if og is not None and ck.get("optimizer-gpt"):
+        og.load_state_dict(ck["optimizer-gpt"])
+    if oy is not None and ck.get("optimizer-yolox"):
+        oy.load_state_dict(ck["optimizer-yolox"])
 
 
 def load_detection_checkpoint(train_config, trainer_or_model) -> None:

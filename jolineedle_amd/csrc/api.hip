@@ -636,6 +636,9 @@ int jn_load_weights(jn_ctx* ctx, const jn_tensor* tensors, size_t n) {
   }
   if (!ctx->gpt_arena_end) ctx->gpt_arena_end = ctx->arena_used;
   if ((rc = pack_net(JN_NET_DETECTOR))) return rc;
+  ctx->det_head_begin = ctx->arena_used;
+  for (const ParamSeg& sg : ctx->segs)
+    if (sg.name.compare(0, 11, "yolox.head.") == 0) { ctx->det_head_begin = std::min(ctx->det_head_begin, sg.off); }
   JN_HIP(hipDeviceSynchronize());
   ctx->weights_loaded = true;
   return JN_OK;
@@ -2096,7 +2099,10 @@ int jn_optimizer_step_group(jn_ctx* ctx, int group, float lr, float weight_decay
   JN_CHECK(ctx && ctx->grads, JN_ESTATE, "no gradients: run jn_reinforce_step / jn_detector_step first");
   JN_CHECK(group == 0 || group == 1, JN_EINVAL, "parameter group %d: 0 = optim_gpt, 1 = optim_yolox", group);
   JN_HIP(hipSetDevice(ctx->cfg.device));
-  const size_t lo = group == 0 ? 0 : ctx->gpt_arena_end, hi = group == 0 ? ctx->gpt_arena_end : ctx->arena_used;
+  // a frozen detector backbone (requires_grad = False in the reference: torch's AdamW skips it) keeps its values; its
+  // BatchNorm running statistics still move in train-mode passes, as torch's do
+  const size_t lo = group == 0 ? 0 : (ctx->freeze_det_backbone ? std::max(ctx->gpt_arena_end, ctx->det_head_begin) : ctx->gpt_arena_end);
+  const size_t hi = group == 0 ? ctx->gpt_arena_end : ctx->arena_used;
   JN_CHECK(hi > lo, JN_ESTATE, "parameter group %d is empty", group);
   int& step = group == 0 ? ctx->adam_step : ctx->adam_step_yolox;
   step += 1;
@@ -2135,14 +2141,15 @@ int jn_arena_segment(jn_ctx* ctx, const char* name, size_t* off, size_t* numel) 
 
 static int arena_copy(jn_ctx* ctx, int what, float* ref_dev, size_t numel, int to_ref, int accumulate, void* stream) {
   JN_CHECK(ctx && ref_dev && ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
-  JN_CHECK(what == 0 || what == 1, JN_EINVAL, "what: 0 = parameters, 1 = gradients");
+  JN_CHECK(what >= 0 && what <= 3, JN_EINVAL, "what: 0 = parameters, 1 = gradients, 2 / 3 = AdamW first / second moments");
   JN_CHECK(numel >= ctx->arena_used, JN_EINVAL, "reference-layout buffer needs %zu floats, got %zu", ctx->arena_used, numel);
   JN_HIP(hipSetDevice(ctx->cfg.device));
   int rc;
-  if (what == 1 && (rc = ensure_train_state(ctx))) return rc;
+  if (what >= 1 && (rc = ensure_train_state(ctx))) return rc;
   if ((rc = ensure_segs_dev(ctx))) return rc;
-  launch_arena_copy(ctx->segs_dev, ctx->segs_dev_n, what == 0 ? ctx->params : ctx->grads, ref_dev, (long long)ctx->arena_used,
-                    to_ref, accumulate, (hipStream_t)stream);
+  float* arena = what == 0 ? ctx->params : what == 1 ? ctx->grads : what == 2 ? ctx->adam_m : ctx->adam_v;
+  launch_arena_copy(ctx->segs_dev, ctx->segs_dev_n, arena, ref_dev, (long long)ctx->arena_used, to_ref, accumulate,
+                    (hipStream_t)stream);
   JN_HIP(hipGetLastError());
   if (!to_ref && what == 0)
     for (int ni = 0; ni < 2; ++ni) if (ctx->has_net[ni]) ctx->nets[ni].eval_tab_dirty = true;   // BN affine may have moved
@@ -2155,6 +2162,19 @@ int jn_export_arena(jn_ctx* ctx, int what, float* dst_dev, size_t numel, int acc
 
 int jn_import_arena(jn_ctx* ctx, int what, const float* src_dev, size_t numel, void* stream) {
   return arena_copy(ctx, what, const_cast<float*>(src_dev), numel, 0, 0, stream);
+}
+
+int jn_set_freeze(jn_ctx* ctx, int freeze_detector_backbone) {
+  JN_CHECK(ctx, JN_EINVAL, "null ctx");
+  ctx->freeze_det_backbone = freeze_detector_backbone != 0;
+  return JN_OK;
+}
+
+int jn_optimizer_steps(jn_ctx* ctx, int group, int* steps, int set) {
+  JN_CHECK(ctx && steps && (group == 0 || group == 1), JN_EINVAL, "jn_optimizer_steps: bad argument");
+  int& st = group == 0 ? ctx->adam_step : ctx->adam_step_yolox;
+  if (set) st = *steps; else *steps = st;
+  return JN_OK;
 }
 
 int jn_set_dropout(jn_ctx* ctx, float p, uint64_t seed) {

@@ -176,6 +176,8 @@ struct jn_ctx {
   float* params = nullptr; float* grads = nullptr; float* adam_m = nullptr; float* adam_v = nullptr;
   size_t arena_size = 0, arena_used = 0, gpt_arena_end = 0;   // [0, gpt_arena_end) = optim_gpt parameters
   int adam_step = 0, adam_step_yolox = 0;
+  bool freeze_det_backbone = false;   // --freeze-image-processor: yolox.backbone.* keep their values (src/models/gpt.py:264-268)
+  size_t det_head_begin = 0;          // arena offset of the first yolox.head.* tensor
   jnr::GptLayerPtrs* g_layers_dev = nullptr;
   float* efpn_train = nullptr;    // [T][B][h*w*C] embed_fpn.0 activations of every glimpse step
   float* tok_emb_train = nullptr; // [B][T][C] patch embeddings of every glimpse step

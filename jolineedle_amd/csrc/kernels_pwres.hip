@@ -49,7 +49,7 @@ __device__ __forceinline__ void split3(const f32x4& v, bf16x4& h, bf16x4& m, bf1
 
 // SP: operands split into three bf16 terms each, six v_mfma_f32_16x16x32_bf16 per product block (all cross terms down
 // to 2^-24 of the product: the accuracy of an fp32 multiply-add chain) — 96 matrix-pipe cycles per 16 x 16 x 32 block
-// instead of the 256 of eight v_mfma_f32_16x16x4_f32.  SP = false: exact fp32 (JN_PW_EXACT=1).
+// instead of the 256 of eight v_mfma_f32_16x16x4_f32.  SP = false: exact fp32 (the default; JN_PW_SPLIT=1 selects SP).
 template <int CT, int KC, int BM, int PD, bool WT, bool SP>
 __global__ __launch_bounds__(256) void pw_res_kernel(
     const float* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, int w_ld, float* __restrict__ out,
@@ -598,12 +598,15 @@ bool pw_res_supported(const ConvArgs& a) {
   return true;
 }
 
-// The production route for wide 1x1 layers (forward and data gradient): the barrier-free weight-stationary kernel with
-// split-bf16 products (JN_PW_EXACT=1: fp32 MFMA).  Shapes it measured no better on stay with their old kernels:
-// 64 -> 64 on fewer than 65536 pixels (pw_mfma_kernel, 14.3 against 14.6 us at 28x28).
+// The production route for wide 1x1 layers (forward and data gradient): the barrier-free weight-stationary kernel on
+// exact-fp32 MFMA.  JN_PW_SPLIT=1 switches its products to the split-bf16 form: 2.07 against 2.15 ms per forward pass and
+// 117.0 against 118.1 ms per iteration (these kernels are latency-, not matrix-bound), but a rounding noise ~10x that of
+// an fp32 fma chain per layer, which the 77 train-mode BatchNorms amplify to 1.0 - 1.5e-3 on the first layers'
+// gradients — not worth 1 %.  Shapes the kernel measured no better on stay with their old kernels: 64 -> 64 on fewer
+// than 65536 pixels (pw_mfma_kernel, 14.3 against 14.6 us at 28x28).
 int launch_pw_wide(const ConvArgs& a, hipStream_t s) {
   static const bool off = std::getenv("JN_NO_PW_DIR") != nullptr;
-  static const bool exact = std::getenv("JN_PW_EXACT") != nullptr;
+  static const bool exact = std::getenv("JN_PW_SPLIT") == nullptr;
   if (off || !pw_res_supported(a) || a.cin % 64 != 0) return -1;
   const long long M = (long long)a.N * a.H * a.W * (a.n_slots > 1 ? a.n_slots : 1);
   if (a.cin == 64 && a.cout == 64 && M < 65536) return -1;
@@ -617,7 +620,7 @@ int launch_pw_res(const ConvArgs& a, hipStream_t s) {
   const long long M = (long long)a.N * a.H * a.W;
   const int K = a.cin, N = a.cout;
   const int nz = a.n_slots > 1 ? a.n_slots : 1;
-  static const bool exact = std::getenv("JN_PW_EXACT") != nullptr;     // fp32 MFMA instead of the split-bf16 products
+  static const bool exact = std::getenv("JN_PW_SPLIT") == nullptr;     // fp32 MFMA unless the split-bf16 products are asked for
   static const char* force_env = std::getenv("JN_PW_RES_CFG");         // "ct,kc,bm,pd,split": tuning aid (0 = automatic)
   const char* force = g_pw_res_force ? g_pw_res_force : force_env;
   int sp = exact ? 0 : 1;

@@ -78,6 +78,13 @@ class GPT(nn.Module):
         self.dropout = float(getattr(config, "dropout", 0.0) or 0.0)
         self.set_dropout_seed(int(getattr(config, "seed", 0)))
         self._build_parameters()
+        # --freeze-image-processor (gpt.py:264-268): yolox.backbone.* out of the optimiser
+        self.freeze_image_processor = bool(getattr(config, "freeze_image_processor", False))
+        if self.freeze_image_processor and self._engine.cfg.with_detector:
+            check(self._engine.lib.jn_set_freeze(self._engine.handle, 1), "jn_set_freeze")
+            for pn, p in self.named_parameters():
+                if pn.startswith("yolox.backbone."):
+                    p.requires_grad_(False)
         self._uploaded_version = None
         self._engine_grads = None          # packed gradient arena (torch-owned: ONE RCCL all-reduce per optimiser step)
         self._flat_params = self._flat_grads = None   # reference-layout mirrors behind param.data / param.grad (bind_flat)
@@ -296,7 +303,7 @@ class GPT(nn.Module):
         self._flat_params = torch.zeros(n, device=self.device, dtype=torch.float32)
         self._flat_grads = torch.zeros(n, device=self.device, dtype=torch.float32)
         check(eng.lib.jn_export_arena(eng.handle, 0, ptr(self._flat_params), n, 0, stream), "jn_export_arena")
-        self._flat_names = []
+        self._flat_names, self._flat_offsets = [], {}
         for name, p in self.named_parameters():
             off, num = C.c_size_t(), C.c_size_t()
             if eng.lib.jn_arena_segment(eng.handle, name.encode(), C.byref(off), C.byref(num)) != 0:
@@ -305,6 +312,7 @@ class GPT(nn.Module):
             p.data = self._flat_params[off.value:off.value + num.value].view(p.shape)
             p.grad = self._flat_grads[off.value:off.value + num.value].view(p.shape)
             self._flat_names.append(name)
+            self._flat_offsets[name] = off.value
         self._uploaded_version = self._weights_version()
 
     def refresh_flat_params(self):

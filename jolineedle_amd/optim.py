@@ -51,6 +51,69 @@ class EngineAdamW(torch.optim.Optimizer):
         m._uploaded_version = m._weights_version()        # the engine already holds these values
         return None
 
+    # ---- checkpoint state in torch.optim.AdamW's layout (main.py:436-449, 532-563: "optimizer-gpt" / "optimizer-yolox") ----
+    def _moments(self, what: int) -> torch.Tensor:
+        m = self._model
+        buf = torch.zeros(m._arena_numel, device=m.device, dtype=torch.float32)
+        check(m.engine().lib.jn_export_arena(m.engine().handle, what, ptr(buf), buf.numel(), 0, _lib.current_stream(m.device)), "jn_export_arena")
+        return buf
+
+    def state_dict(self):
+        """{"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]} over this optimiser's parameters in order,
+        the moments converted from the engine's arena to the reference layout: a dict ``torch.optim.AdamW.load_state_dict``
+        accepts for the same parameter list."""
+        import ctypes as C
+        m = self._model
+        m.bind_flat()
+        steps = C.c_int()
+        check(m.engine().lib.jn_optimizer_steps(m.engine().handle, self._group, C.byref(steps), 0), "jn_optimizer_steps")
+        ea, eas = self._moments(2), self._moments(3)
+        names = {id(p): n for n, p in m.named_parameters()}
+        state, idx = {}, []
+        for i, p in enumerate(self.param_groups[0]["params"]):
+            idx.append(i)
+            n = names.get(id(p))
+            off = m._flat_offsets.get(n) if n is not None else None
+            if off is None or not p.requires_grad or steps.value == 0:
+                continue
+            sl = slice(off, off + p.numel())
+            state[i] = {"step": torch.tensor(float(steps.value)), "exp_avg": ea[sl].view(p.shape).cpu().clone(),
+                        "exp_avg_sq": eas[sl].view(p.shape).cpu().clone()}
+        g = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        g.update(params=idx, amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None)
+        return {"state": state, "param_groups": [g]}
+
+    def load_state_dict(self, sd):
+        """Accepts what ``state_dict`` writes and what ``torch.optim.AdamW.state_dict()`` of the reference writes for the same
+        parameter list (main.py:548-556); an empty dict (a checkpoint of round 1) leaves the moments at zero."""
+        import ctypes as C
+        if not sd or not sd.get("state"):
+            return
+        m = self._model
+        m.bind_flat()
+        ea, eas = self._moments(2), self._moments(3)
+        names = {id(p): n for n, p in m.named_parameters()}
+        step = 0
+        for i, p in enumerate(self.param_groups[0]["params"]):
+            st = sd["state"].get(i, sd["state"].get(str(i)))
+            off = m._flat_offsets.get(names.get(id(p)))
+            if st is None or off is None:
+                continue
+            sl = slice(off, off + p.numel())
+            ea[sl] = st["exp_avg"].to(m.device, torch.float32).flatten()
+            eas[sl] = st["exp_avg_sq"].to(m.device, torch.float32).flatten()
+            step = max(step, int(float(st["step"])))
+        eng, stream = m.engine(), _lib.current_stream(m.device)
+        # (both groups share the arena: the other group's slices were exported above and go back unchanged)
+        check(eng.lib.jn_import_arena(eng.handle, 2, ptr(ea), ea.numel(), stream), "jn_import_arena")
+        check(eng.lib.jn_import_arena(eng.handle, 3, ptr(eas), eas.numel(), stream), "jn_import_arena")
+        steps = C.c_int(step)
+        check(eng.lib.jn_optimizer_steps(eng.handle, self._group, C.byref(steps), 1), "jn_optimizer_steps")
+        if sd.get("param_groups"):
+            for k in ("lr", "weight_decay"):
+                if k in sd["param_groups"][0]:
+                    self.param_groups[0][k] = sd["param_groups"][0][k]
+
     def zero_grad(self, set_to_none: bool = False):
         """Zeroes this group's slice of the flat gradient buffer in place (``param.grad`` stays a view of it)."""
         lo, hi = self._bound_range()

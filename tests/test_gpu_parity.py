@@ -1342,7 +1342,7 @@ def test_augment_fused_pass_vs_oracle(N, P):
 
 def test_augment_device_noise_statistics_and_trainer_hook():
     from jolineedle_amd.augment import DetectionAugment
-    aug = DetectionAugment(p_planckian=0, p_gray=0, p_blur=0, p_noise=1.0, p_motion=0, noise_std=0.05, seed=9)
+    aug = DetectionAugment(p_planckian=0, p_gray=0, p_blur=0, p_noise=1.0, p_motion=0, p_shadow=0, noise_std=0.05, seed=9)
     x = torch.full((4, 3, 256, 256), 0.5, device=DEV)
     d = (aug(x) - x).cpu()
     assert abs(float(d.mean())) < 2e-4 and abs(float(d.std()) - 0.05) < 5e-4
@@ -1390,6 +1390,64 @@ def test_checkpoint_round_trip_and_detection_checkpoint(tmp_path):
     assert any(not torch.equal(sd3[k], sd0[k]) for k in sd0 if k.startswith("transformer."))
     x = torch.rand(2, 3, 64, 64)
     assert torch.equal(third.yolox(x)[1][2], product.yolox(x)[1][2])      # same detector features now
+
+
+def test_checkpoint_resume_continues_the_optimiser_state(tmp_path):
+    """main.py:436-449 / 532-563: "optimizer-gpt" carries torch.optim.AdamW state dicts.  Two iterations in one go equal
+    one iteration -> checkpoint -> fresh model + load -> one iteration (moments and bias-correction step restored), the
+    saved dict loads into a real torch.optim.AdamW over the same parameter list, and a frozen detector backbone
+    (--freeze-image-processor, src/models/gpt.py:264-268) is left alone by optim_yolox."""
+    from jolineedle_amd import checkpoint
+    P, Tn, B = 64, 3, 2
+    images, bboxes, start = synth_batch(B, 3, 4, P, seed=51)
+    forced = torch.randint(0, 8, (B, Tn), generator=torch.Generator().manual_seed(6))
+    cfg = _cfg(T=Tn, learning_rate=1e-3, gradient_accumulation=1)
+    cfg.resume_training = str(tmp_path)
+
+    def iteration(model):
+        tr = ja.ReinforceTrainer(cfg, model)
+        env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True)
+        tr.train_iteration(env, forced_actions=forced, start_positions=start, optimizer_step=True)
+    a, _ = make_pair(5, patch_size=P, block_size=Tn, with_detector=False, image_processor=None)
+    iteration(a); iteration(a)
+    a.pull_parameters()
+    b, _ = make_pair(5, patch_size=P, block_size=Tn, with_detector=False, image_processor=None)
+    iteration(b)
+    checkpoint.save_checkpoint(b, tmp_path)
+    ck = torch.load(tmp_path / "checkpoint.pt", weights_only=False)
+    st = ck["optimizer-gpt"]["state"]
+    assert len(st) > 150 and all(float(v["step"]) == 1.0 for v in st.values())
+    c, _ = make_pair(6, patch_size=P, block_size=Tn, with_detector=False, image_processor=None)     # other weights: everything comes from the file
+    checkpoint.load_checkpoint(cfg, c)
+    iteration(c)
+    c.pull_parameters()
+    sa, sc = a.state_dict(), c.state_dict()
+    for k in sa:
+        if sa[k].dtype.is_floating_point:
+            assert torch.allclose(sa[k].cpu(), sc[k].cpu(), atol=2e-5, rtol=1e-4), k
+    # without the moments the second step would differ: AdamW's bias correction at step 1 vs step 2
+    d, _ = make_pair(5, patch_size=P, block_size=Tn, with_detector=False, image_processor=None)
+    d.load_state_dict(ck["model"])
+    iteration(d)
+    d.pull_parameters()
+    k = "transformer.wte.weight"
+    assert (d.state_dict()[k].cpu() - sa[k].cpu()).abs().max() > 1e-4
+    # the dict is a torch.optim.AdamW state dict for the same parameter list
+    plist = [torch.nn.Parameter(p.detach().cpu().clone()) for n, p in b.named_parameters() if not n.startswith("yolox")]
+    topt = torch.optim.AdamW(plist, lr=1e-3)
+    topt.load_state_dict(ck["optimizer-gpt"])
+    assert len(topt.state_dict()["state"]) == len(st)
+    # frozen detector backbone: optim_yolox moves the head only
+    f, _ = make_pair(7, patch_size=P, block_size=Tn, image_processor="yolox-nano", gpt_backbone="yolox-nano", freeze_image_processor=True)
+    before = {kk: v.detach().cpu().clone() for kk, v in f.state_dict().items()}
+    fcfg = _cfg(T=Tn, learning_rate=1e-3, gradient_accumulation=1)
+    fcfg.detection_enabled, fcfg.yolo_lr = True, 1e-3
+    ja.ReinforceTrainer(fcfg, f).train_iteration(ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True), start_positions=start)
+    f.pull_parameters()
+    after = f.state_dict()
+    assert torch.equal(after["yolox.backbone.backbone.dark3.0.pconv.conv.weight"].cpu(), before["yolox.backbone.backbone.dark3.0.pconv.conv.weight"])
+    assert not torch.equal(after["yolox.head.stems.0.conv.weight"].cpu(), before["yolox.head.stems.0.conv.weight"])
+    assert not any(p.requires_grad for n, p in f.named_parameters() if n.startswith("yolox.backbone."))
 
 
 def test_infer_images_pads_and_maps_boxes_to_the_full_image():
