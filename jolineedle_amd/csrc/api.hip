@@ -775,9 +775,10 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
     if (dbg_skip) return;
     ChanTab t1{nullptr, nullptr, nullptr};
     if (op.alias.buf >= 0) t1 = tab(op.alias);
-    launch_bn_finalize(stats + 2 * cw.stat_off, rep_stride, (double)N * op.out.H * op.out.W, cw.gamma_dev, cw.beta_dev, cw.rmean_dev,
-                       cw.rvar_dev, save + 2 * cw.stat_off, tab(op.out), t1, cw.cout, kBnEps, kBnMomentum, skip_flag,
-                       skip_when, s);
+    // with the end-of-pass finalize (defer): table only here, saved / running statistics there
+    launch_bn_finalize(stats + 2 * cw.stat_off, rep_stride, (double)N * op.out.H * op.out.W, cw.gamma_dev, cw.beta_dev,
+                       defer ? nullptr : cw.rmean_dev, defer ? nullptr : cw.rvar_dev, defer ? nullptr : save + 2 * cw.stat_off,
+                       tab(op.out), t1, cw.cout, kBnEps, kBnMomentum, skip_flag, skip_when, s);
   };
   // JN_LAYER_PROFILE=1: HIP events around every op of the pass, table on stderr (a measuring aid, off by default)
   static const bool layer_profile = std::getenv("JN_LAYER_PROFILE") != nullptr;

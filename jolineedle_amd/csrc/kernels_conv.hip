@@ -1197,19 +1197,22 @@ int launch_bn_finalize(const double* stats, long long rep_stride, double count, 
   return 0;
 }
 
-// One launch at the end of a train-mode pass for every layer whose table was deferred (ChanTab, jn_kernels.h): the same
-// arithmetic as bn_finalize_kernel per BatchNorm channel (thread = channel; layers above the deferral limit had their own
-// finalize launch and are skipped).
+// One launch at the end of a train-mode pass: saved (mean, invstd) and running statistics of EVERY BatchNorm layer of the
+// pass, and the table of the layers whose table was deferred (ChanTab, jn_kernels.h) — the arithmetic of
+// bn_finalize_kernel per channel (thread = channel).  The per-layer finalize launches that remain (layers above the
+// deferral limit) then only write their table: one global round trip shorter each.
 __global__ __launch_bounds__(256) void bn_finalize_all_kernel(BnAllArgs a) {
   if (a.skip_flag && *a.skip_flag >= a.skip_when) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n_stat) return;
   const float hw = a.hw[i];
-  if (hw <= 0.0f || (long long)a.N * (long long)hw > JN_DEFER_MAX_M) return;   // hw == 0: not a layer of this pass (detection head)
+  if (hw <= 0.0f) return;                                  // not a layer of this pass (detection head)
+  // layers above the deferral limit spread their sums over all JN_NREP replicas and had their table written by their own
+  // (table-only) finalize launch; their saved statistics and running averages are formed here with everybody else's
+  const int nrep = (long long)a.N * (long long)hw > JN_DEFER_MAX_M ? JN_NREP : JN_NREP_DEFER;
   const double count = (double)a.N * (double)hw;
   float sc, sh, mean, invstd; double var;
-  bn_from_sums(a.stats, a.rep_stride, JN_NREP_DEFER, i, count, a.params[a.goff[i]], a.params[a.boff[i]], a.eps, sc, sh, mean,
-               invstd, var);
+  bn_from_sums(a.stats, a.rep_stride, nrep, i, count, a.params[a.goff[i]], a.params[a.boff[i]], a.eps, sc, sh, mean, invstd, var);
   const int t0 = a.t0[i], t1 = a.t1[i];
   a.tab[t0] = sc; a.tab[a.tab_channels + t0] = sh; a.tab[2 * a.tab_channels + t0] = 1.0f;
   if (t1 >= 0) { a.tab[t1] = sc; a.tab[a.tab_channels + t1] = sh; a.tab[2 * a.tab_channels + t1] = 1.0f; }
