@@ -13,22 +13,27 @@
 
 namespace jnr {
 
-constexpr int GPT_THREADS = 256;
+constexpr int GPT_THREADS = 1024;      // 16 waves per agent: every Linear splits K over all of them (256 threads left a 192 -> 576
+                                       // layer of gpt-mini with ONE K slice: 192 dependent loads per thread)
+constexpr int GPT_WAVES = GPT_THREADS / 64;
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
-  // 256 threads -> 4 waves; wave reduce by shuffles then LDS
+  // wave reduce by shuffles, then the waves' partials through LDS
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __syncthreads();
   if (lane == 0) red[wave] = v;
   __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
+  float s = 0.0f;
+#pragma unroll
+  for (int w = 0; w < GPT_WAVES; ++w) s += red[w];
+  return s;
 }
 
 // y[n] = b[n] + sum_k x[k] * wt[k*N + n]   (x in LDS, wt transposed in global/L2).
 // All 256 threads work whatever N is: thread = (column quad, K slice); each slice walks K with stride `slices`
-// (independent dwordx4 loads), partials meet in LDS scratch `part` (>= 1024 floats).  With one thread per column a
+// (independent dwordx4 loads), partials meet in LDS scratch `part` (>= 4 * GPT_THREADS floats).  With one thread per column a
 // 192 -> 48 layer was 192 dependent loads on 48 threads: the whole step was a chain of L2 latencies.
 __device__ __forceinline__ void linear_t(float* y, const float* x, const float* __restrict__ wt,
                                          const float* __restrict__ b, int K, int N, float* part) {
@@ -106,9 +111,9 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
   float* qkv = h + C;            // [3C]
   float* mlp = qkv + 3 * C;      // [4C]  also the concatenated embedding parts
   float* att = mlp + 4 * C;      // [n_head * Tmax]
-  float* red = att + a.n_head * a.Tmax;   // [4]
-  float* lg = red + 4;           // [16]  logits
-  float* part = sm + ((9 * C + a.n_head * a.Tmax + 4 + 16 + 3) & ~3);   // [1024] split-K partials of linear_t (16-B aligned)
+  float* red = att + a.n_head * a.Tmax;   // [GPT_WAVES]
+  float* lg = red + GPT_WAVES;   // [16]  logits
+  float* part = sm + ((9 * C + a.n_head * a.Tmax + GPT_WAVES + 16 + 3) & ~3);   // [4 * GPT_THREADS] split-K partials of linear_t (16-B aligned)
 
   const int t = a.step;
   const int hs = C / a.n_head;
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
 }
 
 int launch_gpt_step(const GptStepArgs& a, hipStream_t s) {
-  const size_t smem = (size_t)(9 * a.C + a.n_head * a.Tmax + 4 + 16 + 4 + 1024) * sizeof(float);
+  const size_t smem = (size_t)(9 * a.C + a.n_head * a.Tmax + GPT_WAVES + 16 + 4 + 4 * GPT_THREADS) * sizeof(float);
   hipLaunchKernelGGL(gpt_step_kernel, dim3(a.B), dim3(GPT_THREADS), smem, s, a);
   return 0;
 }
