@@ -313,7 +313,7 @@ const char* g_pw_res_force = nullptr;   // tools/pwbench.hip: forced "ct,kc,bm,p
 // showed why this matters on these shapes: with one 4-wave workgroup per CU its stage -> barrier -> MFMA -> store
 // phases ran back to back and the matrix pipe was busy a third of the time.
 // A step = KH = 64 input channels of one tile; steps are prefetched PF ahead in registers.
-template <int CTW, bool WT, bool SP>
+template <int CTW, bool WT, bool SP, int PF = 2>
 __global__ __launch_bounds__(256, 2) void pw_dir_kernel(
     const float* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, int w_ld, float* __restrict__ out,
     int out_ld, long long M, int K, int Nc, int accumulate, double* __restrict__ stats, long long rep_stride, int nrep,
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void pw_dir_kernel(
   if (skip_flag && *skip_flag >= skip_when) return;
   x += blockIdx.z * x_slot; out += blockIdx.z * out_slot;
   it.sc += blockIdx.z * tab_slot; it.sh += blockIdx.z * tab_slot; it.fl += blockIdx.z * tab_slot;
-  constexpr int KH = 64, NF = KH / 16, PF = 2;                   // frags (float4 per lane) per step, prefetch depth
+  constexpr int KH = 64, NF = KH / 16;                           // frags (float4 per lane) per step; PF = prefetch depth (steps)
   constexpr int NCH = 16 * CTW;                                   // output channels of the slice
   const int LDW = K + 8, LDWh = K + 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void pw_dir_kernel(
     if (u < n_it) fetch(xr[u]);
 
   {   // weight slice -> LDS (all loads of a batch in flight before the first store), table meanwhile
-    constexpr int WB = 16;
+    constexpr int WB = 8;                                         // a 64 x 128 slice in one batch
     const int NQ = NCH / 4, KQ = K / 4;
     const int total = WT ? K * NQ : NCH * KQ;
     f32x4 wr[WB];
@@ -506,11 +506,11 @@ static size_t pw_dir_lds(int ctw, int K, bool split) {
   return (split ? (size_t)6 * 16 * ctw * (K + 16) : (size_t)4 * 16 * ctw * (K + 8)) + tail;
 }
 
-template <int CTW, bool WT, bool SP>
+template <int CTW, bool WT, bool SP, int PF = 2>
 static void launch_pw_dir_t(const ConvArgs& a, long long M, hipStream_t s) {
   const int K = a.cin;
   const size_t smem = pw_dir_lds(CTW, K, SP);
-  auto kern = pw_dir_kernel<CTW, WT, SP>;
+  auto kern = pw_dir_kernel<CTW, WT, SP, PF>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -531,6 +531,7 @@ static void launch_pw_dir_t(const ConvArgs& a, long long M, hipStream_t s) {
 
 // ctw = channel tiles per workgroup slice (0: automatic — the widest slice <= 128 channels whose weights leave room for two
 // workgroups per CU); returns -1 when the shape does not fit (K % 64, slice too large).
+int g_pw_dir_pf = 0;      // tools/pwbench.hip: prefetch depth override (3, 4) for the fp32 64-channel-slice kernel
 int launch_pw_dir(const ConvArgs& a, int ctw, int split, hipStream_t s) {
   const long long M = (long long)a.N * a.H * a.W;
   const int K = a.cin, N = a.cout;
@@ -547,6 +548,8 @@ int launch_pw_dir(const ConvArgs& a, int ctw, int split, hipStream_t s) {
   }
   if (pw_dir_lds(ctw, K, split != 0) > 160 * 1024) return -1;
   const bool wt = a.w_transposed != 0;
+  if (ctw == 4 && !split && !wt && g_pw_dir_pf == 3) { launch_pw_dir_t<4, false, false, 3>(a, M, s); return 0; }
+  if (ctw == 4 && !split && !wt && g_pw_dir_pf == 4) { launch_pw_dir_t<4, false, false, 4>(a, M, s); return 0; }
 #define JN_PD(C_)                                                                                   \
   if (ctw == C_) {                                                                                  \
     if (split) { if (wt) launch_pw_dir_t<C_, true, true>(a, M, s); else launch_pw_dir_t<C_, false, true>(a, M, s); }     \

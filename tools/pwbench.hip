@@ -87,6 +87,13 @@ int main(int argc, char** argv) {
         const float tt = time_it([&] { launch_pw_dir(a, ctw, sp, s); });
         printf(" | dir%d/%d %6.1f", ctw, sp, tt);
       }
+    for (int pf : {3, 4}) {
+      g_pw_dir_pf = pf;
+      if (launch_pw_dir(a, 4, 0, s) != 0 || hipDeviceSynchronize() != hipSuccess) { printf(" | dir4/0/pf%d n/a", pf); continue; }
+      const float tt = time_it([&] { launch_pw_dir(a, 4, 0, s); });
+      printf(" | dir4/0/pf%d %6.1f", pf, tt);
+    }
+    g_pw_dir_pf = 0;
     {
       std::vector<float> ref((size_t)M * sh.N), got((size_t)M * sh.N);
       launch_pw_types<float, float, false>(a2, s); CK(hipDeviceSynchronize());
