@@ -40,7 +40,7 @@ def main():
     _lib.check(eng.lib.jn_optimizer_step(eng.handle, 1e-3, 0.01, 1.0, scale, _lib.current_stream(product.device)), "step")
     product.pull_parameters()
     torch.save({"local": local, "mean": mean, "world_seen": dist.get_world_size(),
-                "params": {k: v.detach().cpu().clone() for k, v in product.state_dict().items()}}, outdir / f"rank{rank}.pt")
+                "params": {k: v.detach().cpu().clone() for k, v in product.named_parameters()}}, outdir / f"rank{rank}.pt")
     dist.barrier()
     dist.destroy_process_group()
 
