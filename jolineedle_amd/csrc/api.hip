@@ -1009,8 +1009,22 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
   if (!no_aux) { int ra = ensure_aux_stream(ctx); if (ra) return ra; }
   static const bool no_red_fusion = std::getenv("JN_NO_FUSED_REDUCE") != nullptr;
   const int n_ops_b = (with_head || net.n_backbone_ops < 0) ? (int)net.ops.size() : net.n_backbone_ops;
+  // JN_BWD_PROFILE=1: HIP events around the launches of every op, table on stderr (a measuring aid; use it together with
+  // JN_NO_AUX_STREAM=1 so that the wide weight-gradient GEMMs are inside the brackets)
+  static const bool bwd_profile = std::getenv("JN_BWD_PROFILE") != nullptr;
+  std::vector<hipEvent_t> bev;
+  if (bwd_profile) {
+    bev.resize(n_ops_b + 1);
+    for (auto& e : bev) hipEventCreate(&e);
+  }
+  struct BwdProfileMark {        // records the event of op `i` when the loop body is left (continue / break / fall through)
+    std::vector<hipEvent_t>& ev; int i; hipStream_t s;
+    ~BwdProfileMark() { if (!ev.empty()) hipEventRecord(ev[i], s); }
+  };
+  if (bwd_profile) hipEventRecord(bev[n_ops_b], s);
   for (int obi = n_ops_b - 1; obi >= 0; --obi) {
     const Op& op = net.ops[obi];
+    BwdProfileMark mark{bev, obi, s};
     if (op.wslot >= 0) {
       const ConvW& cw = net.convs[op.wslot];
       JN_CHECK(cw.has_bn, JN_ESTATE, "backward of BN-free conv %s inside a PAFPN", op.name.c_str());
@@ -1022,6 +1036,10 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
       const long long M = (long long)N * op.out.H * op.out.W;
       double* red = net.bred + 2 * cw.stat_off;
       float* consts = net.bconsts + 3 * cw.stat_off;
+      static const bool dbg_plan = std::getenv("JN_DBG_BWD_PLAN") != nullptr;
+      if (dbg_plan)
+        std::fprintf(stderr, "[bwd-plan] %-28s kind %d cout %4d cin %4d M/patch %6lld stride %d acc_in %d reduce %s\n", op.name.c_str(), (int)op.kind,
+                     cw.cout, cw.cin, M / N, op.stride, (int)op.acc_in, red_done.count(op.wslot) ? "fused" : "SEPARATE");
       if (!red_done.count(op.wslot))
         launch_bn_bwd_reduce(gp_out, gld_out, ptr(op.out), net.act_dtype, ld(op.out), tab(op.out), save + 2 * cw.stat_off, cw.cout,
                              M, red, rep_stride, s, sb);
@@ -1171,6 +1189,29 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
   if (aux_used) {
     JN_HIP(hipEventRecord(ctx->aux_join, ctx->aux_stream));
     JN_HIP(hipStreamWaitEvent(s, ctx->aux_join, 0));
+  }
+  if (bwd_profile) {
+    hipStreamSynchronize(s);
+    static const char* kn[] = {"stem", "pw", "dw", "conv3", "spp", "upsample", "addact", "pred"};
+    double tot_us = 0, tot_b = 0;
+    fprintf(stderr, "# backward profile: net %d, N=%d patches x %d steps; bytes = g_out + z_out + x read, g_in written (+ read when accumulated)\n", ni, N, nsl);
+    for (int obi = n_ops_b - 1; obi >= 0; --obi) {
+      const Op& op = net.ops[obi];
+      float ms = 0;
+      hipEventElapsedTime(&ms, bev[obi + 1], bev[obi]);
+      const double in_e = op.kind == OP_STEM ? 0.0 : (double)op.in.H * op.in.W * op.in.C, out_e = (double)op.out.H * op.out.W * op.out.C;
+      double elems;
+      if (op.wslot >= 0) elems = 2.0 * out_e + (op.kind == OP_STEM ? 3.0 * net.P * net.P : 2.0 * in_e + (op.acc_in ? in_e : 0.0));
+      else if (op.kind == OP_ADDACT) elems = 3.0 * out_e;                 // g read, two destinations
+      else if (op.kind == OP_SPP) elems = 8.0 * in_e;
+      else elems = in_e + out_e;
+      const double bytes = elems * 4.0 * N * nsl;
+      tot_us += ms * 1e3; tot_b += bytes;
+      fprintf(stderr, "%-8s %-44s in %3dx%3dx%3d out %3dx%3dx%3d s%d acc %d  %8.1f us  %8.1f MB  %6.0f GB/s\n", kn[op.kind], op.name.c_str(),
+              op.in.H, op.in.W, op.in.C, op.out.H, op.out.W, op.out.C, op.stride, (int)op.acc_in, ms * 1e3, bytes / 1e6, bytes / (ms * 1e-3) / 1e9);
+    }
+    fprintf(stderr, "# total %.1f us, %.1f MB, %.0f GB/s\n", tot_us, tot_b / 1e6, tot_b / (tot_us * 1e-6) / 1e9);
+    for (auto& e : bev) hipEventDestroy(e);
   }
   JN_HIP(hipGetLastError());
   return JN_OK;
@@ -1813,6 +1854,37 @@ static int build_grad_layer_table(jn_ctx* ctx) {
   return JN_OK;
 }
 
+// GPT backward over a trajectory: scratch (sized for either kernel) + launch.  The batched kernels are the default;
+// JN_GPT_BWD_V1=1 keeps the one-workgroup-per-agent kernel (diagnostic), which also takes the shapes the batched one refuses.
+static int launch_gpt_bwd(jn_ctx* ctx, GptBwdArgs& ba, hipStream_t s) {
+  const jn_config& c = ctx->cfg;
+  const int L = ba.T + 1, nL = c.n_layer, nh = c.n_head, C = c.n_embd;
+  const long long per_agent = (long long)(nL + 1) * L * C + (long long)nL * (11LL * L * C + (long long)nh * L * L) +
+                              12LL * L * C + (long long)nh * L * L + 4LL * C + 64;
+  const size_t need = std::max((size_t)per_agent * c.max_batch,
+                               gpt_backward_batched_scratch(C, nh, nL, c.n_actions, c.max_batch, ba.T));
+  if (!ctx->gpt_bwd_scratch || ctx->gpt_bwd_scratch_floats < need) {
+    int rc = dev_alloc(ctx, &ctx->gpt_bwd_scratch, need);
+    if (rc) return rc;
+    ctx->gpt_bwd_scratch_floats = need;
+  }
+  ba.scratch = ctx->gpt_bwd_scratch; ba.scratch_per_agent = per_agent;
+  static const bool v1 = std::getenv("JN_GPT_BWD_V1") != nullptr;
+  if (!v1) {
+    std::vector<GptLayerPtrs> W(nL), G(nL);
+    for (int l = 0; l < nL; ++l) {
+      const GptW::Layer& y = ctx->gpt.layers[l];
+      W[l] = GptLayerPtrs{y.ln1_w, y.ln1_b, y.qkv_wt, y.qkv_b, y.proj_wt, y.proj_b, y.ln2_w, y.ln2_b, y.fc_wt, y.fc_b, y.fc2_wt, y.fc2_b};
+      G[l] = GptLayerPtrs{grad_of(ctx, y.ln1_w), grad_of(ctx, y.ln1_b), grad_of(ctx, y.qkv_wt), grad_of(ctx, y.qkv_b),
+                          grad_of(ctx, y.proj_wt), grad_of(ctx, y.proj_b), grad_of(ctx, y.ln2_w), grad_of(ctx, y.ln2_b),
+                          grad_of(ctx, y.fc_wt), grad_of(ctx, y.fc_b), grad_of(ctx, y.fc2_wt), grad_of(ctx, y.fc2_b)};
+    }
+    if (launch_gpt_backward_batched(ba, W.data(), G.data(), s) == 0) return JN_OK;
+  }
+  launch_gpt_backward(ba, s);
+  return JN_OK;
+}
+
 }  // extern "C"
 static int reinforce_backward_impl(jn_ctx* ctx, const jn_rollout_out* out, int S, int stop_early, hipStream_t s);
 static int check_train_outputs(jn_ctx* ctx, const jn_rollout_out* out) {
@@ -1887,13 +1959,7 @@ static int reinforce_backward_impl(jn_ctx* ctx, const jn_rollout_out* out, int S
   const jn_config& c = ctx->cfg;
   const EnvState& e = ctx->env;
   const int B = e.B, T = e.T, C = c.n_embd, nA = c.n_actions, P = c.patch_size;
-  const int L = T + 1, nL = c.n_layer, nh = c.n_head;
-  const long long per_agent = (long long)(nL + 1) * L * C + (long long)nL * (11LL * L * C + (long long)nh * L * L) +
-                              12LL * L * C + (long long)nh * L * L + 4LL * C + 64;
-  if (!ctx->gpt_bwd_scratch || ctx->gpt_bwd_scratch_floats < (size_t)per_agent * c.max_batch) {
-    if ((rc = dev_alloc(ctx, &ctx->gpt_bwd_scratch, (size_t)per_agent * c.max_batch))) return rc;
-    ctx->gpt_bwd_scratch_floats = (size_t)per_agent * c.max_batch;
-  }
+  const int nL = c.n_layer, nh = c.n_head;
   const GptW& g = ctx->gpt;
   GptBwdArgs ba{};
   ba.C = C; ba.n_head = nh; ba.n_layer = nL; ba.nA = nA; ba.B = B; ba.T = T; ba.stop_early = stop_early ? 1 : 0;
@@ -1909,9 +1975,8 @@ static int reinforce_backward_impl(jn_ctx* ctx, const jn_rollout_out* out, int S
   ba.g_embed_class = grad_of(ctx, g.embed_class);
   ba.g_proj_wt = g.proj_wt ? grad_of(ctx, g.proj_wt) : nullptr; ba.g_proj_b = g.proj_b ? grad_of(ctx, g.proj_b) : nullptr;
   ba.g_head_wt = grad_of(ctx, g.head_wt); ba.g_lnf_w = grad_of(ctx, g.lnf_w); ba.g_lnf_b = grad_of(ctx, g.lnf_b);
-  ba.scratch = ctx->gpt_bwd_scratch; ba.scratch_per_agent = per_agent;
   ba.pdrop = ctx->pdrop; ba.drop_seed = ctx->drop_seed_used; ba.Tmax = c.block_size + 1;
-  launch_gpt_backward(ba, s);
+  if ((rc = launch_gpt_bwd(ctx, ba, s))) return rc;
 
   // patch-encoder side: all executed glimpse steps in ONE set of launches (chunks of net.g_slots steps
   // when the gradient buffers of a whole trajectory do not fit): embed_fpn backward, then the PAFPN.
@@ -2035,12 +2100,6 @@ int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* cur
   // ---- loss + backward ----
   launch_ce_loss(ctx->sup_logits, next_actions_dev, masks_dev, stop_weight, ctx->dlogits, metrics_dev, N, nA, T, s);
   const int nL = c.n_layer, nh = c.n_head;
-  const long long per_agent = (long long)(nL + 1) * L * C + (long long)nL * (11LL * L * C + (long long)nh * L * L) +
-                              12LL * L * C + (long long)nh * L * L + 4LL * C + 64;
-  if (!ctx->gpt_bwd_scratch || ctx->gpt_bwd_scratch_floats < (size_t)per_agent * c.max_batch) {
-    if ((rc = dev_alloc(ctx, &ctx->gpt_bwd_scratch, (size_t)per_agent * c.max_batch))) return rc;
-    ctx->gpt_bwd_scratch_floats = (size_t)per_agent * c.max_batch;
-  }
   const GptW& g = ctx->gpt;
   GptBwdArgs ba{};
   ba.C = C; ba.n_head = nh; ba.n_layer = nL; ba.nA = nA; ba.B = B; ba.T = T; ba.stop_early = 0;
@@ -2055,9 +2114,8 @@ int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* cur
   ba.g_embed_class = grad_of(ctx, g.embed_class);
   ba.g_proj_wt = g.proj_wt ? grad_of(ctx, g.proj_wt) : nullptr; ba.g_proj_b = g.proj_b ? grad_of(ctx, g.proj_b) : nullptr;
   ba.g_head_wt = grad_of(ctx, g.head_wt); ba.g_lnf_w = grad_of(ctx, g.lnf_w); ba.g_lnf_b = grad_of(ctx, g.lnf_b);
-  ba.scratch = ctx->gpt_bwd_scratch; ba.scratch_per_agent = per_agent;
   ba.pdrop = ctx->pdrop; ba.drop_seed = ctx->drop_seed_used; ba.Tmax = c.block_size + 1;
-  launch_gpt_backward(ba, s);
+  if ((rc = launch_gpt_bwd(ctx, ba, s))) return rc;
   const int MB = c.max_batch;
   const View& f2 = net.fpn[2];
   const ChanTab ident{ctx->ident, ctx->ident + 2048, ctx->ident + 4096};

@@ -337,6 +337,10 @@ struct GptBwdArgs {
   float pdrop; uint64_t drop_seed; int Tmax;   // dropout of the forward being differentiated (Tmax = block_size + 1)
 };
 int launch_gpt_backward(const GptBwdArgs& a, hipStream_t s);
+// the same backward batched over the agents (kernels_gptbwd.hip): W / G are HOST arrays of the per-layer weight and
+// gradient pointers; returns 1 when the shape is outside what it takes (caller falls back to launch_gpt_backward)
+size_t gpt_backward_batched_scratch(int C, int n_head, int n_layer, int nA, int B, int T);
+int launch_gpt_backward_batched(const GptBwdArgs& a, const GptLayerPtrs* W, const GptLayerPtrs* G, hipStream_t s);
 int launch_ce_loss(const float* logits, const int64_t* target, const uint8_t* masks, float stop_weight, float* dlogits,
                    float* metrics, int n, int nA, int T, hipStream_t s);
 // de[m][k] = 0 where e[m][k] <= 0 (ReLU mask of embed_fpn.0);  gb[o] += sum_m dpe[m][o]
