@@ -9,6 +9,7 @@
 // g buffers mirror the activation buffers (NHWC fp32, same views).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "jn_kernels.h"
@@ -303,8 +304,15 @@ static void launch_pw_bw_t(const float* gz, int g_ld, const void* x, int x_dtype
 // Wide layers (N, K >= 128): workgroup tile = 128 x 128 outputs, wave w owns the 64 x 64 quadrant (w & 1, w >> 1) and
 // contracts ALL 64 rows of a stage itself (no cross-wave sum).  Against the 64 x 64 tiles above every input row is
 // re-read half as often: (N/128 + K/128) instead of (N/64 + K/64) passes over g_z / x.
-template <typename XT>
-__global__ __launch_bounds__(256) void pw_bwd_weight_wide_kernel(const float* __restrict__ gz, int g_ld,
+// SP (the default; JN_WW_EXACT=1 keeps fp32 MFMA): both operands are split into two bf16 terms when they leave LDS
+// (x = hi + lo to 2^-17) and each 16 x 16 x 32 block takes three v_mfma_f32_16x16x32_bf16 (hi*hi + hi*lo + lo*hi; lo*lo
+// < 2^-16 of the product is dropped) — 48 matrix-pipe cycles instead of the 256 of eight fp32 MFMAs, which turns the
+// kernel from matrix-bound (~40 % of the fp32 peak) into a pass at memory speed.  A weight gradient is a leaf: its ~1e-5
+// relative error goes to the optimiser and nowhere else (the forward / data-gradient GEMMs stay exact).
+// Lane group g of a k-step takes rows 4g + (e & 3) + 16 (e >> 2): any row order is a valid contraction order, and this
+// one puts the four groups 16 banks apart (row stride 132 floats).
+template <typename XT, bool SP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void pw_bwd_weight_wide_kernel(const float* __restrict__ gz, int g_ld,
                                                                  const XT* __restrict__ x, int x_ld, ChanTab it,
                                                                  float* __restrict__ gw, long long M, int N, int K,
                                                                  int rows_per_block, int chunks_per_slot,
@@ -361,18 +369,51 @@ __global__ __launch_bounds__(256) void pw_bwd_weight_wide_kernel(const float* __
     }
     __syncthreads();
     if (rb + 64 < r1) fetch(rb + 64);
+    if constexpr (SP) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const float* gs = Gs + (ks * 32 + 4 * g) * LD + wn + lm;
+        const float* as = As + (ks * 32 + 4 * g) * LD + wk + lm;
+        bf16x8 bh[4], bl[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = as[((e & 3) + 16 * (e >> 2)) * LD + 16 * b];
+            const bf16_t h = (bf16_t)v;
+            bh[b][e] = h; bl[b][e] = (bf16_t)(v - (float)h);
+          }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          bf16x8 ah, al;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = gs[((e & 3) + 16 * (e >> 2)) * LD + 16 * a];
+            const bf16_t h = (bf16_t)v;
+            ah[e] = h; al[e] = (bf16_t)(v - (float)h);
+          }
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[b], acc[a][b], 0, 0, 0);
+          }
+        }
+      }
+    } else {
 #pragma unroll 4
-    for (int st = 0; st < 16; ++st) {
-      const int row = 4 * st + g;
-      float av[4], bv[4];
+      for (int st = 0; st < 16; ++st) {
+        const int row = 4 * st + g;
+        float av[4], bv[4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) av[a] = Gs[row * LD + wn + 16 * a + lm];
+        for (int a = 0; a < 4; ++a) av[a] = Gs[row * LD + wn + 16 * a + lm];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) bv[b] = As[row * LD + wk + 16 * b + lm];
+        for (int b = 0; b < 4; ++b) bv[b] = As[row * LD + wk + 16 * b + lm];
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+      }
     }
   }
 #pragma unroll
@@ -395,18 +436,20 @@ static void launch_pw_bwd_weight_wide(const float* gz, int g_ld, const void* x, 
   const int chunks_per_slot = (int)((M + rpb - 1) / rpb);
   dim3 grid((unsigned)(chunks_per_slot * sb.n), (N + 127) / 128, (K + 127) / 128);
   const size_t smem = (size_t)2 * 64 * (128 + 4) * sizeof(float);
-#define JN_WW(T_)                                                                                                     \
+  static const bool exact = std::getenv("JN_WW_EXACT") != nullptr;
+#define JN_WW(T_, SP_)                                                                                                \
   {                                                                                                                   \
     static bool raised = false;                                                                                       \
     if (!raised) {                                                                                                    \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_weight_wide_kernel<T_>),                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_weight_wide_kernel<T_, SP_>),                  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                               \
       raised = true;                                                                                                  \
     }                                                                                                                 \
-    hipLaunchKernelGGL((pw_bwd_weight_wide_kernel<T_>), grid, dim3(256), smem, s, gz, g_ld, (const T_*)x, x_ld, it, gw, M, N, \
-                       K, (int)rpb, chunks_per_slot, gz_slot, sb.act, sb.tab);                                        \
+    hipLaunchKernelGGL((pw_bwd_weight_wide_kernel<T_, SP_>), grid, dim3(256), smem, s, gz, g_ld, (const T_*)x, x_ld, it, gw, M, \
+                       N, K, (int)rpb, chunks_per_slot, gz_slot, sb.act, sb.tab);                                     \
   }
-  if (x_dtype == JN_BF16) JN_WW(bf16_t) else JN_WW(float)
+  if (x_dtype == JN_BF16) { if (exact) JN_WW(bf16_t, false) else JN_WW(bf16_t, true) }
+  else { if (exact) JN_WW(float, false) else JN_WW(float, true) }
 #undef JN_WW
 }
 
