@@ -11,44 +11,47 @@ from ast import literal_eval
 
 
 class CfgNode:
-    def __init__(self, **kwargs):
-        self.__dict__.update(kwargs)
+    """Nested attribute bag with the interface of the reference's ``CfgNode`` (src/utils.py:15-92): keyword construction,
+    ``str()`` as an indented listing, ``to_dict`` / ``merge_from_dict``, and ``merge_from_args(["--a.b=value", ...])``
+    overrides of attributes that already exist (values parsed as Python literals when they are ones)."""
+
+    def __init__(self, **entries):
+        vars(self).update(entries)
+
+    def _lines(self, depth=0):
+        pad = " " * (4 * depth)
+        for name, value in vars(self).items():
+            if isinstance(value, CfgNode):
+                yield f"{pad}{name}:\n"
+                yield from value._lines(depth + 1)
+            else:
+                yield f"{pad}{name}: {value}\n"
 
     def __str__(self):
-        return self._str_helper(0)
-
-    def _str_helper(self, indent):
-        parts = []
-        for k, v in self.__dict__.items():
-            if isinstance(v, CfgNode):
-                parts.append("%s:\n" % k)
-                parts.append(v._str_helper(indent + 1))
-            else:
-                parts.append("%s: %s\n" % (k, v))
-        return "".join(" " * (indent * 4) + p for p in parts)
+        return "".join(self._lines())
 
     def to_dict(self):
-        return {k: v.to_dict() if isinstance(v, CfgNode) else v for k, v in self.__dict__.items()}
+        return {name: value.to_dict() if isinstance(value, CfgNode) else value for name, value in vars(self).items()}
 
     def merge_from_dict(self, d):
-        self.__dict__.update(d)
+        vars(self).update(d)
 
     def merge_from_args(self, args):
-        for arg in args:
-            keyval = arg.split("=")
-            assert len(keyval) == 2, "expecting each override arg to be of form --arg=value, got %s" % arg
-            key, val = keyval
+        for override in args:
+            flag, sep, text = override.partition("=")
+            if not sep or "=" in text or not flag.startswith("--"):
+                raise AssertionError(f"override must look like --name=value or --node.name=value, got {override!r}")
             try:
-                val = literal_eval(val)
-            except ValueError:
-                pass
-            assert key[:2] == "--"
-            keys = key[2:].split(".")
-            obj = self
-            for k in keys[:-1]:
-                obj = getattr(obj, k)
-            assert hasattr(obj, keys[-1]), f"{key[2:]} is not an attribute that exists in the config"
-            setattr(obj, keys[-1], val)
+                value = literal_eval(text)
+            except (ValueError, SyntaxError):
+                value = text                                # a plain string
+            *path, leaf = flag[2:].split(".")
+            node = self
+            for part in path:
+                node = getattr(node, part)
+            if not hasattr(node, leaf):
+                raise AssertionError(f"{flag[2:]} is not an attribute that exists in the config")
+            setattr(node, leaf, value)
 
 
 def get_args(args=None):

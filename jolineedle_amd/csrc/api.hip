@@ -1112,7 +1112,7 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
         a.out = gptr(op.in); a.out_ld = ld(op.in); a.out_dtype = JN_F32; a.bf16_mfma = net.act_dtype == JN_BF16;
         a.N = N; a.H = op.out.H; a.W = op.out.W; a.OH = op.out.H; a.OW = op.out.W;
         a.cin = cw.cout; a.cout = cw.cin; a.stride = 1; a.act = ACT_NONE;
-        a.accumulate = op.acc_in ? 1 : 0; a.w_transposed = 1;
+        a.accumulate = op.acc_in ? 1 : 0; a.w_transposed = 1; a.in_identity = 1;
         a.n_slots = nsl; a.in_slot_stride = sb.grad; a.out_slot_stride = sb.grad; a.tab_slot_stride = 0;
         hipStream_t ws = s;
         if (!no_aux && cw.cout >= 128 && cw.cin >= 128) {      // the wide kernel: plain atomics on gw, no shared scratch
@@ -1150,7 +1150,7 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
           a.out = gptr(op.in); a.out_ld = ld(op.in); a.out_dtype = JN_F32;
           a.N = N; a.H = op.out.H; a.W = op.out.W; a.OH = op.in.H; a.OW = op.in.W;
           a.cin = cw.cout; a.cout = cw.cin; a.stride = 1; a.act = ACT_NONE;
-          a.accumulate = op.acc_in ? 1 : 0; a.w_transposed = 1;
+          a.accumulate = op.acc_in ? 1 : 0; a.w_transposed = 1; a.in_identity = 1;
           a.n_slots = nsl; a.in_slot_stride = sb.grad; a.out_slot_stride = sb.grad;
           rc3 = launch_conv3(a, s);
         } else {
@@ -2010,7 +2010,7 @@ static int reinforce_backward_impl(jn_ctx* ctx, const jn_rollout_out* out, int S
     a.in = ctx->de_ws; a.in_ld = C; a.in_dtype = JN_F32; a.itab = ident; a.w = g.efpn_w; a.bias = nullptr;
     a.out = g_f2; a.out_ld = net.bufs[f2.buf].C; a.out_dtype = JN_F32; a.bf16_mfma = 0;
     a.N = B; a.H = f2.H; a.W = f2.W; a.OH = f2.H; a.OW = f2.W; a.cin = C; a.cout = f2.C; a.stride = 1; a.act = ACT_NONE;
-    a.accumulate = 0; a.w_transposed = 1;
+    a.accumulate = 0; a.w_transposed = 1; a.in_identity = 1;
     a.n_slots = g_n; a.in_slot_stride = (long long)B * K; a.out_slot_stride = g_slot; a.tab_slot_stride = 0;
     // the detector's PAFPN as patch encoder is detached (src/models/gpt.py:376-380 "Do not backpropagate through
     // yolox"): the policy gradient stops at embed_fpn.0's weight
@@ -2134,7 +2134,7 @@ int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* cur
   ca.in = ctx->de_ws; ca.in_ld = C; ca.in_dtype = JN_F32; ca.itab = ident; ca.w = g.efpn_w; ca.bias = nullptr;
   ca.out = g_f2; ca.out_ld = net.bufs[f2.buf].C; ca.out_dtype = JN_F32; ca.bf16_mfma = net.act_dtype == JN_BF16;
   ca.N = N; ca.H = f2.H; ca.W = f2.W; ca.OH = f2.H; ca.OW = f2.W; ca.cin = C; ca.cout = f2.C; ca.stride = 1; ca.act = ACT_NONE;
-  ca.accumulate = 0; ca.w_transposed = 1;
+  ca.accumulate = 0; ca.w_transposed = 1; ca.in_identity = 1;
   const bool detached = ctx->enc_net == JN_NET_DETECTOR;        // src/models/gpt.py:376-380, see jn_reinforce_step
   if (!detached) launch_pw(ca, s);
   launch_pw_bwd_weight(ctx->de_ws, C, view_ptr(net, 0, MB, f2), net.act_dtype, net.bufs[f2.buf].C, view_tab(net, 0, f2),

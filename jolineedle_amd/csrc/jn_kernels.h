@@ -81,6 +81,7 @@ struct ConvArgs {
   int N, H, W, OH, OW, cin, cout, stride, act;
   int accumulate;                        // out += (gradient buffers)
   int w_transposed;                      // pw: w is [cin][cout] and read transposed (data-gradient)
+  int in_identity;                       // the input needs no "normalize on read" (gradient views): kernels may skip the transform
   double* stats; long long stats_rep_stride;
   int stats_nrep;                        // replicas the workgroups spread their sums over (0 -> JN_NREP)
   const int* skip_flag; int skip_when;

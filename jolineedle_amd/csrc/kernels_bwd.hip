@@ -9,6 +9,7 @@
 // g buffers mirror the activation buffers (NHWC fp32, same views).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -705,8 +706,17 @@ static void launch_pw_bwd_fused_r(const PwBwdFusedArgs& a, hipStream_t s) {
     }
   }
   const long long n_tiles = (a.M + 63) / 64;
-  long long bx = 1024 / a.sb.n;                       // ~1024 persistent workgroups over all slots
-  if (bx < 32) bx = 32;
+  // ~1024 persistent workgroups over all slots, in WHOLE resident rounds: an instantiation that fits 3 workgroups per CU
+  // (768 places) ran 1020 of them, i.e. a second round at a third of the occupancy
+  static int places = 0;
+  if (!places) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&pw_bwd_fused_kernel<CTN, CTK, RED>), 256, smem) != hipSuccess || per_cu < 1) per_cu = 2;
+    places = per_cu * 256;
+  }
+  const int rounds = std::max(1, (1024 + places / 2) / places);
+  long long bx = (long long)rounds * places / a.sb.n;
+  if (bx < 1) bx = 1;
   if (bx > n_tiles) bx = n_tiles;
   const int rep = (a.wpart && N * K <= JN_WPART_MAX) ? 1 : 0;
   hipLaunchKernelGGL((pw_bwd_fused_kernel<CTN, CTK, RED>), dim3((unsigned)bx, a.sb.n), dim3(256), smem, s, a.g, a.g_ld, a.z,

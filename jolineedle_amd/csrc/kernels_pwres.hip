@@ -313,7 +313,7 @@ const char* g_pw_res_force = nullptr;   // tools/pwbench.hip: forced "ct,kc,bm,p
 // showed why this matters on these shapes: with one 4-wave workgroup per CU its stage -> barrier -> MFMA -> store
 // phases ran back to back and the matrix pipe was busy a third of the time.
 // A step = KH = 64 input channels of one tile; steps are prefetched PF ahead in registers.
-template <int CTW, bool WT, bool SP, int PF = 2>
+template <int CTW, bool WT, bool SP, int PF = 2, bool ST = true, bool TF = true>
 __global__ __launch_bounds__(256, 2) void pw_dir_kernel(
     const float* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, int w_ld, float* __restrict__ out,
     int out_ld, long long M, int K, int Nc, int accumulate, double* __restrict__ stats, long long rep_stride, int nrep,
@@ -341,7 +341,11 @@ __global__ __launch_bounds__(256, 2) void pw_dir_kernel(
   f32x4 xr[PF][NF];
   long long pf_tile = wid; int pf_step = 0;
   auto fetch = [&](f32x4 (&dst)[NF]) {
+#ifdef JN_PWDIR_HOT                         // tools/pwdirbench.hip: every fetch from the same few (cache-resident) tiles
+    const long long m = (pf_tile & 7) * 16 + lm;
+#else
     const long long m = pf_tile * 16 + lm;
+#endif
     const float* xp = x + m * x_ld + pf_step * KH;
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void pw_dir_kernel(
       }
     };
     wload(0);
-    tab_to_lds(Tb, K, K, it, tid, 256);
+    if constexpr (TF) tab_to_lds(Tb, K, K, it, tid, 256);
     wstore(0);
     for (int base = 256 * WB; base < total; base += 256 * WB) { wload(base); wstore(base); }
   }
@@ -426,8 +430,11 @@ __global__ __launch_bounds__(256, 2) void pw_dir_kernel(
 #pragma unroll
       for (int j = 0; j < NF; ++j) {
         const int k = k0 + (SP ? 32 * (j >> 1) + 8 * g + 4 * (j & 1) : 16 * j + 4 * g);
-        xa[j] = tf4_tab(xr[u][j], *reinterpret_cast<const f32x4*>(Tb + k), *reinterpret_cast<const f32x4*>(Tb + K + k),
-                        *reinterpret_cast<const f32x4*>(Tb + 2 * K + k));
+        if constexpr (TF)
+          xa[j] = tf4_tab(xr[u][j], *reinterpret_cast<const f32x4*>(Tb + k), *reinterpret_cast<const f32x4*>(Tb + K + k),
+                          *reinterpret_cast<const f32x4*>(Tb + 2 * K + k));
+        else
+          xa[j] = xr[u][j];
       }
       if (cur_tile * 16 + lm >= M) {                              // rows past the end contribute nothing (and store nothing)
 #pragma unroll
@@ -462,15 +469,28 @@ __global__ __launch_bounds__(256, 2) void pw_dir_kernel(
           }
         }
       } else {
+        // weight fragments of k-substep j + 1 are read from LDS while the MFMAs of substep j run (left to itself the
+        // compiler issues every ds_read right before its four MFMAs and waits out the LDS latency each time: the matrix
+        // pipe sat idle for about half of every step)
         const float* wrow = Ws + lm * LDW + k0 + 4 * g;
+        f32x4 wa[2][CTW];
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) wa[0][c] = *reinterpret_cast<const f32x4*>(wrow + c * 16 * LDW);
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
+          if (j + 1 < NF) {
 #pragma unroll
-          for (int c = 0; c < CTW; ++c) {
-            const f32x4 wa = *reinterpret_cast<const f32x4*>(wrow + c * 16 * LDW + 16 * j);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[e], xa[j][e], acc[c], 0, 0, 0);
+            for (int c = 0; c < CTW; ++c) wa[(j + 1) & 1][c] = *reinterpret_cast<const f32x4*>(wrow + c * 16 * LDW + 16 * (j + 1));
           }
+#ifdef JN_PWDIR_NOMFMA                     // tools/pwdirbench.hip: the same loads and transform, no matrix work
+#pragma unroll
+          for (int c = 0; c < CTW; ++c) acc[c] += wa[j & 1][c] * xa[j];
+#else
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < CTW; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j & 1][c][e], xa[j][e], acc[c], 0, 0, 0);
+#endif
         }
       }
       if (++cur_step == nsteps) {
@@ -485,14 +505,13 @@ __global__ __launch_bounds__(256, 2) void pw_dir_kernel(
           float* op = out + m * out_ld + n;
           if (accumulate) v += *reinterpret_cast<const f32x4*>(op);
           *reinterpret_cast<f32x4*>(op) = v;
-          s1[c] += v;
-          s2[c] += v * v;
+          if constexpr (ST) { s1[c] += v; s2[c] += v * v; }
         }
         cur_tile += wstride;
       }
     }
   }
-  if (stats) {
+  if (ST && stats) {
     wave_stats_to_lds<CTW>(s1, s2, red + wave * 2 * NCH, lane, Nc - n0);
     __syncthreads();
     if (tid < 2 * NCH && n0 + (tid >> 1) < Nc)
@@ -506,11 +525,11 @@ static size_t pw_dir_lds(int ctw, int K, bool split) {
   return (split ? (size_t)6 * 16 * ctw * (K + 16) : (size_t)4 * 16 * ctw * (K + 8)) + tail;
 }
 
-template <int CTW, bool WT, bool SP, int PF = 2>
+template <int CTW, bool WT, bool SP, int PF = 2, bool ST = true, bool TF = true>
 static void launch_pw_dir_t(const ConvArgs& a, long long M, hipStream_t s) {
   const int K = a.cin;
   const size_t smem = pw_dir_lds(CTW, K, SP);
-  auto kern = pw_dir_kernel<CTW, WT, SP, PF>;
+  auto kern = pw_dir_kernel<CTW, WT, SP, PF, ST, TF>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -519,8 +538,10 @@ static void launch_pw_dir_t(const ConvArgs& a, long long M, hipStream_t s) {
   const long long n_tiles = (M + 15) / 16;
   const int ny = (a.cout + 16 * CTW - 1) / (16 * CTW), nz = a.n_slots > 1 ? a.n_slots : 1;
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / smem));
-  long long gx = (256LL * per_cu + (long long)ny * nz - 1) / ((long long)ny * nz);
-  if (ny > 1) gx = std::max<long long>(8, (gx + 7) / 8 * 8);
+  // one resident round: as many workgroups as the chip holds at once, never a few more (20 steps x 4 slices with the
+  // old round-up-to-8 rule gave 640 workgroups for 512 places: a second round at a quarter of the occupancy)
+  long long gx = std::max<long long>(1, 256LL * per_cu / ((long long)ny * nz));
+  if (nz == 1 && ny > 1) gx = std::max<long long>(8, gx / 8 * 8);
   gx = std::min<long long>(gx, (n_tiles + 3) / 4);
   dim3 grid((unsigned)gx, (unsigned)ny, (unsigned)nz);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const float*)a.in, a.in_ld, a.itab, a.w, WT ? a.cout : a.cin,
@@ -548,6 +569,22 @@ int launch_pw_dir(const ConvArgs& a, int ctw, int split, hipStream_t s) {
   }
   if (pw_dir_lds(ctw, K, split != 0) > 160 * 1024) return -1;
   const bool wt = a.w_transposed != 0;
+  // data gradients (transposed weights) collect no statistics: without the two sum registers per tile a third step of
+  // prefetch fits the 256-VGPR budget (JN_PW_WT_PF=2: the forward's depth; 4: one more)
+  static const int wt_pf = std::getenv("JN_PW_WT_PF") ? std::atoi(std::getenv("JN_PW_WT_PF")) : 4;
+  if (wt && !split && !a.stats && wt_pf >= 3 && (ctw == 4 || ctw == 2)) {
+    // (gradient views carry the identity table: the transform — two transcendentals and half a dozen VALU ops per value,
+    //  as long as the MFMAs of the step, tools/pwdirbench.hip — is compiled out)
+    static const bool keep_tf = std::getenv("JN_PW_WT_TF") != nullptr;
+    if (a.in_identity && !keep_tf) {
+      if (ctw == 4) launch_pw_dir_t<4, true, false, 4, false, false>(a, M, s); else launch_pw_dir_t<2, true, false, 4, false, false>(a, M, s);
+    } else if (wt_pf >= 4) {
+      if (ctw == 4) launch_pw_dir_t<4, true, false, 4, false>(a, M, s); else launch_pw_dir_t<2, true, false, 4, false>(a, M, s);
+    } else {
+      if (ctw == 4) launch_pw_dir_t<4, true, false, 3, false>(a, M, s); else launch_pw_dir_t<2, true, false, 3, false>(a, M, s);
+    }
+    return 0;
+  }
   if (ctw == 4 && !split && !wt && g_pw_dir_pf == 3) { launch_pw_dir_t<4, false, false, 3>(a, M, s); return 0; }
   if (ctw == 4 && !split && !wt && g_pw_dir_pf == 4) { launch_pw_dir_t<4, false, false, 4>(a, M, s); return 0; }
 #define JN_PD(C_)                                                                                   \

@@ -334,26 +334,36 @@ class ReinforceTrainer:
         return res
 
     def compute_metrics(self, rollout: Dict[str, torch.Tensor], env: NeedleGeneralEnv = None):
-        """src/reinforce.py:217-265."""
-        metrics = dict()
-        returns, masks = rollout["returns"], rollout["logit_masks"]
+        """The reference's metric dictionary (src/reinforce.py:217-265): REINFORCE loss with window-normalised returns,
+        entropy bonus, mean return and episode length over the valid steps; with ``env``, the found-ratios and STOP usage
+        of image 0.  (``train_iteration`` gets the same numbers from ``reinforce_loss_kernel``; this form is the one that
+        carries the autograd graph of ``training_step``.)"""
+        valid = rollout["logit_masks"]
+        n_valid = valid.sum()
+        returns = rollout["returns"]
         if self.config.reward_norm:
-            self.last_return_values.append(returns[masks].clone().detach())
-            mean, std = self.last_return_mean, self.last_return_std
-            advantages = (returns - mean) / (std + 1e-8)
-        else:
-            advantages = returns
-        metrics["action_loss"] = -(rollout["logprobs"] * advantages * masks).sum() / masks.sum()
-        metrics["entropy_loss"] = -(rollout["entropies"] * masks).sum() / masks.sum()
-        metrics["loss"] = metrics["action_loss"] + self.entropy_weight * metrics["entropy_loss"]
-        metrics["returns"] = (rollout["rewards"] * masks).sum(dim=1).mean()
-        metrics["episode_length"] = masks.sum(dim=1).float().mean()
+            self.last_return_values.append(returns[valid].detach().clone())      # feeds the window statistics
+            returns = (returns - self.last_return_mean) / (self.last_return_std + 1e-8)
+
+        def masked_mean(x):
+            return (x * valid).sum() / n_valid
+        action_loss = -masked_mean(rollout["logprobs"] * returns)
+        entropy_loss = -masked_mean(rollout["entropies"])
+        metrics = {
+            "action_loss": action_loss,
+            "entropy_loss": entropy_loss,
+            "loss": action_loss + self.entropy_weight * entropy_loss,
+            "returns": (rollout["rewards"] * valid).sum(dim=1).mean(),
+            "episode_length": valid.sum(dim=1).float().mean(),
+        }
         if env:
-            metrics["prop_patches_found"] = env.prop_patches_found[0]
+            found = env.prop_patches_found[0]
+            metrics["prop_patches_found"] = found
             metrics["prop_bbox_found"] = env.prop_bboxes_found[0]
             if self.stop_enabled:
-                metrics["stop_used"] = env.terminated[0].to(torch.float32)
-                metrics["stop_misused"] = (env.terminated[0] and env.prop_patches_found[0] < 1).to(torch.float32)
+                stopped = env.terminated[0]
+                metrics["stop_used"] = stopped.to(torch.float32)
+                metrics["stop_misused"] = (stopped & (found < 1)).to(torch.float32)
         return metrics
 
     @torch.no_grad()
