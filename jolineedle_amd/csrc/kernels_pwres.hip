@@ -542,6 +542,8 @@ static void launch_pw_dir_t(const ConvArgs& a, long long M, hipStream_t s) {
   // old round-up-to-8 rule gave 640 workgroups for 512 places: a second round at a quarter of the occupancy)
   long long gx = std::max<long long>(1, 256LL * per_cu / ((long long)ny * nz));
   if (nz == 1 && ny > 1) gx = std::max<long long>(8, gx / 8 * 8);
+  static const int gx_div = std::getenv("JN_PW_DIR_GXDIV") ? std::atoi(std::getenv("JN_PW_DIR_GXDIV")) : 1;   // tuning aid
+  if (gx_div > 1 && nz == 1) gx = std::max<long long>(8, gx / gx_div);
   gx = std::min<long long>(gx, (n_tiles + 3) / 4);
   dim3 grid((unsigned)gx, (unsigned)ny, (unsigned)nz);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const float*)a.in, a.in_ld, a.itab, a.w, WT ? a.cout : a.cin,
@@ -583,6 +585,10 @@ int launch_pw_dir(const ConvArgs& a, int ctw, int split, hipStream_t s) {
     } else {
       if (ctw == 4) launch_pw_dir_t<4, true, false, 3, false>(a, M, s); else launch_pw_dir_t<2, true, false, 3, false>(a, M, s);
     }
+    return 0;
+  }
+  if (wt && split && !a.stats && a.in_identity && (ctw == 4 || ctw == 2)) {
+    if (ctw == 4) launch_pw_dir_t<4, true, true, 2, false, false>(a, M, s); else launch_pw_dir_t<2, true, true, 2, false, false>(a, M, s);
     return 0;
   }
   if (ctw == 4 && !split && !wt && g_pw_dir_pf == 3) { launch_pw_dir_t<4, false, false, 3>(a, M, s); return 0; }
@@ -650,7 +656,10 @@ int launch_pw_wide(const ConvArgs& a, hipStream_t s) {
   if (off || !pw_res_supported(a) || a.cin % 64 != 0) return -1;
   const long long M = (long long)a.N * a.H * a.W * (a.n_slots > 1 ? a.n_slots : 1);
   if (a.cin == 64 && a.cout == 64 && M < 65536) return -1;
-  return launch_pw_dir(a, 0, exact ? 0 : 1, s);
+  // JN_PW_WT_SPLIT=1 (experiment): split products for the data gradients only — the backward is linear in g, a GEMM
+  // error of ~5e-6 travels up the chain without the amplification a forward perturbation gets from BatchNorm statistics
+  static const bool wt_split = std::getenv("JN_PW_WT_SPLIT") != nullptr;
+  return launch_pw_dir(a, 0, (!exact || (wt_split && a.w_transposed && a.in_identity)) ? 1 : 0, s);
 }
 
 // Picks the configuration: the weight slice (CT channel tiles per workgroup) must fit LDS with the two pixel buffers;
