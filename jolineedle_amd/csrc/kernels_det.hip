@@ -434,8 +434,12 @@ constexpr int CW_BO = 64, CW_BK = 32, CW_LDG = CW_BO + 4, CW_LDX = CW_BK + 4;
 
 // TH = tile rows: 8 for stride 1; 4 for stride 2 (the 18 x 34 input halo tile of an 8-row tile left room for ONE
 // workgroup per CU and nothing to overlap its loads with: matrix pipe 28 % busy)
-template <int S, typename XT, int TH>
-__global__ __launch_bounds__(256) void conv3_bwd_weight_kernel(const float* __restrict__ gz, int g_ld,
+// SP (default; JN_WW_EXACT=1 keeps fp32 MFMA): as in pw_bwd_weight_wide_kernel, the operands are split into bf16 hi + lo
+// when they leave LDS and every 16 x 16 x 32 block takes three v_mfma_f32_16x16x32_bf16 (hi*hi + hi*lo + lo*hi) — a weight
+// gradient is a leaf, its ~1e-5 relative error reaches the optimiser only.  Lane group g of a 32-pixel k-step takes
+// pixels (row e >> 2, column 4 g + (e & 3)) of the step's two tile rows: conflict-free for both LDS tiles at stride 1.
+template <int S, typename XT, int TH, bool SP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 2 ? 2 : 1))) void conv3_bwd_weight_kernel(const float* __restrict__ gz, int g_ld,
                                                                const XT* __restrict__ x, int x_ld, ChanTab it,
                                                                float* __restrict__ gw, int H, int W, int OH, int OW,
                                                                int Co, int Ci, int tiles_x, int tiles_y, int n_tiles,
@@ -509,16 +513,51 @@ __global__ __launch_bounds__(256) void conv3_bwd_weight_kernel(const float* __re
     }
     __syncthreads();
     if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
-#pragma unroll 2
-    for (int st = 0; st < NPIX / 4; ++st) {              // 4 pixels per k-step: lane group g takes pixel 4 st + g
-      const int pix = 4 * st + g, ty = pix / C3_TW, tx = pix % C3_TW;
-      const float av = Gs[pix * CW_LDG + 16 * wave + lm];            // A[i = cout][k = pixel]
-      const float* xp = Xs + ((ty * S) * IW + tx * S) * CW_LDX + lm;
+    if constexpr (SP) {
+      static_assert(C3_TW == 16 && NPIX % 32 == 0, "a 32-pixel k-step is two rows of the tile");
+#pragma unroll 1
+      for (int ks = 0; ks < NPIX / 32; ++ks) {
+        bf16x8 ah, al;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const float* xt = xp + ((t / 3) * IW + (t % 3)) * CW_LDX;
-        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xt[0], acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xt[16], acc[t][1], 0, 0, 0);
+        for (int e = 0; e < 8; ++e) {
+          const int pix = 32 * ks + 16 * (e >> 2) + 4 * g + (e & 3);
+          const float v = Gs[pix * CW_LDG + 16 * wave + lm];          // A[i = cout][k = pixel]
+          const bf16_t h = (bf16_t)v;
+          ah[e] = h; al[e] = (bf16_t)(v - (float)h);
+        }
+        const float* xp = Xs + ((2 * ks * S) * IW + 4 * g * S) * CW_LDX + lm;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const float* xt = xp + ((t / 3) * IW + (t % 3)) * CW_LDX;
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            bf16x8 bh, bl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float v = xt[(((e >> 2) * S) * IW + (e & 3) * S) * CW_LDX + 16 * hh];
+              const bf16_t h = (bf16_t)v;
+              bh[e] = h; bl[e] = (bf16_t)(v - (float)h);
+            }
+            f32x4 d = acc[t][hh];
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d, 0, 0, 0);
+            acc[t][hh] = d;
+          }
+        }
+      }
+    } else {
+#pragma unroll 2
+      for (int st = 0; st < NPIX / 4; ++st) {              // 4 pixels per k-step: lane group g takes pixel 4 st + g
+        const int pix = 4 * st + g, ty = pix / C3_TW, tx = pix % C3_TW;
+        const float av = Gs[pix * CW_LDG + 16 * wave + lm];            // A[i = cout][k = pixel]
+        const float* xp = Xs + ((ty * S) * IW + tx * S) * CW_LDX + lm;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const float* xt = xp + ((t / 3) * IW + (t % 3)) * CW_LDX;
+          acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xt[0], acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xt[16], acc[t][1], 0, 0, 0);
+        }
       }
     }
   }
@@ -543,22 +582,25 @@ int launch_conv3_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtyp
   if (gx < 1) gx = 1;
   if (gx > n_tiles) gx = n_tiles;
   dim3 grid((unsigned)gx, nbo, nbk * sb.n);
-#define JN_CW(S_, T_, TH_)                                                                                                 \
+  static const bool exact = std::getenv("JN_WW_EXACT") != nullptr;
+#define JN_CW(S_, T_, TH_, SP_)                                                                                       \
   {                                                                                                                   \
     const size_t smem = ((size_t)TH_ * C3_TW * CW_LDG + (size_t)(TH_ * S_ + 2) * (C3_TW * S_ + 2) * CW_LDX) * sizeof(float); \
     if (smem > 64 * 1024) {                                                                                           \
       static bool raised = false;                                                                                     \
       if (!raised) {                                                                                                  \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bwd_weight_kernel<S_, T_, TH_>),                    \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bwd_weight_kernel<S_, T_, TH_, SP_>),          \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                             \
         raised = true;                                                                                                \
       }                                                                                                               \
     }                                                                                                                 \
-    hipLaunchKernelGGL((conv3_bwd_weight_kernel<S_, T_, TH_>), grid, dim3(256), smem, s, gz, g_ld, (const T_*)x, x_ld, it, \
-                       gw, H, W, OH, OW, Co, Ci, tiles_x, tiles_y, n_tiles, sb);                                      \
+    hipLaunchKernelGGL((conv3_bwd_weight_kernel<S_, T_, TH_, SP_>), grid, dim3(256), smem, s, gz, g_ld, (const T_*)x, x_ld, \
+                       it, gw, H, W, OH, OW, Co, Ci, tiles_x, tiles_y, n_tiles, sb);                                  \
   }
-  if (x_dtype == JN_BF16) { if (stride == 1) JN_CW(1, bf16_t, 4) else JN_CW(2, bf16_t, 4) }
-  else { if (stride == 1) JN_CW(1, float, 4) else JN_CW(2, float, 4) }
+#define JN_CW2(S_, T_) { if (exact) JN_CW(S_, T_, 4, false) else JN_CW(S_, T_, 4, true) }
+  if (x_dtype == JN_BF16) { if (stride == 1) JN_CW2(1, bf16_t) else JN_CW2(2, bf16_t) }
+  else { if (stride == 1) JN_CW2(1, float) else JN_CW2(2, float) }
+#undef JN_CW2
 #undef JN_CW
   return 0;
 }
