@@ -526,11 +526,20 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
   for (int c = tid; c < K; c += 256) { Cs[7 * N + c] = it.sc[c]; Cs[7 * N + K + c] = it.sh[c]; Cs[7 * N + 2 * K + c] = it.fl[c]; }
   if (RED)
     for (int c = tid; c < 8 * K; c += 256) Cs[7 * N + 3 * K + c] = 0.0f;       // [4 waves][K][2] input-layer BN sums
-  f32x4 dw[CTN][CTK];
+  // weight-gradient tiles of this wave: all of them (fp32 form) or one half, split along cin when CTK is even, else cout
+#ifdef JN_FUSED_DW_EXACT
+  constexpr bool DW_SPLIT = false;
+#else
+  constexpr bool DW_SPLIT = (CTK % 2 == 0) || (CTN % 2 == 0);
+#endif
+  constexpr bool DW_HALF_K = DW_SPLIT && CTK % 2 == 0;
+  constexpr int DW_AN = !DW_SPLIT ? CTN : (DW_HALF_K ? CTN : CTN / 2), DW_BN = !DW_SPLIT ? CTK : (DW_HALF_K ? CTK / 2 : CTK);
+  const int dw_a0 = (DW_SPLIT && !DW_HALF_K) ? (wave & 1) * DW_AN : 0, dw_b0 = DW_HALF_K ? (wave & 1) * DW_BN : 0;
+  f32x4 dw[DW_AN][DW_BN];
 #pragma unroll
-  for (int a = 0; a < CTN; ++a)
+  for (int a = 0; a < DW_AN; ++a)
 #pragma unroll
-    for (int b = 0; b < CTK; ++b) dw[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < DW_BN; ++b) dw[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const long long n_tiles = (M + 63) / 64;
   f32x4 rg[NGq], rz[NGq], rx[NAq];
@@ -646,22 +655,58 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
         }
       }
     }
-    // ---- phase 3: dW[cout][cin] += sum_pixel g_z[pixel][cout] * a[pixel][cin]; wave = 16 pixels = 4 k-steps
+    // ---- phase 3: dW[cout][cin] += sum_pixel g_z[pixel][cout] * a[pixel][cin]
+    if constexpr (DW_SPLIT) {
+      // split-bf16 products (a weight gradient is a leaf, see pw_bwd_weight_wide_kernel): one 32-pixel k-step per wave —
+      // waves 0, 1 take pixels 0..31, waves 2, 3 pixels 32..63 — and half of the output tiles each, so a wave holds
+      // HALF the accumulators of the fp32 form.  Lane group gq, element e -> pixel 4 gq + (e & 3) + 16 (e >> 2).
+      const int prow = 32 * (wave >> 1) + 4 * gq;
+      bf16x8 bh[DW_BN], bl[DW_BN];
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      const int row = wave * 16 + 4 * st + gq;
-      float av[CTN], bv[CTK];
+      for (int b = 0; b < DW_BN; ++b)
 #pragma unroll
-      for (int a = 0; a < CTN; ++a) av[a] = Gs[row * LDG + 16 * a + lm];
+        for (int e = 0; e < 8; ++e) {
+          float v = As[(prow + (e & 3) + 16 * (e >> 2)) * LDA + 16 * (dw_b0 + b) + lm];
+          if constexpr (RED) v = p_fl[dw_b0 + b] != 0.0f ? silu_(fmaf(v, p_sc[dw_b0 + b], p_sh[dw_b0 + b])) : v;
+          const bf16_t h = (bf16_t)v;
+          bh[b][e] = h; bl[b][e] = (bf16_t)(v - (float)h);
+        }
 #pragma unroll
-      for (int b = 0; b < CTK; ++b) {
-        bv[b] = As[row * LDA + 16 * b + lm];
-        if constexpr (RED) bv[b] = p_fl[b] != 0.0f ? silu_(fmaf(bv[b], p_sc[b], p_sh[b])) : bv[b];
+      for (int a = 0; a < DW_AN; ++a) {
+        bf16x8 ah, al;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = Gs[(prow + (e & 3) + 16 * (e >> 2)) * LDG + 16 * (dw_a0 + a) + lm];
+          const bf16_t h = (bf16_t)v;
+          ah[e] = h; al[e] = (bf16_t)(v - (float)h);
+        }
+#pragma unroll
+        for (int b = 0; b < DW_BN; ++b) {
+          f32x4 d = dw[a][b];
+          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[b], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[b], d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[b], d, 0, 0, 0);
+          dw[a][b] = d;
+        }
       }
+    } else {
+      // fp32 MFMA: wave = 16 pixels = 4 k-steps, every output tile in every wave
 #pragma unroll
-      for (int a = 0; a < CTN; ++a)
+      for (int st = 0; st < 4; ++st) {
+        const int row = wave * 16 + 4 * st + gq;
+        float av[CTN], bv[CTK];
 #pragma unroll
-        for (int b = 0; b < CTK; ++b) dw[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], dw[a][b], 0, 0, 0);
+        for (int a = 0; a < CTN; ++a) av[a] = Gs[row * LDG + 16 * a + lm];
+#pragma unroll
+        for (int b = 0; b < CTK; ++b) {
+          bv[b] = As[row * LDA + 16 * b + lm];
+          if constexpr (RED) bv[b] = p_fl[b] != 0.0f ? silu_(fmaf(bv[b], p_sc[b], p_sh[b])) : bv[b];
+        }
+#pragma unroll
+        for (int a = 0; a < CTN; ++a)
+#pragma unroll
+          for (int b = 0; b < CTK; ++b) dw[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], dw[a][b], 0, 0, 0);
+      }
     }
   }
   if constexpr (RED) {
@@ -672,19 +717,36 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
       atomicAdd(&red_in[(blockIdx.x % JN_NREP) * red_rep_stride + tid],
                 (double)(rs[tid] + rs[2 * K + tid] + rs[4 * K + tid] + rs[6 * K + tid]));
   }
-  // cross-wave sum of dW (one wave at a time: plain LDS read-modify-write), then one set of atomics
-  for (int wv = 0; wv < 4; ++wv) {
-    __syncthreads();
-    if (wave == wv) {
+  // cross-wave sum of dW (plain LDS read-modify-write, one round per wave that shares tiles), then one set of atomics
+  if constexpr (DW_SPLIT) {
+    for (int ph = 0; ph < 2; ++ph) {                 // waves (0, 1) hold disjoint tiles, (2, 3) the same two sets
+      __syncthreads();
+      if ((wave >> 1) == ph) {
 #pragma unroll
-      for (int a = 0; a < CTN; ++a)
+        for (int a = 0; a < DW_AN; ++a)
 #pragma unroll
-        for (int b = 0; b < CTK; ++b)
+          for (int b = 0; b < DW_BN; ++b)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float* tp = &Ts[(16 * a + 4 * gq + r) * K + 16 * b + lm];
-            *tp = (wv == 0 ? 0.0f : *tp) + dw[a][b][r];
-          }
+            for (int r = 0; r < 4; ++r) {
+              float* tp = &Ts[(16 * (dw_a0 + a) + 4 * gq + r) * K + 16 * (dw_b0 + b) + lm];
+              *tp = (ph == 0 ? 0.0f : *tp) + dw[a][b][r];
+            }
+      }
+    }
+  } else {
+    for (int wv = 0; wv < 4; ++wv) {
+      __syncthreads();
+      if (wave == wv) {
+#pragma unroll
+        for (int a = 0; a < DW_AN; ++a)
+#pragma unroll
+          for (int b = 0; b < DW_BN; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float* tp = &Ts[(16 * a + 4 * gq + r) * K + 16 * b + lm];
+              *tp = (wv == 0 ? 0.0f : *tp) + dw[a][b][r];
+            }
+      }
     }
   }
   __syncthreads();
