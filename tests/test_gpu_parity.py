@@ -518,8 +518,10 @@ def _conditioning_probe(oracle, run, ref64, samples=1):
     return out
 
 
-def _check_grads(grads, oracle, skip_prefix=("yolox",), tag="", ref64=None, probe=None):
+def _check_grads(grads, oracle, skip_prefix=("yolox",), tag="", ref64=None, probe=None, full_size=None):
     import os
+    if full_size is None:
+        full_size = ref64 is not None
     rows, checked = [], 0
     for name, p in oracle.named_parameters():
         if any(name.startswith(sp) for sp in skip_prefix) or p.grad is None or not p.requires_grad:
@@ -550,7 +552,7 @@ def _check_grads(grads, oracle, skip_prefix=("yolox",), tag="", ref64=None, prob
     for err, name, scale, noise in rows:
         # (one probe run samples the near-ties once: a flip it shows on one tensor of a family can land on a sibling
         #  under other rounding — hence also FAMILY_FACTOR x the family's worst probe distance)
-        bar = max(grad_bar(name, ref64 is not None), NOISE_FACTOR * noise, PROBE_FACTOR * (probe or {}).get(name, 0.0),
+        bar = max(grad_bar(name, full_size), NOISE_FACTOR * noise, PROBE_FACTOR * (probe or {}).get(name, 0.0),
                   FAMILY_FACTOR * fam_probe.get(family(name), 0.0))
         assert err < bar, (fam_probe, tag, name, err, scale, noise, (probe or {}).get(name), sorted(rows, reverse=True)[:5])
     return checked
@@ -587,13 +589,9 @@ def test_reinforce_iteration_gradients_vs_oracle(stop, B, P, Tn, grad_slots, arc
     product, oracle = make_pair(5, patch_size=P, block_size=Tn, nclasses=nA, with_detector=False, image_processor=None, **arch)
     images, bboxes, start = synth_batch(B, 3, 4, P, seed=41)
     forced = torch.randint(0, 8, (B, Tn), generator=torch.Generator().manual_seed(3))
-    ref64 = probe = None
-    if P >= 448:                                         # see _check_grads: fp64 oracle + the fp32 oracle's own noise
-        import copy
-        o64 = copy.deepcopy(oracle).double()
-        _oracle_reinforce_grads(o64, images.double(), bboxes, start, forced, P, Tn, stop, 0.25, 1.5, 0.01)
-        ref64 = _grads64(o64)
-        probe = _conditioning_probe(oracle, lambda o: _oracle_reinforce_grads(o, images, bboxes, start, forced, P, Tn, stop, 0.25, 1.5, 0.01), ref64)
+    # (448 px / T = 20: one fp32 oracle pass — three minutes of CPU time went into the fp64 and probe passes of this case
+    #  alone; the full-size bars (twice the stage bars) apply, the fp64 / conditioning-probe treatment stays with the
+    #  supervised step at 448 px, the worse-conditioned and much cheaper case)
     ro, m = _oracle_reinforce_grads(oracle, images, bboxes, start, forced, P, Tn, stop, 0.25, 1.5, 0.01)
     cfg = _cfg(T=Tn, stop=stop, learning_rate=1e-3, gradient_accumulation=1)
     tr = ja.ReinforceTrainer(cfg, product)
@@ -601,8 +599,8 @@ def test_reinforce_iteration_gradients_vs_oracle(stop, B, P, Tn, grad_slots, arc
     env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, stop)
     got_m = tr.train_iteration(env, forced_actions=forced, start_positions=start, optimizer_step=False)
     for k in ("action_loss", "entropy_loss", "loss", "returns", "episode_length"):
-        assert abs(float(got_m[k]) - float(m[k])) < 2e-4, (k, float(got_m[k]), float(m[k]))
-    checked = _check_grads(product.engine_grads(), oracle, tag=f"reinforce P={P} T={Tn} {arch.get('gpt_backbone', 'nano')}", ref64=ref64, probe=probe)
+        assert abs(float(got_m[k]) - float(m[k].detach())) < 2e-4, (k, float(got_m[k]), float(m[k].detach()))
+    checked = _check_grads(product.engine_grads(), oracle, tag=f"reinforce P={P} T={Tn} {arch.get('gpt_backbone', 'nano')}", full_size=P >= 448)
     assert checked > 150
     # running statistics moved Tn times, as in the reference's train-mode rollout
     product.pull_bn_statistics()
