@@ -43,20 +43,29 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
 # profiles/r01_g_pmc_conv_stack_traffic_{train,eval}.txt — the eval pass fuses DWConv / shortcut adds and moves
 # fewer bytes than the layer-wise algorithmic figure.
 PMC_TRAFFIC_BYTES_B64_448 = {"train": 5.651e9, "rollout": 4.399e9}       # round-1 values, used when no newer file exists
-# Backward of the same stack: 2 (in + out) + 2 out = 2 * 17.44 M + 2 * 7.35 M elements per patch.
-NANO_448_BWD_ELEMS_PER_PATCH = 2 * 17.44e6 + 2 * 7.35e6
+# Backward of the same stack, ALGORITHMIC bytes: per conv layer read g_out and z_out, read x_in, write g_in
+# = 2 (in + out) = 2 * 17.44 M elements per patch = 139.5 MB fp32.  The implementation of a layer whose BatchNorm-backward
+# sums are not fused into a neighbour's kernel reads g_out and z_out a second time (+ 2 out = 2 * 7.35 M elements): that
+# re-read is NOT algorithmic (36 of the 77 layers already avoid it) and is only reported as a labelled second figure.
+NANO_448_BWD_ELEMS_PER_PATCH = 2 * 17.44e6
+NANO_448_BWD_REREAD_ELEMS_PER_PATCH = 2 * 7.35e6
 
 
 def pmc_traffic(mode):
-    """HBM bytes of one forward conv-stack pass (B=64, 448 px, fp32) from the committed PMC passes of THIS bench command
-    (tools/pmc_traffic.py -> profiles/pmc_traffic_latest.json; rocprofv3 cannot run inside the timed process)."""
+    """(HBM bytes per glimpse step at B=64, 448 px, fp32; the profile file they come from) for `mode` = "train" / "rollout"
+    (one forward conv-stack pass) or "backward" (the conv-stack backward of one glimpse step), from the committed PMC passes
+    of THIS bench command — separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs summarised by
+    tools/pmc_traffic.py into profiles/pmc_traffic_latest.json (rocprofv3 cannot run inside the timed process)."""
     f = ROOT / "profiles" / "pmc_traffic_latest.json"
     if f.exists():
         try:
-            return float(json.loads(f.read_text())[mode])
+            d = json.loads(f.read_text())
+            return float(d[mode]), d.get("files", {}).get(mode, "profiles/pmc_traffic_latest.json")
         except (KeyError, ValueError):
             pass
-    return PMC_TRAFFIC_BYTES_B64_448.get(mode)
+    if mode in PMC_TRAFFIC_BYTES_B64_448:
+        return PMC_TRAFFIC_BYTES_B64_448[mode], f"profiles/r01_g_pmc_conv_stack_traffic_{'train' if mode == 'train' else 'eval'}.txt"
+    return None, None
 
 
 def synth_inputs(B, G, P, seed, device):
@@ -398,6 +407,7 @@ def main():
 
     if rank == 0:
         conv_ms_per_launch = conv_ms / max(glimpse_steps, 1)  # one PAFPN pass over B patches
+        headline_shape = (B, P, args.dtype) == (64, 448, "f32")
         esz = 2.0 if args.dtype == "bf16" else 4.0
         algo_bytes = NANO_448_ELEMS_PER_PATCH * (P / 448.0) ** 2 * esz * B
         achieved = algo_bytes / (conv_ms_per_launch * 1e-3) / 1e9
@@ -423,22 +433,42 @@ def main():
                                                    "), one pass over the batch per glimpse step",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic(args.mode) if (B, P, args.dtype) == (64, 448, "f32") else None,
+                         "traffic": headline_shape and pmc_traffic(args.mode)[0] or None,
+                         "traffic_source": headline_shape and pmc_traffic(args.mode)[1] or None,
                          "ms_per_launch": round(conv_ms_per_launch, 4),
-                         "algorithmic_bytes_per_launch": int(algo_bytes)},
+                         "algorithmic_bytes_per_launch": int(algo_bytes),
+                         "timing": "HIP events around the conv section of every glimpse step, on the launch stream "
+                                   "(jn_set_profiling / jn_last_timing); rocprofv3 kernel stats of the same command: "
+                                   "profiles/r03_*_train_iteration_kernel_stats.csv"},
         }
         if train and args.config == "c3":
-            # second entry: the step-batched conv-stack backward (embed_fpn + PAFPN), priced at DESIGN.md §4's algorithmic
-            # backward traffic: per conv layer read g_out and z_out twice (the BN-backward sums must be complete before g_z
-            # exists), read x_in, write g_in = 2 (in + out) + 2 out elements
+            # second entry: the step-batched conv-stack backward (embed_fpn + PAFPN), priced at its ALGORITHMIC traffic:
+            # per conv layer read g_out and z_out, read x_in, write g_in = 2 (in + out) elements (139.5 MB / patch)
             bwd_bytes = NANO_448_BWD_ELEMS_PER_PATCH * (P / 448.0) ** 2 * 4.0 * B
+            bwd_reread = NANO_448_BWD_REREAD_ELEMS_PER_PATCH * (P / 448.0) ** 2 * 4.0 * B
             bwd_ms_per_pass = bwd_ms / max(glimpse_steps, 1)
             bwd_ach = bwd_bytes / (bwd_ms_per_pass * 1e-3) / 1e9
+            bwd_traffic, bwd_src = pmc_traffic("backward") if headline_shape else (None, None)
             out["roofline_backward"] = {
                 "bound": "hbm", "kernel": "yolox-nano PAFPN conv-stack backward (step-batched: fused 1x1 / depthwise data + "
                                           "weight gradients, BN-backward reductions, stem weight gradient), per glimpse step",
                 "achieved": round(bwd_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bwd_ach / HBM_PEAK_GBS, 4),
-                "traffic": None, "ms_per_launch": round(bwd_ms_per_pass, 4), "algorithmic_bytes_per_launch": int(bwd_bytes)}
+                "traffic": bwd_traffic, "traffic_source": bwd_src,
+                "ms_per_launch": round(bwd_ms_per_pass, 4), "algorithmic_bytes_per_launch": int(bwd_bytes),
+                "achieved_incl_one_bn_reduce_reread": round((bwd_bytes + bwd_reread) / (bwd_ms_per_pass * 1e-3) / 1e9, 1),
+                "note": "algorithmic = 2 (in + out) elements per layer; the labelled second figure adds one re-read of g_out and "
+                        "z_out per layer (what a separate BatchNorm-backward reduction pass costs) and is not a roofline claim",
+                "timing": "HIP events around the conv-stack backward of the iteration (jn_last_timing(2)); per-op table: "
+                          "profiles/r03_*_backward_table_f32.txt"}
+            # third entry: the whole iteration against the same roof — forward + backward algorithmic bytes of every
+            # executed glimpse step over the wall time of the iteration (everything else included in the time)
+            it_bytes = (algo_bytes + bwd_bytes) * glimpse_steps
+            it_ach = it_bytes / elapsed / 1e9
+            out["roofline_iteration"] = {
+                "bound": "hbm", "kernel": "whole REINFORCE iteration (conv-stack forward + backward algorithmic bytes of all "
+                                          "glimpse steps over the iteration's wall time)",
+                "achieved": round(it_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(it_ach / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_iteration": int(it_bytes / max(args.steps, 1))}
         if args.detect:
             out["metric"] += " + yolox-s detection on every visited patch"
             out["config"]["phase"] += "; do_detection=True (yolox-s PAFPN + head + NMS per glimpse)"

@@ -254,6 +254,18 @@ int jn_optimizer_steps(jn_ctx* ctx, int group, int* steps, int set);
 int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* current_actions_dev,
                        const int64_t* next_actions_dev, const int64_t* positions_dev, const uint8_t* masks_dev,
                        int B, int T, float stop_weight, float* logits_out_dev, float* metrics_dev, void* stream);
+/* Supervised autograd bridge — the two halves of jn_supervised_step around the CALLER's loss, so that the reference's
+ * supervised loop runs unchanged (src/supervised.py:863-868: `action_logits, embeddings = model(patches, current_actions,
+ * classes=classes, positions=positions)`, then :138-177 its cross-entropy, then :897 `loss.backward()`):
+ * jn_supervised_forward = GPT.forward (src/models/gpt.py:481-534, full-sequence, train mode: BatchNorm statistics over
+ * the B*T patches, running statistics updated, dropout) -> logits_out_dev [B,T,n_actions], final_emb_out_dev [B,T+1,C]
+ * (optional); jn_supervised_backward = the backward of that forward for GIVEN d loss / d logits [B,T,n_actions],
+ * gradients ACCUMULATE in the arena.  patches / actions / positions must stay alive until the backward; any pass over
+ * the patch encoder in between makes the saved activations stale and the backward fails with JN_ESTATE. */
+int jn_supervised_forward(jn_ctx* ctx, const float* patches_dev, const int64_t* current_actions_dev,
+                          const int64_t* positions_dev, int B, int T, float* logits_out_dev, float* final_emb_out_dev,
+                          void* stream);
+int jn_supervised_backward(jn_ctx* ctx, const float* dlogits_dev, void* stream);
 /* clip_grad_value_(clip_value) + AdamW (torch defaults) over the optim_gpt parameters
  * (src/reinforce.py:344-346, src/models/gpt.py:552-557); grad_scale multiplies the gradients first
  * (1/world_size after a SUM all-reduce). */

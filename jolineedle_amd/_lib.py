@@ -85,6 +85,9 @@ SIGNATURES = {
                                     C.POINTER(JnTrainOpts), C.POINTER(JnRolloutOut), C.c_void_p, C.c_void_p]),
     "jn_supervised_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jn_supervised_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
+    "jn_supervised_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "jn_optimizer_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "jn_arena_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "jn_set_grad_arena": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -58,16 +58,30 @@ def _strip_ddp(sd):
     return {k.replace("module.", ""): v for k, v in sd.items()}
 
 
-def save_checkpoint(model, folder, best: bool = False, extra: dict = None, optim_gpt=None, optim_yolox=None) -> Path:
-    """main.py:436-449's checkpoint dict.  `optim_gpt` / `optim_yolox`: the optimisers of ``model.configure_optimizers``
-    (default: fresh front ends onto the engine's state, which is where the moments live)."""
+def save_checkpoint(model, folder, best: bool = False, extra: dict = None, optim_gpt=None, optim_yolox=None,
+                    train_config=None) -> Path:
+    """main.py:436-449's checkpoint dict.  `optim_gpt` / `optim_yolox`: the optimisers of ``model.configure_optimizers``.
+    Without them the model's most recent optimisers are used, else fresh front ends onto the engine's state (where the
+    moments live) carrying `train_config`'s learning rates — the file's ``param_groups`` are what a resumed run trains
+    with (``AdamW.load_state_dict`` restores lr), so they must hold real values."""
     folder = Path(folder)
     folder.mkdir(parents=True, exist_ok=True)
     if hasattr(model, "pull_parameters") and getattr(model, "_engine", None) is not None:
         model.pull_parameters()            # optimiser-updated weights and BN statistics live in the engine
+    if optim_gpt is None and getattr(model, "_last_optimizers", None) is not None:
+        optim_gpt, optim_yolox = model._last_optimizers
     if optim_gpt is None and hasattr(model, "configure_optimizers") and torch.cuda.is_available():
         from .config import CfgNode as _C
-        optim_gpt, optim_yolox = model.configure_optimizers(_C(learning_rate=0.0, yolo_lr=0.0))
+        # learning rates for the file's param_groups: the train config, else what the engine's optimiser last stepped
+        # with (train_iteration records it), else torch.optim.AdamW's default — never 0, which a resumed run would train with
+        last = getattr(model, "_last_lr", None) or (1e-3, 1e-3)
+        lr = float(getattr(train_config, "learning_rate", 0.0) or 0.0) if train_config is not None else 0.0
+        lr = lr if lr > 0.0 else float(last[0])
+        ylr = float(getattr(train_config, "yolo_lr", 0.0) or 0.0) if train_config is not None else 0.0
+        ylr = ylr if ylr > 0.0 else float(last[1])
+        keep = getattr(model, "_last_optimizers", None)
+        optim_gpt, optim_yolox = model.configure_optimizers(_C(learning_rate=lr, yolo_lr=ylr))
+        object.__setattr__(model, "_last_optimizers", keep)
     ck = {"model": {k: v.detach().cpu() for k, v in model.state_dict().items()},
           "optimizer-gpt": optim_gpt.state_dict() if optim_gpt is not None else {},
           "optimizer-yolox": optim_yolox.state_dict() if optim_yolox is not None else {}}

@@ -721,6 +721,9 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
   const int n_ops = (with_head || net.n_backbone_ops < 0) ? (int)net.ops.size() : net.n_backbone_ops;
   const int MB = ctx->cfg.max_batch;
   int rc;
+  // the autograd bridges differentiate LATER what a forward left in the workspace: a pass over the same slots in
+  // between makes that state stale (the backward entry points then fail with JN_ESTATE instead of computing garbage)
+  if (ni == ctx->enc_net) { if (slot == 0) ctx->sup_valid = false; else ctx->train_out_valid = false; }
   if (!train && (rc = refresh_eval_table(ctx, net, s))) return rc;
   double* stats = train ? slot_stats(net, slot) : nullptr;
   float* save = train ? slot_save(net, slot) : nullptr;
@@ -1661,6 +1664,8 @@ static int rollout_impl(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev
   const jn_config& c = ctx->cfg;
   const EnvState& e = ctx->env;
   const int B = e.B, T = e.T, C = c.n_embd, P = c.patch_size, nA = c.n_actions;
+  ctx->train_out_valid = false;       // every rollout restarts n_done / the env state the REINFORCE backward reads
+  if (train) ctx->sup_valid = false;  // ... and a train-mode one the per-token buffers the supervised backward reads
   RolloutBuffers r{out->rewards_dev, out->returns_dev, out->logprobs_dev, out->entropies_dev, out->masks_dev,
                    out->logit_masks_dev, out->positions_dev, out->actions_dev, out->logits_dev, out->final_emb_dev};
   // zero-fill so that columns past an early stop read as the reference's absent columns would be cut
@@ -2035,14 +2040,13 @@ static int reinforce_backward_impl(jn_ctx* ctx, const jn_rollout_out* out, int S
   return JN_OK;
 }
 
-// One supervised (teacher-forced) training step minus the optimiser: src/supervised.py:863-902 with the
-// detector term off.  GPT.forward on the full sequence (B*T patches through the encoder in ONE train-mode
-// pass, 1-D positions 0..T-1), CrossEntropy(weight[STOP] = stop_weight) over non-padding tokens, backward.
-int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* current_actions_dev,
-                       const int64_t* next_actions_dev, const int64_t* positions_dev, const uint8_t* masks_dev, int B,
-                       int T, float stop_weight, float* logits_out_dev, float* metrics_dev, void* stream) {
-  JN_CHECK(ctx && patches_dev && current_actions_dev && next_actions_dev && masks_dev && metrics_dev, JN_EINVAL,
-           "jn_supervised_step: null argument");
+// Teacher-forced (supervised) step, src/supervised.py:863-902 with the detector term off, in two halves so that the
+// reference's own loop can sit between them (GPT.forward -> its CE loss -> loss.backward(), the supervised autograd
+// bridge): the forward runs GPT.forward on the full sequence (B*T patches through the encoder in ONE train-mode pass,
+// 1-D positions 0..T-1) and leaves the logits in ctx->sup_logits; the backward takes d loss / d logits in ctx->dlogits.
+static int supervised_forward_impl(jn_ctx* ctx, const float* patches_dev, const int64_t* current_actions_dev,
+                                   const int64_t* positions_dev, int B, int T, float* logits_out_dev, float* final_emb_out_dev,
+                                   hipStream_t s) {
   JN_CHECK(ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
   const jn_config& c = ctx->cfg;
   JN_CHECK(!c.no_patch_emb, JN_ESTATE, "training without a patch encoder is not supported");
@@ -2051,12 +2055,12 @@ int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* cur
   JN_CHECK(B >= 1 && B * T <= c.max_batch, JN_EINVAL, "B*T = %d patches exceed max_batch = %d", B * T, c.max_batch);
   JN_CHECK(!c.use_pos_emb || positions_dev, JN_EINVAL, "positions are required when use_pos_emb is set");
   JN_HIP(hipSetDevice(c.device));
-  hipStream_t s = (hipStream_t)stream;
   int rc;
+  ctx->train_out_valid = false;     // the per-token training buffers (efpn_train, tok_emb_train, dropout seed) are reused
   if ((rc = ensure_train_state(ctx))) return rc;
   if ((rc = build_grad_layer_table(ctx))) return rc;
   const int C = c.n_embd, nA = c.n_actions, P = c.patch_size, N = B * T, L = T + 1;
-  const int HW = ctx->efpn_h * ctx->efpn_w, K = HW * C;
+  const int HW = ctx->efpn_h * ctx->efpn_w;
   if (!ctx->efpn_train) {
     const size_t MBt = (size_t)c.max_batch * c.block_size;
     if ((rc = dev_alloc(ctx, &ctx->efpn_train, MBt * HW * C))) return rc;
@@ -2070,7 +2074,6 @@ int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* cur
     if ((rc = dev_alloc(ctx, &ctx->sup_logits, (size_t)c.max_batch * c.block_size * nA))) return rc;
   }
   // ---- forward: encoder over all B*T patches at once (BN statistics over B*T) ----
-  Net& net = ctx->nets[ctx->enc_net];
   StemSrc ss{patches_dev, nullptr, 3LL * P * P, (long long)P * P, P};
   if ((rc = run_net(ctx, ctx->enc_net, N, ss, 0, 1, nullptr, 0, s))) return rc;
   if ((rc = run_embed_fpn(ctx, N, 0, ctx->efpn_train, nullptr, 0, s))) return rc;
@@ -2097,8 +2100,26 @@ int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* cur
   }
   if (logits_out_dev)
     JN_HIP(hipMemcpyAsync(logits_out_dev, ctx->sup_logits, (size_t)N * nA * sizeof(float), hipMemcpyDeviceToDevice, s));
-  // ---- loss + backward ----
-  launch_ce_loss(ctx->sup_logits, next_actions_dev, masks_dev, stop_weight, ctx->dlogits, metrics_dev, N, nA, T, s);
+  if (final_emb_out_dev)
+    JN_HIP(hipMemcpyAsync(final_emb_out_dev, ctx->sup_final_emb, (size_t)B * L * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+  ctx->sup = {patches_dev, current_actions_dev, positions_dev, B, T};
+  ctx->sup_valid = true;      // (run_net on slot 0 of the encoder cleared it: set last)
+  JN_HIP(hipGetLastError());
+  return JN_OK;
+}
+
+// backward of the forward above for d loss / d logits [B][T][nA] in ctx->dlogits
+static int supervised_backward_impl(jn_ctx* ctx, hipStream_t s) {
+  JN_CHECK(ctx->sup_valid, JN_ESTATE,
+           "the activations of the supervised forward were overwritten (another pass used the encoder's workspace) or no forward ran");
+  const jn_config& c = ctx->cfg;
+  const int B = ctx->sup.B, T = ctx->sup.T;
+  const int64_t* current_actions_dev = ctx->sup.actions; const int64_t* positions_dev = ctx->sup.positions;
+  const int C = c.n_embd, nA = c.n_actions, P = c.patch_size, N = B * T;
+  const int HW = ctx->efpn_h * ctx->efpn_w, K = HW * C;
+  int rc;
+  Net& net = ctx->nets[ctx->enc_net];
+  StemSrc ss{ctx->sup.patches, nullptr, 3LL * P * P, (long long)P * P, P};
   const int nL = c.n_layer, nh = c.n_head;
   const GptW& g = ctx->gpt;
   GptBwdArgs ba{};
@@ -2147,6 +2168,43 @@ int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* cur
   if ((rc = run_net_backward(ctx, ctx->enc_net, N, ss, 0, s))) return rc;
   JN_HIP(hipGetLastError());
   return JN_OK;
+}
+
+// One supervised (teacher-forced) training step minus the optimiser: forward, CrossEntropy(weight[STOP] = stop_weight)
+// over non-padding tokens, backward.
+int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* current_actions_dev,
+                       const int64_t* next_actions_dev, const int64_t* positions_dev, const uint8_t* masks_dev, int B,
+                       int T, float stop_weight, float* logits_out_dev, float* metrics_dev, void* stream) {
+  JN_CHECK(ctx && patches_dev && current_actions_dev && next_actions_dev && masks_dev && metrics_dev, JN_EINVAL,
+           "jn_supervised_step: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = supervised_forward_impl(ctx, patches_dev, current_actions_dev, positions_dev, B, T, logits_out_dev, nullptr, s);
+  if (rc) return rc;
+  launch_ce_loss(ctx->sup_logits, next_actions_dev, masks_dev, stop_weight, ctx->dlogits, metrics_dev, B * T, ctx->cfg.n_actions, T, s);
+  return supervised_backward_impl(ctx, s);
+}
+
+// Supervised autograd bridge: GPT.forward(patches [B,T,3,P,P], actions [B,T], classes = 0, positions [B,T,2]) in train
+// mode (src/models/gpt.py:481-534 as called by src/supervised.py:863-868) -> logits [B,T,nA], final_emb [B,T+1,C].  The
+// input buffers must stay alive until jn_supervised_backward.
+int jn_supervised_forward(jn_ctx* ctx, const float* patches_dev, const int64_t* current_actions_dev, const int64_t* positions_dev,
+                          int B, int T, float* logits_out_dev, float* final_emb_out_dev, void* stream) {
+  JN_CHECK(ctx && patches_dev && current_actions_dev && logits_out_dev, JN_EINVAL, "jn_supervised_forward: null argument");
+  return supervised_forward_impl(ctx, patches_dev, current_actions_dev, positions_dev, B, T, logits_out_dev, final_emb_out_dev,
+                                 (hipStream_t)stream);
+}
+
+// ... and its backward for GIVEN d loss / d logits [B,T,nA] (what torch hands to the logits node when the caller's
+// loss.backward() runs, src/supervised.py:897): parameter gradients accumulate in the gradient arena.
+int jn_supervised_backward(jn_ctx* ctx, const float* dlogits_dev, void* stream) {
+  JN_CHECK(ctx && dlogits_dev, JN_EINVAL, "jn_supervised_backward: null argument");
+  JN_CHECK(ctx->sup_valid, JN_ESTATE,
+           "jn_supervised_backward: no supervised forward to differentiate (none ran, or a later pass overwrote its activations)");
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  JN_HIP(hipMemcpyAsync(ctx->dlogits, dlogits_dev, (size_t)ctx->sup.B * ctx->sup.T * ctx->cfg.n_actions * sizeof(float),
+                        hipMemcpyDeviceToDevice, s));
+  return supervised_backward_impl(ctx, s);
 }
 
 int jn_optimizer_step(jn_ctx* ctx, float lr, float weight_decay, float clip_value, float grad_scale, void* stream) {

@@ -41,6 +41,51 @@ def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor, is_buffer: bool)
         mod.register_parameter(parts[-1], nn.Parameter(tensor))
 
 
+class _ForwardGraph(torch.autograd.Function):
+    """Graph node behind the logits of a train-mode ``GPT.forward`` (the supervised loop, src/supervised.py:863-868, 897):
+    backward = ``jn_supervised_backward(d loss / d logits)``, then the engine's packed gradients are added to
+    ``param.grad`` (reference layout).  ``final_emb`` leaves without a graph (the supervised loop never differentiates it)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, gen, logits, keep):
+        ctx.model, ctx.gen, ctx.keep = model, gen, keep     # keep: the input buffers the engine's backward reads
+        return logits.view_as(logits)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model = ctx.model
+        if ctx.gen != model._rollout_gen:
+            raise RuntimeError("backward through a forward whose activations were overwritten by a later train-mode pass")
+        eng, dev = model.engine(), model.device
+        dlogits = dlogits.to(dev, torch.float32).contiguous()
+        check(eng.lib.jn_supervised_backward(eng.handle, ptr(dlogits), _lib.current_stream(dev)), "jn_supervised_backward")
+        model.publish_engine_grads()
+        return None, None, None, None, None
+
+
+# Registration order of the reference's module tree (src/models/gpt.py:162-321 for the top level and the transformer;
+# the published YOLOX modules for the detector / patch encoder, SURVEY.md §2.1).  ``named_parameters()`` must walk the
+# tensors in THIS order: ``torch.optim.AdamW.state_dict()`` keys its moments by position in the parameter list, so a
+# checkpoint's "optimizer-gpt" / "optimizer-yolox" entries only mean the same thing on both sides if the lists agree.
+# The engine's own table is in execution order (conv2|conv1 pairs, bottlenecks before conv3).
+_REF_ORDER = [
+    ["action_head", "positional_encoding", "decoder_token_pos_enc", "embed_class", "project_concat", "yolox",
+     "gpt_backbone", "embed_fpn", "transformer"],
+    ["backbone", "head", "upsample", "lateral_conv0", "C3_p4", "reduce_conv1", "C3_p3", "bu_conv2", "C3_n3", "bu_conv1", "C3_n4"],
+    ["stem", "dark2", "dark3", "dark4", "dark5"],
+    ["conv1", "conv2", "conv3", "m"], ["dconv", "pconv"], ["conv", "bn"],
+    ["cls_convs", "reg_convs", "cls_preds", "reg_preds", "obj_preds", "stems"],
+    ["wte", "wpe", "drop", "h", "ln_f"], ["ln_1", "attn", "ln_2", "mlp"], ["c_attn", "c_fc", "c_proj"],
+    ["weight", "bias", "running_mean", "running_var", "num_batches_tracked", "inv_freq", "cached_penc"],
+]
+_REF_RANK = {tok: i for group in _REF_ORDER for i, tok in enumerate(group)}
+
+
+def reference_order_key(name: str):
+    """Sort key that puts state-dict names in the reference's ``named_parameters()`` / ``state_dict()`` order."""
+    return tuple((0, int(t)) if t.isdigit() else (1, _REF_RANK.get(t, 99), t) for t in name.split("."))
+
+
 class GPT(nn.Module):
     """GPT Language Model driving the glimpse agent (drop-in for src/models/gpt.py:GPT)."""
 
@@ -99,7 +144,7 @@ class GPT(nn.Module):
     # ---- parameters under the reference's names -------------------------------------
     def _build_parameters(self):
         C = self.n_embd
-        for name, shape, dtype, is_buffer, _used in self._engine.param_table():
+        for name, shape, dtype, is_buffer, _used in sorted(self._engine.param_table(), key=lambda e: reference_order_key(e[0])):
             leaf = name.rsplit(".", 1)[-1]
             if dtype == 1:
                 t = torch.zeros(shape, dtype=torch.long)
@@ -159,8 +204,11 @@ class GPT(nn.Module):
 
     # ---- forward ----------------------------------------------------------------------
     def forward(self, patches, actions, classes, positions=None, prev_embeddings=None):
-        """Same contract as src/models/gpt.py:481-534 (eval mode).  ``classes`` must be 0
-        (the reference never passes anything else, src/reinforce.py:128-129)."""
+        """Same contract as src/models/gpt.py:481-534.  ``classes`` must be 0 (the reference never passes anything else,
+        src/reinforce.py:128-129).  Eval mode / no-grad: BatchNorm running statistics, no graph.  ``model.train()`` + grad
+        mode on a full sequence (no ``prev_embeddings``: the supervised loop's call, src/supervised.py:863-868): train-mode
+        numerics — BatchNorm statistics over the B*T patches, running statistics updated, dropout — and the logits carry a
+        graph whose backward is the engine's teacher-forced backward (``jn_supervised_forward`` / ``_backward``)."""
         seq_len = actions.shape[1]
         assert seq_len <= self.block_size, \
             f"Cannot forward sequence of length {seq_len}, block size is only {self.block_size}"
@@ -175,6 +223,19 @@ class GPT(nn.Module):
         patches = None if self.no_patch_emb else patches.to(dev, torch.float32).contiguous()
         actions = actions.to(dev, torch.int64).contiguous()
         positions = None if positions is None else positions.to(dev, torch.int64).contiguous()
+        if self.training and torch.is_grad_enabled() and prev_embeddings is None and not self.no_patch_emb:
+            assert B * seq_len <= self.max_batch, \
+                f"train-mode forward: B*T = {B * seq_len} patches exceed max_batch = {self.max_batch} (BatchNorm statistics need one pass)"
+            self.bind_flat()
+            self._rollout_gen += 1
+            logits = torch.empty((B, seq_len, nA), device=dev, dtype=torch.float32)
+            final_emb = torch.empty((B, seq_len + 1, C), device=dev, dtype=torch.float32)
+            check(self._engine.lib.jn_supervised_forward(self._engine.handle, ptr(patches), ptr(actions), ptr(positions), B,
+                                                         seq_len, ptr(logits), ptr(final_emb), _lib.current_stream(dev)),
+                  "jn_supervised_forward")
+            anchor = next(p for p in self.parameters() if p.requires_grad)
+            logits = _ForwardGraph.apply(anchor, self, self._rollout_gen, logits, (patches, actions, positions))
+            return logits, final_emb
         Tp = 0
         if prev_embeddings is not None:
             prev_embeddings = prev_embeddings.to(dev, torch.float32).contiguous()
@@ -340,4 +401,5 @@ class GPT(nn.Module):
         yolo_params = [p for pn, p in self.named_parameters() if pn.startswith("yolox")]
         optim_yolox = EngineAdamW(self, 1, yolo_params, lr=getattr(train_config, "yolo_lr", train_config.learning_rate)) \
             if yolo_params else None
+        object.__setattr__(self, "_last_optimizers", (optim_gpt, optim_yolox))     # save_checkpoint's default
         return optim_gpt, optim_yolox

@@ -36,6 +36,9 @@ class EngineAdamW(torch.optim.Optimizer):
         assert closure is None, "closures are not supported"
         m = self._model
         lo, hi = self._bound_range()
+        # torch-side edits of a bound model (load_state_dict, manual in-place changes) reach the engine before the update:
+        # the export below would otherwise overwrite them and mark them as uploaded
+        m.sync_weights()
         eng, stream = m.engine(), _lib.current_stream(m.device)
         from .dist import allreduce_gradients
         scale = 1.0
@@ -99,6 +102,13 @@ class EngineAdamW(torch.optim.Optimizer):
             off = m._flat_offsets.get(names.get(id(p)))
             if st is None or off is None:
                 continue
+            # positions mean the same tensor on both sides only if the parameter lists agree (they do for the
+            # reference's module order, gpt.py::reference_order_key); a foreign list is skipped entry by entry, not crashed on
+            if tuple(st["exp_avg"].shape) != tuple(p.shape) or tuple(st["exp_avg_sq"].shape) != tuple(p.shape):
+                import warnings
+                warnings.warn(f"optimizer state {i} has shape {tuple(st['exp_avg'].shape)}, parameter {names.get(id(p))} "
+                              f"has {tuple(p.shape)}: entry skipped (moments stay as they are)")
+                continue
             sl = slice(off, off + p.numel())
             ea[sl] = st["exp_avg"].to(m.device, torch.float32).flatten()
             eas[sl] = st["exp_avg_sq"].to(m.device, torch.float32).flatten()
@@ -110,8 +120,11 @@ class EngineAdamW(torch.optim.Optimizer):
         steps = C.c_int(step)
         check(eng.lib.jn_optimizer_steps(eng.handle, self._group, C.byref(steps), 1), "jn_optimizer_steps")
         if sd.get("param_groups"):
+            # torch.optim.AdamW.load_state_dict restores the hyper-parameters too (and the reference's later `optim.lr = lr`
+            # is a no-op, main.py:548-556).  A non-positive learning rate is never a training value: such an entry (a
+            # checkpoint written without optimisers by an earlier version of save_checkpoint) keeps the configured one.
             for k in ("lr", "weight_decay"):
-                if k in sd["param_groups"][0]:
+                if k in sd["param_groups"][0] and (k != "lr" or float(sd["param_groups"][0][k]) > 0.0):
                     self.param_groups[0][k] = sd["param_groups"][0][k]
 
     def zero_grad(self, set_to_none: bool = False):

@@ -17,8 +17,11 @@ class _RolloutGraph(torch.autograd.Function):
     the engine's packed gradients are added to ``param.grad`` (reference layout)."""
 
     @staticmethod
-    def forward(ctx, anchor, model, gen, logprobs, entropies):
-        ctx.model, ctx.gen = model, gen
+    def forward(ctx, anchor, model, gen, logprobs, entropies, keep):
+        # `keep`: every buffer the engine's backward reads through raw pointers (logits, actions, positions, final_emb,
+        # masks, ..., forced actions) — held here so that the caching allocator cannot hand them out again when the
+        # caller drops the rollout dict before loss.backward()
+        ctx.model, ctx.gen, ctx.keep = model, gen, keep
         return logprobs.view_as(logprobs), entropies.view_as(entropies)
 
     @staticmethod
@@ -31,7 +34,7 @@ class _RolloutGraph(torch.autograd.Function):
         dent = None if dent is None else dent.to(dev, torch.float32).contiguous()
         check(eng.lib.jn_reinforce_backward(eng.handle, ptr(dlp), ptr(dent), _lib.current_stream(dev)), "jn_reinforce_backward")
         model.publish_engine_grads()
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 
 class ReinforceTrainer:
@@ -122,8 +125,9 @@ class ReinforceTrainer:
             check(eng.lib.jn_reinforce_forward(eng.handle, mode, ptr(forced_actions), ptr(start_positions), seed,
                                                int(stop_early), C.byref(out), stream), "jn_reinforce_forward")
             anchor = next(p for p in model.parameters() if p.requires_grad)
+            keep = dict(buf, forced_actions=forced_actions, start_positions=start_positions)
             buf["logprobs"], buf["entropies"] = _RolloutGraph.apply(anchor, model, model._rollout_gen, buf["logprobs"],
-                                                                    buf["entropies"])
+                                                                    buf["entropies"], keep)
         else:
             check(eng.lib.jn_rollout(eng.handle, mode, ptr(forced_actions), ptr(start_positions), seed,
                                      int(do_detection), int(stop_early), C.byref(out), stream), "jn_rollout")
@@ -190,18 +194,27 @@ class ReinforceTrainer:
                 metrics["yolo_" + k] = v
             loss = loss + yolo_loss["total_loss"].detach()
         if self.iter_num % ga == 0:
+            opts = [o for o in (optim_gpt, optim_yolox) if o is not None]
+            was = [getattr(o, "sync_gradients", False) for o in opts]
             if sync_gradients:
-                # data-parallel ranks: ONE all-reduce of the flat gradient buffer (mean), before the clip as under DDP
+                # data-parallel ranks: ONE all-reduce of the flat gradient buffer (mean), before the clip as under DDP —
+                # the optimisers must not reduce the (already averaged, clipped) gradients a second time
                 from .dist import allreduce_gradients
                 sc = allreduce_gradients(model._flat_grads, model._arena_numel)
                 if sc != 1.0:
                     model._flat_grads.mul_(sc)
+                for o in opts:
+                    if hasattr(o, "sync_gradients"):
+                        o.sync_gradients = False
             clip_grad.clip_grad_value_(model.parameters(), 1)
             optim_gpt.step()
             optim_gpt.zero_grad()
             if getattr(config, "detection_enabled", False) and optim_yolox is not None:
                 optim_yolox.step()
                 optim_yolox.zero_grad()
+            for o, w in zip(opts, was):
+                if hasattr(o, "sync_gradients"):
+                    o.sync_gradients = w
             if config.reward_norm:
                 self._compute_last_returns_mean_std()
         metrics["loss"] = loss.detach()
@@ -319,6 +332,7 @@ class ReinforceTrainer:
             from .dist import allreduce_gradients
             scale = allreduce_gradients(grads, grads.numel() if detection else self._optim_numel, process_group)
             lr = float(getattr(self.config, "learning_rate", 1e-4))
+            object.__setattr__(model, "_last_lr", (lr, float(getattr(self.config, "yolo_lr", lr))))     # save_checkpoint's default
             check(eng.lib.jn_optimizer_step(eng.handle, lr, 0.01, 1.0, scale, stream), "jn_optimizer_step")
             if detection:                          # optim_yolox.step(), src/reinforce.py:348-350
                 ylr = float(getattr(self.config, "yolo_lr", lr))

@@ -15,6 +15,7 @@ from ._lib import check, ptr
 class SupervisedTrainer:
     def __init__(self, config, model, logger=None, train_dataset=None, test_dataset=None, rank: int = 0):
         self.config, self.model, self.rank = config, model, rank
+        self.logger, self.train_dataset, self.test_dataset = logger, train_dataset, test_dataset
         self.device = model.device
         self.stop_weight = float(getattr(config, "stop_weight", 1.0)) if getattr(config, "stop_enabled", False) else 1.0
         self.best_metric_name = "map"
@@ -78,7 +79,7 @@ class SupervisedTrainer:
             ref_actions[rows, last] = nxt[rows, last]
         else:
             ref_actions = nxt
-        detection = self.model.yolox is not None and bool(getattr(cfg, "detection_enabled", True))
+        detection = self.yolox_model() is not None and bool(getattr(cfg, "detection_enabled", True))
         aug = getattr(self, "detection_augment", None)
         if aug is not None:
             B_, T_ = cur.shape
@@ -106,6 +107,120 @@ class SupervisedTrainer:
         res["trajectories"] = tr
         return res
 
+    # ---- the reference's supervised loop on the autograd bridge (src/supervised.py:138-198, 812-911) -------------------
+    def yolox_model(self):
+        return getattr(self.model, "_yolox_view", None)      # None: no detector configured (with_detector = False)
+
+    def ddp_setup(self, rank: int, world_size: int, port: int, backend: str = None):
+        """``Trainer.ddp_setup`` (src/trainer.py:61-71); rendezvous on 127.0.0.1, ``backend="gloo"`` for rehearsals."""
+        import os
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        if not dist.is_initialized():
+            dist.init_process_group(backend=backend or "nccl", rank=rank, world_size=world_size)
+
+    def compute_metrics(self, action_logits, actions, masks, yolo_loss: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+        """src/supervised.py:138-198: CrossEntropy(weight[STOP] = stop_weight, reduction none) over the non-padding tokens,
+        accuracy, the detector's loss terms under ``yolo_*`` and their total added to ``loss``, ``episode_length``."""
+        nA = action_logits.shape[-1]
+        weight = torch.ones(nA, device=action_logits.device)
+        if getattr(self.config, "stop_enabled", False):
+            weight[-1] = self.stop_weight
+        flat, target = action_logits.reshape(-1, nA), actions.flatten()
+        valid = (masks == 1).flatten()
+        per_token = torch.nn.functional.cross_entropy(flat, target, weight=weight, reduction="none")
+        metrics = {"action_loss": per_token[valid].mean(),
+                   "action_accuracy": (target[valid] == flat.argmax(dim=1)[valid]).float().mean()}
+        metrics["loss"] = metrics["action_loss"]
+        if yolo_loss is not None:
+            for k, v in yolo_loss.items():
+                metrics["yolo_" + k] = v if isinstance(v, torch.Tensor) else torch.tensor(v)
+            metrics["yolo_loss"] = metrics["yolo_total_loss"]
+            metrics["loss"] = metrics["loss"] + metrics["yolo_loss"].to(metrics["loss"].device)
+        if torch.isnan(metrics["action_accuracy"]):
+            metrics["action_accuracy"] = torch.zeros((), device=action_logits.device)
+        metrics["episode_length"] = masks.sum(dim=1).float().mean()
+        return metrics
+
+    def training_step(self, batch: Dict, optim_gpt, optim_yolox=None, seed: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        """The body of the reference's loop (src/supervised.py:834-902): trajectories -> [augmentation] ->
+        ``model(patches, current_actions, classes, positions)`` -> reference actions -> detector loss -> compute_metrics
+        -> ``loss.backward()`` -> every ga-th iteration ``optim.step()`` / ``zero_grad()`` (no clipping).  ``model`` is this
+        package's GPT in train mode: the logits carry a graph whose backward is the engine's; the detector's loss is
+        differentiated inside its own call (its value joins ``loss`` as a constant, its gradients are already in
+        ``param.grad``); the optimisers average the gradients over the ranks with ONE all-reduce of the flat buffer each
+        (the job DDP's bucketed all-reduce does in the reference, src/supervised.py:815)."""
+        cfg, model = self.config, self.model
+        self.iter_num += 1
+        model.train()
+        batch = self.generate_trajectories(batch, seed=seed)
+        patches, current_actions, next_actions = batch["patches"], batch["current_actions"], batch["next_actions"]
+        positions, masks, classes = batch["positions"], batch["masks"], batch["class_id"]
+        aug = getattr(self, "detection_augment", None)
+        if aug is not None:
+            with torch.no_grad():
+                B_, T_ = current_actions.shape
+                patches = aug(patches.flatten(0, 1)).view(B_, T_, *patches.shape[2:])
+        action_logits, _ = model(patches, current_actions, classes=classes, positions=positions)
+        if getattr(cfg, "loss_mode", "best-action") == "on-self-trajectory":
+            reference_actions = torch.zeros_like(current_actions)
+            reference_actions[:, :-1] = current_actions[:, 1:]
+            last = masks.sum(dim=1).long() - 1
+            rows = torch.arange(current_actions.shape[0], device=current_actions.device)
+            reference_actions[rows, last] = next_actions[rows, last]
+        else:
+            reference_actions = next_actions
+        yolo_loss = None
+        if self.yolox_model() is not None and bool(getattr(cfg, "detection_enabled", True)):
+            patches_yolox = batch["patches_yolox"]
+            if aug is not None:
+                with torch.no_grad():
+                    patches_yolox = aug(patches_yolox)
+            _, _, yolo_loss = self.yolox_model()(patches_yolox, batch["bboxes_yolox"])
+        metrics = self.compute_metrics(action_logits, reference_actions, masks, yolo_loss)
+        metrics["loss"].backward()
+        if self.iter_num % int(getattr(cfg, "gradient_accumulation", 1)) == 0:
+            optim_gpt.step()
+            if optim_yolox is not None:
+                optim_yolox.step()
+            optim_gpt.zero_grad()
+            if optim_yolox is not None:
+                optim_yolox.zero_grad()
+        return {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in metrics.items()}
+
+    def run(self, rank: int, world_size: int, port: int, batches=None, max_iters: int = None, backend: str = None,
+            seed: Optional[int] = None):
+        """``SupervisedTrainer.run`` (src/supervised.py:812-911) without the dataset / Visdom / test plumbing (out of scope,
+        SURVEY.md §8): `batches` is any iterable of collated batches ({"image", "bboxes"[, "class_id"]}), re-iterated when
+        exhausted.  One process per GPU; gradients are averaged by the optimisers' all-reduce (DDP semantics), BatchNorm
+        statistics stay per rank.  Returns the metrics of the last iteration."""
+        import torch.distributed as dist
+        if bool(getattr(self.config, "augment_detection", False)):
+            self.init_detection()
+        self.rank = rank
+        if world_size > 1 or backend:
+            self.ddp_setup(rank, world_size, port, backend)
+        optim_gpt, optim_yolox = self.model.configure_optimizers(self.config)
+        for o in (optim_gpt, optim_yolox):
+            if o is not None:
+                o.sync_gradients = world_size > 1
+        self.optim_gpt, self.optim_yolox = optim_gpt, optim_yolox
+        batches = batches if batches is not None else getattr(self, "train_dataset", None)
+        assert batches is not None, "run() needs an iterable of collated batches"
+        n_iters = int(max_iters if max_iters is not None else getattr(self.config, "max_iters", 1))
+        it, metrics = iter(batches), None
+        for i in range(n_iters):
+            try:
+                batch = next(it)
+            except StopIteration:
+                it = iter(batches)
+                batch = next(it)
+            metrics = self.training_step(batch, optim_gpt, optim_yolox, seed=None if seed is None else seed + i)
+        if dist.is_available() and dist.is_initialized() and (world_size > 1 or backend):
+            dist.destroy_process_group()
+        return metrics
+
     def train_step(self, patches, current_actions, next_actions, positions, masks, optimizer_step: bool = True,
                    process_group=None) -> Dict[str, torch.Tensor]:
         """model(patches, current_actions, classes=0, positions) -> CE vs next_actions -> backward -> AdamW."""
@@ -129,6 +244,7 @@ class SupervisedTrainer:
             from .dist import allreduce_gradients
             scale = allreduce_gradients(grads, self._optim_numel, process_group)
             lr = float(getattr(self.config, "learning_rate", 1e-4))
+            object.__setattr__(model, "_last_lr", (lr, float(getattr(self.config, "yolo_lr", lr))))     # save_checkpoint's default
             # the supervised loop does not clip gradients (src/supervised.py:897-902)
             check(eng.lib.jn_optimizer_step(eng.handle, lr, 0.01, 0.0, scale, stream), "jn_optimizer_step")
             grads.zero_()

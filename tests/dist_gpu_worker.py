@@ -23,6 +23,8 @@ def main():
     from tests.helpers import make_pair, synth_batch
     case = torch.load(outdir / "case.pt")
     P, Tn, B = case["P"], case["T"], case["B"]
+    if case.get("mode") == "supervised":
+        return supervised(rank, world, port, outdir, case)
     product, _ = make_pair(5, patch_size=P, block_size=Tn, with_detector=False, image_processor=None)
     lo, hi = shard_range(B, rank, world)
     images, bboxes, start, forced = (case[k][lo:hi] for k in ("images", "bboxes", "start", "forced"))
@@ -43,6 +45,41 @@ def main():
                 "params": {k: v.detach().cpu().clone() for k, v in product.named_parameters()}}, outdir / f"rank{rank}.pt")
     dist.barrier()
     dist.destroy_process_group()
+
+
+def supervised(rank, world, port, outdir, case):
+    """The reference's supervised loop body (src/supervised.py:863-868, 897-902) on this rank's shard; the process group
+    is the one main() initialised (ddp_setup is idempotent)."""
+    import jolineedle_amd as ja
+    from jolineedle_amd.dist import shard_range
+    from tests.helpers import make_pair
+    P, T, B = case["P"], case["T"], case["B"]
+    product, _ = make_pair(5, patch_size=P, block_size=T, with_detector=False, image_processor=None, max_batch=B * T)
+    lo, hi = shard_range(B, rank, world)
+    batch = {"image": case["images"][lo:hi].cuda(), "bboxes": case["bboxes"][lo:hi]}
+    cfg = ja.CfgNode(patch_size=P, max_seq_len=T, min_keypoints=0, max_keypoints=2, binomial_keypoints=False, stop_enabled=True,
+                     stop_weight=1.0, learning_rate=1e-3, gradient_accumulation=1, detection_enabled=False, max_iters=2)
+    trainer = ja.SupervisedTrainer(cfg, product, rank=rank)
+    trainer.ddp_setup(rank, world, port, backend="gloo")
+    optim_gpt, optim_yolox = product.configure_optimizers(cfg)
+    assert optim_yolox is None and optim_gpt.sync_gradients
+    product.train()
+    tr = trainer.generate_trajectories(batch, seed=100 + 10 * rank)
+    action_logits, _ = product(tr["patches"], tr["current_actions"], classes=tr["class_id"], positions=tr["positions"])
+    metrics = trainer.compute_metrics(action_logits, tr["next_actions"], tr["masks"])
+    metrics["loss"].backward()
+    named = dict(product.named_parameters())
+    local = {k: p.grad.detach().cpu().clone() for k, p in named.items() if p.grad is not None}
+    optim_gpt.step()                     # ONE all-reduce of the flat buffer (SUM) + AdamW on the mean; no clipping
+    mean = {k: p.grad.detach().cpu().clone() / world for k, p in named.items() if p.grad is not None}
+    optim_gpt.zero_grad()
+    params = {k: v.detach().cpu().clone() for k, v in product.named_parameters()}
+    world_seen = dist.get_world_size()
+    # ... and run() itself for two more iterations on the same group (it tears the group down at the end)
+    m = trainer.run(rank, world, port, batches=[batch], max_iters=2, backend="gloo", seed=7 + rank)
+    torch.save({"local": local, "mean": mean, "world_seen": world_seen, "params": params,
+                "trajectories": {k: v.detach().cpu() for k, v in tr.items() if isinstance(v, torch.Tensor)},
+                "run_iters": trainer.iter_num, "run_loss_finite": bool(torch.isfinite(m["loss"]))}, outdir / f"rank{rank}.pt")
 
 
 if __name__ == "__main__":

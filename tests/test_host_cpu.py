@@ -71,6 +71,15 @@ def test_state_dict_table_matches_oracle(kw):
     oracle.load_state_dict(m.state_dict())
     names = {n for n, _ in m.named_parameters()}
     assert {n for n, _ in oracle.named_parameters()} == names
+    # ... and in the reference's ORDER: torch.optim.AdamW keys its state by position in the parameter list, so the
+    # "optimizer-gpt" / "optimizer-yolox" entries of a checkpoint name the same tensors on both sides only if the lists agree
+    # (CSPLayer registers conv1, conv2, conv3, m; the engine's own table runs conv2|conv1 pairs and m before conv3)
+    assert [n for n, _ in m.named_parameters()] == [n for n, _ in oracle.named_parameters()]
+    assert list(sd) == list(osd)
+    for prefix_is_yolox in (False, True):
+        mine = [(n, tuple(p.shape)) for n, p in m.named_parameters() if n.startswith("yolox") == prefix_is_yolox]
+        ref = [(n, tuple(p.shape)) for n, p in oracle.named_parameters() if n.startswith("yolox") == prefix_is_yolox]
+        assert mine == ref               # the two optimiser groups of gpt.py:547-562, position by position
     g, y = m.configure_optimizers(ja.CfgNode(learning_rate=1e-4, yolo_lr=1e-4))
     n_gpt = sum(p.numel() for grp in g.param_groups for p in grp["params"])
     assert n_gpt == sum(p.numel() for n, p in oracle.named_parameters() if not n.startswith("yolox"))

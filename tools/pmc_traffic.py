@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter CSVs of the conv stack into HBM bytes per pass.
 
-usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <glimpse steps in the run> <batch> [train|eval] [json to update]
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <glimpse steps in the run> <batch> [train|eval|backward] [json to update] [name of the summary file for the json]
 (train: counters of a `--mode train` run — only the FORWARD conv-stack kernels are summed: the data-gradient launches
-of pw_mfma_kernel carry `true` as their third template argument and are left out)
+of pw_mfma_kernel carry `true` as their third template argument and are left out; backward: the same run, only the
+conv-stack BACKWARD kernels — BatchNorm-backward reductions, fused / unfused data and weight gradients, stem weight
+gradient, pooling / upsample / copy backward — per glimpse step)
 
 Units and the gfx950 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KB;
 FETCH_SIZE reports half of the bytes of wide coalesced streaming reads, so read bytes = 2 * FETCH_SIZE * 1024.
@@ -24,6 +26,12 @@ def short(name):
 
 
 TRAIN = False
+BACKWARD = False
+BWD = ("bn_bwd_", "pw_bwd_", "dw_bwd_", "stem_bwd_", "spp_bwd", "upsample_bwd", "grad_copy", "wpart_reduce", "conv3_bwd_")
+
+
+def is_data_gradient(k):
+    return (k.startswith("pw_mfma_kernel") and ", true," in k) or bool(re.match(r"pw_(dir|res)_kernel<\d+(, \d+, \d+, \d+)?, true", k))
 
 
 def load(path, counter):
@@ -32,6 +40,12 @@ def load(path, counter):
         if r["Counter_Name"] != counter:
             continue
         k = short(r["Kernel_Name"])
+        if BACKWARD:
+            if not (any(c in k for c in BWD) or is_data_gradient(k)):
+                continue
+            tot[k] += float(r["Counter_Value"])
+            calls[k] += 1
+            continue
         if not any(c in k for c in CONV + (("bn_finalize_kernel",) if TRAIN else ())):
             continue
         if TRAIN and k.startswith("pw_mfma_kernel") and ", true," in k:
@@ -44,8 +58,9 @@ def load(path, counter):
 
 
 def main():
-    global TRAIN
+    global TRAIN, BACKWARD
     TRAIN = len(sys.argv) > 5 and sys.argv[5] == "train"
+    BACKWARD = len(sys.argv) > 5 and sys.argv[5] == "backward"
     fetch, calls = load(sys.argv[1], "FETCH_SIZE")
     write, _ = load(sys.argv[2], "WRITE_SIZE")
     steps, batch = int(sys.argv[3]), int(sys.argv[4])
@@ -54,17 +69,21 @@ def main():
         print(f"{k:58s} {calls[k]:6d} {fetch[k]:14.0f} {write[k]:14.0f}")
     f, w = sum(fetch.values()), sum(write.values())
     rd, wr = 2 * f * 1024 / steps, w * 1024 / steps
-    algo = 17.44e6 * 4 * batch
-    print(f"# conv stack, {steps} glimpse steps: FETCH {f:.0f} KB, WRITE {w:.0f} KB")
-    print(f"# per glimpse step (one pass over {batch} patches): reads 2*{f * 1024 / steps / 1e9:.3f} = {rd / 1e9:.3f} GB, "
+    algo = (2 * 17.44e6 if BACKWARD else 17.44e6) * 4 * batch
+    what = "conv-stack backward" if BACKWARD else "conv stack"
+    print(f"# {what}, {steps} glimpse steps: FETCH {f:.0f} KB, WRITE {w:.0f} KB")
+    print(f"# per glimpse step ({'backward of ' if BACKWARD else ''}one pass over {batch} patches): reads 2*{f * 1024 / steps / 1e9:.3f} = {rd / 1e9:.3f} GB, "
           f"writes {wr / 1e9:.3f} GB, total {(rd + wr) / 1e9:.3f} GB")
-    print(f"# algorithmic (SURVEY 8d, fp32): 17.44 M elems * 4 B * {batch} = {algo / 1e9:.3f} GB -> traffic / algorithmic = "
+    print(f"# algorithmic ({'2 (in + out) = 2 * ' if BACKWARD else 'SURVEY 8d, fp32: '}17.44 M elems * 4 B * {batch}) = {algo / 1e9:.3f} GB -> traffic / algorithmic = "
           f"{(rd + wr) / algo:.2f}")
     if len(sys.argv) > 6:                  # bench.py reads the per-pass bytes of the latest committed PMC passes from here
         import json, os
         path = sys.argv[6]
         cur = json.load(open(path)) if os.path.exists(path) else {}
-        cur["train" if TRAIN else "rollout"] = rd + wr
+        key = "backward" if BACKWARD else "train" if TRAIN else "rollout"
+        cur[key] = rd + wr
+        if len(sys.argv) > 7:
+            cur.setdefault("files", {})[key] = sys.argv[7]
         json.dump(cur, open(path, "w"))
 
 

@@ -20,7 +20,8 @@ run_prof fetch --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- python
 find $OUT/prof_fetch -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_pmc_fetch.csv
 run_prof write --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline
 find $OUT/prof_write -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_pmc_write.csv
-python3 tools/pmc_traffic.py $OUT/${TAG}_pmc_fetch.csv $OUT/${TAG}_pmc_write.csv 40 64 train $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_conv_stack_traffic_train.txt 2>&1
+python3 tools/pmc_traffic.py $OUT/${TAG}_pmc_fetch.csv $OUT/${TAG}_pmc_write.csv 40 64 train $OUT/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_conv_stack_traffic_train.txt > $OUT/${TAG}_pmc_conv_stack_traffic_train.txt 2>&1
+python3 tools/pmc_traffic.py $OUT/${TAG}_pmc_fetch.csv $OUT/${TAG}_pmc_write.csv 40 64 backward $OUT/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_conv_stack_traffic_backward.txt > $OUT/${TAG}_pmc_conv_stack_traffic_backward.txt 2>&1
 rm -rf $OUT/prof_fetch $OUT/prof_write
 for m in "rollout" "train --sample" "rollout --sample"; do
   n=$(echo $m | tr -d ' -')
