@@ -801,14 +801,15 @@ bool pw_bwd_fused_supported(int cout, int cin) {
   if (cout % 16 || cin % 16) return false;
   const int tn = cout / 16, tk = cin / 16;
   auto pow2 = [](int v) { return v == 1 || v == 2 || v == 4 || v == 8; };
-  return pow2(tn) && pow2(tk) && tn * tk <= 32;
+  static const bool no_wide = std::getenv("JN_NO_FUSED_BWD_WIDE") != nullptr;     // 128 x 128: round 3 (one workgroup per CU)
+  return pow2(tn) && pow2(tk) && (tn * tk <= 32 || (!no_wide && tn == 8 && tk == 8));
 }
 
 int launch_pw_bwd_fused(const PwBwdFusedArgs& a, hipStream_t s) {
   const int tn = a.cout / 16, tk = a.cin / 16;
 #define JN_PF(A, B) if (tn == A && tk == B) { launch_pw_bwd_fused_t<A, B>(a, s); return 0; }
   JN_PF(1, 1) JN_PF(1, 2) JN_PF(1, 4) JN_PF(1, 8) JN_PF(2, 1) JN_PF(2, 2) JN_PF(2, 4) JN_PF(2, 8)
-  JN_PF(4, 1) JN_PF(4, 2) JN_PF(4, 4) JN_PF(4, 8) JN_PF(8, 1) JN_PF(8, 2) JN_PF(8, 4)
+  JN_PF(4, 1) JN_PF(4, 2) JN_PF(4, 4) JN_PF(4, 8) JN_PF(8, 1) JN_PF(8, 2) JN_PF(8, 4) JN_PF(8, 8)
 #undef JN_PF
   return -1;
 }

@@ -1,0 +1,200 @@
+// Pixel-stationary 1x1 convolution for the small maps of a forward pass (28x28 / 14x14 at the headline batch: 12 544 -
+// 50 176 pixels per launch, K, N in {64 .. 512}) — round 3.
+//
+// z[m][n] = sum_k T(x[m][k]) * w[n][k]      (T = "normalize on read", jn_tab.h)
+//
+// Why another kernel: on these shapes the weight-stationary pw_dir_kernel (kernels_pwres.hip) spends a third of its time
+// outside the matrix pipe (profiles/r02_pwdirbench_limiters.txt) — every 64-channel output slice is its own workgroup
+// that loads a 64 KB weight slice behind a barrier, re-reads and re-TRANSFORMS the whole pixel operand (4x for N = 256:
+// two transcendentals per value each time), and a wave sees only one or two tiles, so nothing reaches a steady state.
+// Here the roles are swapped:
+//   * a workgroup owns BM = 16 * PT pixels and ALL N output channels: its [BM][K] operand is read from HBM once,
+//     transformed once (every thread keeps the (scale, shift, flag) quad of ITS four input channels in registers — thread
+//     t always handles channel quad t % (K / 4) — so the table never goes through LDS and its fp64 arithmetic runs under
+//     the operand loads), and staged in LDS once: ONE barrier in the kernel;
+//   * each of the four waves owns N / 4 output channels and streams their weight rows straight from L2 into registers in
+//     MFMA fragment layout (lane (row, g) reads w[n0 + row][16 j + 4 g .. + 3]), D steps ahead of the MFMAs that use
+//     them: the weights never touch LDS and are not shared between waves, so no second barrier;
+//   * per 16-wide k step a wave issues PT ds_read_b128 + CTW global loads for 4 * PT * CTW MFMAs (64 for 64 pixels x 64
+//     channels): the matrix pipe is the only busy unit inside the loop;
+//   * the BatchNorm sums of a wave's channels are complete inside the wave (DPP row sums): fp64 atomics straight from
+//     registers, no cross-wave reduction.
+// Exact fp32 (v_mfma_f32_16x16x4_f32), the same fragment layout and k order as pw_mfma_kernel / pw_dir_kernel: results
+// are bit-identical to theirs.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "jn_kernels.h"
+#include "jn_reduce.h"
+#include "jn_tab.h"
+#include "jn_types.h"
+
+namespace jnr {
+
+template <int K, int CTW, int PT, int D>
+__global__ __launch_bounds__(256, (K <= 256 ? 2 : 1)) void pw_xs_kernel(
+    const float* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, float* __restrict__ out, int out_ld,
+    long long M, double* __restrict__ stats, long long rep_stride, int nrep, const int* __restrict__ skip_flag,
+    int skip_when) {
+  if (skip_flag && *skip_flag >= skip_when) return;
+  constexpr int BM = 16 * PT, LDX = K + 8, KQ = K / 4, NJ = K / 16;
+  constexpr int NX = BM * KQ / 256;                    // float4 of the operand tile per thread
+  constexpr int NXB = NX < 16 ? NX : 16;               // ... fetched in batches of at most 16 (64 VGPRs in flight)
+  static_assert(256 % KQ == 0 && NX >= 1 && NX % NXB == 0 && NJ % D == 0, "pw_xs tile mapping");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* Xs = reinterpret_cast<float*>(smem_raw);      // [BM][LDX]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, g = lane >> 4;
+  const long long m0 = (long long)blockIdx.x * BM;
+
+  // ---- weight fragments of the first D k-steps: in flight before anything else ----
+  const float* wrow[CTW];
+#pragma unroll
+  for (int c = 0; c < CTW; ++c) wrow[c] = w + (long long)((wave * CTW + c) * 16 + lm) * K + 4 * g;
+  f32x4 wr[D][CTW];
+#pragma unroll
+  for (int u = 0; u < D; ++u)
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) wr[u][c] = *reinterpret_cast<const f32x4*>(wrow[c] + 16 * u);
+
+  // ---- operand tile: global -> registers (first batch), table quad meanwhile, transform, -> LDS ----
+  const int q = tid % KQ, r0 = tid / KQ;               // channel quad of this thread, first row; rows advance by 256 / KQ
+  constexpr int RS = 256 / KQ;
+  f32x4 xr[NXB];
+  auto fetch = [&](int b) {
+#pragma unroll
+    for (int u = 0; u < NXB; ++u) {
+      const long long m = m0 + r0 + (long long)(b * NXB + u) * RS;
+      xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (m < M) xr[u] = *reinterpret_cast<const f32x4*>(x + m * x_ld + 4 * q);
+    }
+  };
+  fetch(0);
+  f32x4 sc, sh, fl;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float a, b, f;
+    tab_entry(it, 4 * q + e, a, b, f);
+    sc[e] = a; sh[e] = b; fl[e] = f;
+  }
+#pragma unroll
+  for (int b = 0; b < NX / NXB; ++b) {
+    if (b > 0) fetch(b);
+#pragma unroll
+    for (int u = 0; u < NXB; ++u) {
+      const int r = r0 + (b * NXB + u) * RS;
+      f32x4 v = tf4_tab(xr[u], sc, sh, fl);
+      if (m0 + r >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};  // rows past the end contribute nothing (T(0) is not 0)
+      *reinterpret_cast<f32x4*>(Xs + r * LDX + 4 * q) = v;
+    }
+  }
+  __syncthreads();                                     // the only barrier
+
+  // ---- MFMAs: D-step ring of weight fragments, operand fragments from LDS ----
+  f32x4 acc[CTW][PT];
+#pragma unroll
+  for (int c = 0; c < CTW; ++c)
+#pragma unroll
+    for (int p = 0; p < PT; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* xrow = Xs + lm * LDX + 4 * g;
+#pragma unroll 1
+  for (int j0 = 0; j0 < NJ; j0 += D) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      const int j = j0 + u;
+      f32x4 xa[PT], wa[CTW];
+#pragma unroll
+      for (int p = 0; p < PT; ++p) xa[p] = *reinterpret_cast<const f32x4*>(xrow + p * 16 * LDX + 16 * j);
+#pragma unroll
+      for (int c = 0; c < CTW; ++c) wa[c] = wr[u][c];
+      if (j + D < NJ) {
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) wr[u][c] = *reinterpret_cast<const f32x4*>(wrow[c] + 16 * (j + D));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int c = 0; c < CTW; ++c)
+#pragma unroll
+          for (int p = 0; p < PT; ++p) acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][e], xa[p][e], acc[c][p], 0, 0, 0);
+    }
+  }
+
+  // ---- store (lane = 4 consecutive channels of one pixel) + BatchNorm sums ----
+#pragma unroll
+  for (int c = 0; c < CTW; ++c) {
+    const int n = (wave * CTW + c) * 16 + 4 * g;
+    f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+      const long long m = m0 + 16 * p + lm;
+      const f32x4 v = acc[c][p];
+      if (m < M) *reinterpret_cast<f32x4*>(out + m * out_ld + n) = v;
+      s1 += v; s2 += v * v;                             // rows past the end are exact zeros
+    }
+    if (stats) {
+      double* st = stats + (blockIdx.x % nrep) * rep_stride + 2 * n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = row16_sum(s1[r]);
+        const float b = row16_sum(s2[r]);
+        if (lm == 0) { atomicAdd(st + 2 * r, (double)a); atomicAdd(st + 2 * r + 1, (double)b); }
+      }
+    }
+  }
+}
+
+template <int K, int CTW, int PT, int D>
+static void launch_pw_xs_t(const ConvArgs& a, long long M, hipStream_t s) {
+  constexpr int BM = 16 * PT;
+  const size_t smem = (size_t)BM * (K + 8) * sizeof(float);
+  auto kern = pw_xs_kernel<K, CTW, PT, D>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const long long gx = (M + BM - 1) / BM;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), smem, s, (const float*)a.in, a.in_ld, a.itab, a.w, (float*)a.out,
+                     a.out_ld, M, a.stats, a.stats_rep_stride, a.stats_nrep > 0 ? a.stats_nrep : JN_NREP, a.skip_flag,
+                     a.skip_when);
+}
+
+// Shapes the kernel takes: fp32 forward (no bias / activation epilogue, weight [N][K] not transposed, one slot),
+// K in {64, 128, 256, 512}, N in {64, 128, 256}.  pt = pixel tiles per workgroup (2 or 4; 0 = the measured best for the
+// shape, tools/pwxsbench.hip).  Returns -1 when the shape is not covered.
+bool pw_xs_supported(const ConvArgs& a) {
+  if (a.bf16_mfma || a.in_dtype != JN_F32 || a.out_dtype != JN_F32 || a.bias || a.act != ACT_NONE || a.w_transposed ||
+      a.accumulate || a.n_slots > 1)
+    return false;
+  const int K = a.cin, N = a.cout;
+  if (!(K == 64 || K == 128 || K == 256 || K == 512) || !(N == 64 || N == 128 || N == 256)) return false;
+  if (K == 64 && N == 256) return false;
+  if (K == 512 && N != 256) return false;
+  if (K == 256 && N == 64) return false;
+  return a.in_ld % 4 == 0 && a.out_ld % 4 == 0;
+}
+
+int launch_pw_xs(const ConvArgs& a, int pt, hipStream_t s) {
+  if (!pw_xs_supported(a)) return -1;
+  const long long M = (long long)a.N * a.H * a.W;
+  const int K = a.cin, ctw = a.cout / 64;
+  if (pt == 0) pt = 4;
+#define JN_XS(K_, C_, D_)                                                          \
+  if (K == K_ && ctw == C_) {                                                      \
+    if (pt == 4) launch_pw_xs_t<K_, C_, 4, D_>(a, M, s); else launch_pw_xs_t<K_, C_, 2, D_>(a, M, s); \
+    return 0;                                                                      \
+  }
+  // D: k-steps of weight fragments in flight per wave — a step is 4 * PT * CTW MFMAs (32 cycles each), an L2 round trip
+  // about 1500 cycles: the narrower the wave's channel slice, the deeper the ring (K = 64 with one tile: everything)
+  JN_XS(64, 1, 4) JN_XS(64, 2, 4)
+  JN_XS(128, 1, 4) JN_XS(128, 2, 4) JN_XS(128, 4, 2)
+  JN_XS(256, 2, 4) JN_XS(256, 4, 2)
+  JN_XS(512, 4, 2)
+#undef JN_XS
+  return -1;
+}
+
+}  // namespace jnr

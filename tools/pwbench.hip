@@ -11,6 +11,8 @@
 
 #include "../jolineedle_amd/csrc/kernels_conv.hip"
 #include "../jolineedle_amd/csrc/kernels_pwres.hip"
+#include "../jolineedle_amd/csrc/kernels_pwxs.hip"
+#include "pwres_legacy.hip"
 
 using namespace jnr;
 

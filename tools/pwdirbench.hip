@@ -13,6 +13,7 @@
 
 #include "../jolineedle_amd/csrc/kernels_conv.hip"
 #include "../jolineedle_amd/csrc/kernels_pwres.hip"
+#include "../jolineedle_amd/csrc/kernels_pwxs.hip"
 
 using namespace jnr;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
