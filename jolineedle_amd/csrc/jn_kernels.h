@@ -106,7 +106,7 @@ bool pw_res_supported(const ConvArgs& a);              // kernels_pwres.hip: sha
 int launch_pw_dir(const ConvArgs& a, int ctw, int split, hipStream_t s);
 int launch_pw_wide(const ConvArgs& a, hipStream_t s);   // production route: 0 when taken
 bool pw_xs_supported(const ConvArgs& a);               // kernels_pwxs.hip: pixel-stationary kernel for the small maps of a forward pass
-int launch_pw_xs(const ConvArgs& a, int pt, hipStream_t s);
+int launch_pw_xs(const ConvArgs& a, int pt, hipStream_t s, int wg_per_cu = 0);   // pt: pixel tiles per workgroup (0 = default)
 int launch_spp(void* cat, int dtype, int ld, int h, int H, int W, int N, ChanTab it, const int* skip_flag,
                int skip_when, hipStream_t s);
 int launch_upsample(const void* in, int in_ld, void* out, int out_ld, int dtype, int C, int H, int W, int N,

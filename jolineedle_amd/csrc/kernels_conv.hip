@@ -999,10 +999,11 @@ static void launch_pw_types(const ConvArgs& a, hipStream_t s) {
 // Type combinations in use: fp32 mode (f32, f32, fp32 MFMA); bf16 mode: activations (bf16 -> bf16),
 // embed_fpn.0 (bf16 -> f32) and gradients (f32 -> f32), all on the bf16 MFMA.
 // Pixel-stationary kernel (kernels_pwxs.hip) for the forward 1x1 layers with K, N >= 64 on at most JN_XS_MAX_M pixels per
-// launch (the 28x28 / 14x14 maps of the headline batch); JN_NO_PW_XS=1 keeps them on the weight-stationary kernel.
+// launch (the 56x56 / 28x28 / 14x14 maps of the headline batch: 10 - 30 % under the weight-stationary kernel on every one
+// of them, profiles/r03_pwxsbench.txt); JN_NO_PW_XS=1 keeps them on the weight-stationary kernel.
 static int launch_pw_small_maps(const ConvArgs& a, hipStream_t s) {
   static const bool off = std::getenv("JN_NO_PW_XS") != nullptr;
-  static const long long max_m = std::getenv("JN_XS_MAX_M") ? std::atoll(std::getenv("JN_XS_MAX_M")) : 65536;
+  static const long long max_m = std::getenv("JN_XS_MAX_M") ? std::atoll(std::getenv("JN_XS_MAX_M")) : 262144;
   if (off || (long long)a.N * a.H * a.W > max_m || !pw_xs_supported(a)) return -1;
   return launch_pw_xs(a, 0, s);
 }

@@ -9,16 +9,16 @@
 // two transcendentals per value each time), and a wave sees only one or two tiles, so nothing reaches a steady state.
 // Here the roles are swapped:
 //   * a workgroup owns BM = 16 * PT pixels and ALL N output channels: its [BM][K] operand is read from HBM once,
-//     transformed once (every thread keeps the (scale, shift, flag) quad of ITS four input channels in registers — thread
-//     t always handles channel quad t % (K / 4) — so the table never goes through LDS and its fp64 arithmetic runs under
-//     the operand loads), and staged in LDS once: ONE barrier in the kernel;
+//     transformed once (thread t always handles channel quad t % (K / 4), so its (scale, shift, flag) quad sits in
+//     registers; the table is formed once per workgroup while the operand loads are in flight) and staged in LDS once:
+//     two barriers in the kernel, none in the matrix loop;
 //   * each of the four waves owns N / 4 output channels and streams their weight rows straight from L2 into registers in
 //     MFMA fragment layout (lane (row, g) reads w[n0 + row][16 j + 4 g .. + 3]), D steps ahead of the MFMAs that use
 //     them: the weights never touch LDS and are not shared between waves, so no second barrier;
 //   * per 16-wide k step a wave issues PT ds_read_b128 + CTW global loads for 4 * PT * CTW MFMAs (64 for 64 pixels x 64
 //     channels): the matrix pipe is the only busy unit inside the loop;
-//   * the BatchNorm sums of a wave's channels are complete inside the wave (DPP row sums): fp64 atomics straight from
-//     registers, no cross-wave reduction.
+//   * the BatchNorm sums of a wave's channels are complete inside the wave (DPP row sums): no cross-wave reduction, one
+//     coalesced set of fp64 atomics per workgroup.
 // Exact fp32 (v_mfma_f32_16x16x4_f32), the same fragment layout and k order as pw_mfma_kernel / pw_dir_kernel: results
 // are bit-identical to theirs.
 #include <hip/hip_runtime.h>
@@ -34,129 +34,167 @@
 namespace jnr {
 
 template <int K, int CTW, int PT, int D>
-__global__ __launch_bounds__(256, (K <= 256 ? 2 : 1)) void pw_xs_kernel(
+__global__ __launch_bounds__(256, (K <= 64 ? 3 : (K <= 128 || (K == 256 && CTW <= 2)) ? 2 : 1)) void pw_xs_kernel(
     const float* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, float* __restrict__ out, int out_ld,
     long long M, double* __restrict__ stats, long long rep_stride, int nrep, const int* __restrict__ skip_flag,
     int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
-  constexpr int BM = 16 * PT, LDX = K + 8, KQ = K / 4, NJ = K / 16;
+  constexpr int BM = 16 * PT, LDX = K + 8, KQ = K / 4, NJ = K / 16, N = 64 * CTW;
   constexpr int NX = BM * KQ / 256;                    // float4 of the operand tile per thread
   constexpr int NXB = NX < 16 ? NX : 16;               // ... fetched in batches of at most 16 (64 VGPRs in flight)
   static_assert(256 % KQ == 0 && NX >= 1 && NX % NXB == 0 && NJ % D == 0, "pw_xs tile mapping");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* Xs = reinterpret_cast<float*>(smem_raw);      // [BM][LDX]
+  float* Tb = Xs + BM * LDX;                           // [3][K], later [N][2] statistics
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, g = lane >> 4;
-  const long long m0 = (long long)blockIdx.x * BM;
+  const long long n_tiles = (M + BM - 1) / BM;
 
-  // ---- weight fragments of the first D k-steps: in flight before anything else ----
+  // ---- weight fragments: the first D k-steps (D == K / 16: all of them, once per workgroup) ----
   const float* wrow[CTW];
 #pragma unroll
   for (int c = 0; c < CTW; ++c) wrow[c] = w + (long long)((wave * CTW + c) * 16 + lm) * K + 4 * g;
   f32x4 wr[D][CTW];
+  auto wload_head = [&]() {
 #pragma unroll
-  for (int u = 0; u < D; ++u)
+    for (int u = 0; u < D; ++u)
 #pragma unroll
-    for (int c = 0; c < CTW; ++c) wr[u][c] = *reinterpret_cast<const f32x4*>(wrow[c] + 16 * u);
+      for (int c = 0; c < CTW; ++c) wr[u][c] = *reinterpret_cast<const f32x4*>(wrow[c] + 16 * u);
+  };
+  wload_head();
 
-  // ---- operand tile: global -> registers (first batch), table quad meanwhile, transform, -> LDS ----
+  // ---- operand tile loads (every load unconditional: rows past the end re-read the last row and are zeroed after the
+  //      transform — a per-load bounds branch made the compiler wait for each load before issuing the next) ----
   const int q = tid % KQ, r0 = tid / KQ;               // channel quad of this thread, first row; rows advance by 256 / KQ
   constexpr int RS = 256 / KQ;
   f32x4 xr[NXB];
-  auto fetch = [&](int b) {
+  auto fetch = [&](long long m0, int b) {
 #pragma unroll
     for (int u = 0; u < NXB; ++u) {
-      const long long m = m0 + r0 + (long long)(b * NXB + u) * RS;
-      xr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (m < M) xr[u] = *reinterpret_cast<const f32x4*>(x + m * x_ld + 4 * q);
+      long long m = m0 + r0 + (long long)(b * NXB + u) * RS;
+      m = m < M ? m : M - 1;
+      xr[u] = *reinterpret_cast<const f32x4*>(x + m * x_ld + 4 * q);
     }
   };
-  fetch(0);
-  f32x4 sc, sh, fl;
+  long long tile = blockIdx.x;
+  fetch(tile * BM, 0);
+  // the (scale, shift, flag) entries of the K input channels, once per workgroup (deferred entries: fp64 arithmetic on the
+  // producer's batch sums, jn_tab.h), while the first operand loads are in flight
+  tab_to_lds(Tb, K, K, it, tid, 256);
+  __syncthreads();
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(Tb + 4 * q), sh = *reinterpret_cast<const f32x4*>(Tb + K + 4 * q),
+              fl = *reinterpret_cast<const f32x4*>(Tb + 2 * K + 4 * q);
+  f32x4 s1[CTW], s2[CTW];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float a, b, f;
-    tab_entry(it, 4 * q + e, a, b, f);
-    sc[e] = a; sh[e] = b; fl[e] = f;
-  }
-#pragma unroll
-  for (int b = 0; b < NX / NXB; ++b) {
-    if (b > 0) fetch(b);
-#pragma unroll
-    for (int u = 0; u < NXB; ++u) {
-      const int r = r0 + (b * NXB + u) * RS;
-      f32x4 v = tf4_tab(xr[u], sc, sh, fl);
-      if (m0 + r >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};  // rows past the end contribute nothing (T(0) is not 0)
-      *reinterpret_cast<f32x4*>(Xs + r * LDX + 4 * q) = v;
-    }
-  }
-  __syncthreads();                                     // the only barrier
+  for (int c = 0; c < CTW; ++c) { s1[c] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[c] = s1[c]; }
 
-  // ---- MFMAs: D-step ring of weight fragments, operand fragments from LDS ----
-  f32x4 acc[CTW][PT];
-#pragma unroll
-  for (int c = 0; c < CTW; ++c)
-#pragma unroll
-    for (int p = 0; p < PT; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* xrow = Xs + lm * LDX + 4 * g;
+  // ---- persistent over pixel tiles: the next tile's operand is fetched into registers under the MFMAs of this one ----
 #pragma unroll 1
-  for (int j0 = 0; j0 < NJ; j0 += D) {
+  for (; tile < n_tiles; tile += gridDim.x) {
+    const long long m0 = tile * BM;
 #pragma unroll
-    for (int u = 0; u < D; ++u) {
-      const int j = j0 + u;
-      f32x4 xa[PT], wa[CTW];
+    for (int b = 0; b < NX / NXB; ++b) {
+      if (b > 0) fetch(m0, b);
 #pragma unroll
-      for (int p = 0; p < PT; ++p) xa[p] = *reinterpret_cast<const f32x4*>(xrow + p * 16 * LDX + 16 * j);
-#pragma unroll
-      for (int c = 0; c < CTW; ++c) wa[c] = wr[u][c];
-      if (j + D < NJ) {
-#pragma unroll
-        for (int c = 0; c < CTW; ++c) wr[u][c] = *reinterpret_cast<const f32x4*>(wrow[c] + 16 * (j + D));
+      for (int u = 0; u < NXB; ++u) {
+        const int r = r0 + (b * NXB + u) * RS;
+        f32x4 v = tf4_tab(xr[u], sc, sh, fl);
+        if (m0 + r >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};  // rows past the end contribute nothing (T(0) is not 0)
+        *reinterpret_cast<f32x4*>(Xs + r * LDX + 4 * q) = v;
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int c = 0; c < CTW; ++c)
-#pragma unroll
-          for (int p = 0; p < PT; ++p) acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][e], xa[p][e], acc[c][p], 0, 0, 0);
     }
+    __syncthreads();
+    if (tile + gridDim.x < n_tiles) fetch((tile + gridDim.x) * BM, 0);
+
+    // ---- MFMAs: D-step ring of weight fragments, operand fragments from LDS ----
+    f32x4 acc[CTW][PT];
+#pragma unroll
+    for (int c = 0; c < CTW; ++c)
+#pragma unroll
+      for (int p = 0; p < PT; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xrow = Xs + lm * LDX + 4 * g;
+#pragma unroll 1
+    for (int j0 = 0; j0 < NJ; j0 += D) {
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        const int j = j0 + u;
+        f32x4 xa[PT], wa[CTW];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) xa[p] = *reinterpret_cast<const f32x4*>(xrow + p * 16 * LDX + 16 * j);
+#pragma unroll
+        for (int c = 0; c < CTW; ++c) wa[c] = wr[u][c];
+        if constexpr (D < NJ) {                           // ring (D == NJ: every fragment stays in registers)
+          // step j + D; past the end: the head of the NEXT tile's ring (same fragments for every tile)
+          const int jn = j + D < NJ ? j + D : j + D - NJ;
+#pragma unroll
+          for (int c = 0; c < CTW; ++c) wr[u][c] = *reinterpret_cast<const f32x4*>(wrow[c] + 16 * jn);
+          // keep the loads HERE, ahead of this step's MFMAs (left alone, the scheduler sank all of a body's loads to its
+          // end and the next body waited out an L2 round trip on its first step)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int c = 0; c < CTW; ++c)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][e], xa[p][e], acc[c][p], 0, 0, 0);
+      }
+    }
+
+    // ---- store (lane = 4 consecutive channels of one pixel), BatchNorm sums in registers across the tiles ----
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+      const int n = (wave * CTW + c) * 16 + 4 * g;
+#pragma unroll
+      for (int p = 0; p < PT; ++p) {
+        const long long m = m0 + 16 * p + lm;
+        const f32x4 v = acc[c][p];
+        if (m < M) *reinterpret_cast<f32x4*>(out + m * out_ld + n) = v;
+        s1[c] += v; s2[c] += v * v;                       // rows past the end are exact zeros
+      }
+    }
+    __syncthreads();                                      // every wave is done reading the tile
   }
 
-  // ---- store (lane = 4 consecutive channels of one pixel) + BatchNorm sums ----
+  // ---- BatchNorm sums: through LDS to ONE coalesced set of fp64 atomics per workgroup (thread t -> value t of [N][2]):
+  // issued straight from the four row-leader lanes of every wave they were 8 * CTW instructions of 4 scattered lanes each —
+  // ten times the L2 atomic transactions, and the kernel's time was proportional to their number (36 - 140 us).
+  if (stats) {
+    float* red = Tb;                                    // [N][2] (3 K >= 2 N for every instantiated shape but K = 64, N = 128)
+    if constexpr (3 * K < 2 * N) red = Xs;
 #pragma unroll
-  for (int c = 0; c < CTW; ++c) {
-    const int n = (wave * CTW + c) * 16 + 4 * g;
-    f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
-#pragma unroll
-    for (int p = 0; p < PT; ++p) {
-      const long long m = m0 + 16 * p + lm;
-      const f32x4 v = acc[c][p];
-      if (m < M) *reinterpret_cast<f32x4*>(out + m * out_ld + n) = v;
-      s1 += v; s2 += v * v;                             // rows past the end are exact zeros
-    }
-    if (stats) {
-      double* st = stats + (blockIdx.x % nrep) * rep_stride + 2 * n;
+    for (int c = 0; c < CTW; ++c) {
+      const int n = (wave * CTW + c) * 16 + 4 * g;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float a = row16_sum(s1[r]);
-        const float b = row16_sum(s2[r]);
-        if (lm == 0) { atomicAdd(st + 2 * r, (double)a); atomicAdd(st + 2 * r + 1, (double)b); }
+        const float a = row16_sum(s1[c][r]);
+        const float b = row16_sum(s2[c][r]);
+        if (lm == 0) { red[2 * (n + r)] = a; red[2 * (n + r) + 1] = b; }
       }
     }
+    __syncthreads();
+    double* st = stats + (blockIdx.x % nrep) * rep_stride;
+    for (int i = tid; i < 2 * N; i += 256) atomicAdd(st + i, (double)red[i]);
   }
 }
 
 template <int K, int CTW, int PT, int D>
-static void launch_pw_xs_t(const ConvArgs& a, long long M, hipStream_t s) {
+static void launch_pw_xs_t(const ConvArgs& a, long long M, int wg_per_cu, hipStream_t s) {
   constexpr int BM = 16 * PT;
-  const size_t smem = (size_t)BM * (K + 8) * sizeof(float);
+  const size_t smem = ((size_t)BM * (K + 8) + 3 * K) * sizeof(float);
   auto kern = pw_xs_kernel<K, CTW, PT, D>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static int places = 0;
+  if (!places) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+    places = per_cu;
   }
-  const long long gx = (M + BM - 1) / BM;
+  // persistent grid: at most `wg_per_cu` (<= what fits) workgroups per CU, so that every workgroup is resident from the
+  // start and walks over its tiles with the next operand in flight
+  const long long n_tiles = (M + BM - 1) / BM;
+  const int per_cu = std::max(1, std::min(places, wg_per_cu > 0 ? wg_per_cu : 2));
+  const long long gx = std::min<long long>(n_tiles, 256LL * per_cu);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), smem, s, (const float*)a.in, a.in_ld, a.itab, a.w, (float*)a.out,
                      a.out_ld, M, a.stats, a.stats_rep_stride, a.stats_nrep > 0 ? a.stats_nrep : JN_NREP, a.skip_flag,
                      a.skip_when);
@@ -177,20 +215,27 @@ bool pw_xs_supported(const ConvArgs& a) {
   return a.in_ld % 4 == 0 && a.out_ld % 4 == 0;
 }
 
-int launch_pw_xs(const ConvArgs& a, int pt, hipStream_t s) {
+int launch_pw_xs(const ConvArgs& a, int pt, hipStream_t s, int wg_per_cu) {
   if (!pw_xs_supported(a)) return -1;
   const long long M = (long long)a.N * a.H * a.W;
   const int K = a.cin, ctw = a.cout / 64;
-  if (pt == 0) pt = 4;
+  // measured best per shape (tools/pwxsbench.hip, profiles/r03_pwxsbench.txt): 32-pixel tiles and two persistent
+  // workgroups per CU almost everywhere; 64-pixel tiles, one workgroup per CU for K = 512 (LDS) and for 64 -> 128
+  if (pt == 0) {
+    const bool big = K == 512 || (K == 64 && ctw == 2);
+    pt = big ? 4 : 2;
+    if (wg_per_cu == 0) wg_per_cu = big ? 1 : 2;
+  }
 #define JN_XS(K_, C_, D_)                                                          \
   if (K == K_ && ctw == C_) {                                                      \
-    if (pt == 4) launch_pw_xs_t<K_, C_, 4, D_>(a, M, s); else launch_pw_xs_t<K_, C_, 2, D_>(a, M, s); \
+    if (pt == 4) launch_pw_xs_t<K_, C_, 4, D_>(a, M, wg_per_cu, s); else launch_pw_xs_t<K_, C_, 2, D_>(a, M, wg_per_cu, s); \
     return 0;                                                                      \
   }
   // D: k-steps of weight fragments in flight per wave — a step is 4 * PT * CTW MFMAs (32 cycles each), an L2 round trip
-  // about 1500 cycles: the narrower the wave's channel slice, the deeper the ring (K = 64 with one tile: everything)
+  // about 1500 cycles: the narrower the wave's channel slice, the deeper the ring; D = K / 16 (K <= 128 with at most two
+  // channel tiles per wave): every fragment is fetched up front, no loads inside the matrix loop
   JN_XS(64, 1, 4) JN_XS(64, 2, 4)
-  JN_XS(128, 1, 4) JN_XS(128, 2, 4) JN_XS(128, 4, 2)
+  JN_XS(128, 1, 8) JN_XS(128, 2, 8) JN_XS(128, 4, 2)
   JN_XS(256, 2, 4) JN_XS(256, 4, 2)
   JN_XS(512, 4, 2)
 #undef JN_XS

@@ -74,12 +74,14 @@ int main(int argc, char** argv) {
       const float t_old = time_it([&] { launch_pw_types<float, float, false>(a, s); });
       printf(" mfma %5.1f", t_old);
       if (launch_pw_dir(a, 0, 0, s) == 0 && hipDeviceSynchronize() == hipSuccess) printf(" dir %5.1f", time_it([&] { launch_pw_dir(a, 0, 0, s); }));
-      for (int pt : {2, 4}) {
-        if (launch_pw_xs(a, pt, s) != 0) { printf(" xs%d n/a", pt); continue; }
-        hipError_t e = hipDeviceSynchronize();
-        if (e != hipSuccess) { printf(" xs%d %s\n", pt, hipGetErrorString(e)); return 1; }
-        printf(" xs%d %5.1f", pt, time_it([&] { launch_pw_xs(a, pt, s); }));
-      }
+      for (int pt : {2, 4})
+        for (int wg : {1, 2, 3}) {
+          if (dt == 0 && wg != 2) continue;
+          if (launch_pw_xs(a, pt, s, wg) != 0) { printf(" xs%d n/a", pt); continue; }
+          hipError_t e = hipDeviceSynchronize();
+          if (e != hipSuccess) { printf(" xs%d %s\n", pt, hipGetErrorString(e)); return 1; }
+          printf(" xs%d/%d %5.1f", pt, wg, time_it([&] { launch_pw_xs(a, pt, s, wg); }));
+        }
     }
     // correctness: outputs bit for bit against pw_mfma_kernel (deferred table), statistics to fp64 rounding
     a.itab = defer;
