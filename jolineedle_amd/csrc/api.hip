@@ -1005,6 +1005,7 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
   const ChanTab ident{ctx->ident, ctx->ident + 2048, ctx->ident + 4096};
   std::map<int, std::pair<int, View>> g_alias;      // conv output buffer -> (coff, gradient view to read instead)
   std::set<int> red_done;                           // conv slots whose BN-backward sums a consumer's kernel already formed
+  std::map<int, View> shortcut_grad;                // op index of a bottleneck's conv1 -> gradient view of its shortcut sum
   // Wide 1x1 layers (unfused path): the weight-gradient GEMM only feeds the optimiser, so it runs on a second stream
   // beside the data-gradient GEMM of the same layer and whatever follows; joined before this function returns.
   static const bool no_aux = std::getenv("JN_NO_AUX_STREAM") != nullptr;
@@ -1065,6 +1066,10 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
           fa.x = (const float*)ptr(op.in); fa.x_ld = ld(op.in); fa.it = tab(op.in); fa.w = cw.w_dev + (size_t)c0 * cw.cin;
           fa.gx = gptr(op.in); fa.gx_ld = ld(op.in); fa.accumulate = (op.acc_in || part > 0) ? 1 : 0;
           fa.gw = gw + (size_t)c0 * cw.cin; fa.wpart = ctx->wpart; fa.M = M; fa.cout = pc; fa.cin = cw.cin; fa.sb = sb;
+          const auto sg = shortcut_grad.find(obi);
+          if (sg != shortcut_grad.end()) {      // the shortcut add's backward left its copy to this kernel (OP_ADDACT below)
+            fa.gadd = gptr(sg->second); fa.gadd_ld = ld(sg->second); fa.accumulate = 0;
+          }
           if (parts == 1 && !op.acc_in && !no_red_fusion && pw_bwd_fused_reduces_input(pc, cw.cin)) {
             const int prod = sole_producer(net, obi);
             if (prod >= 0) {
@@ -1174,7 +1179,29 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
         const long long M = (long long)N * op.out.H * op.out.W;
         if (op.acc_in) launch_grad_copy(gptr(op.out), ld(op.out), gptr(op.in), ld(op.in), op.out.C, M, 1, s, sb);
         else g_alias[op.in.buf] = std::make_pair(op.in.coff, op.out);       // sole consumer: no copy, see above
-        launch_grad_copy(gptr(op.out), ld(op.out), gptr(op.res), ld(op.res), op.out.C, M, op.acc_res ? 1 : 0, s, sb);
+        // The shortcut branch: g[res] += g[sum].  When the only other reader of `res` is the bottleneck's first 1x1 conv
+        // and that layer takes the fused backward kernel, the kernel adds g[sum] while it writes its data gradient (one
+        // read of g[sum] instead of a copy pass — read, read-modify-write — over the largest 16 / 32-channel maps)
+        {
+          static const bool no_fold = std::getenv("JN_NO_SHORTCUT_FOLD") != nullptr;
+          static const bool no_fused2 = std::getenv("JN_NO_FUSED_BWD") != nullptr;
+          int conv1 = -1, readers = 0;
+          for (int j = 0; j < n_ops_b; ++j) {
+            const Op& o = net.ops[j];
+            if (j != obi && (views_overlap(o.in, op.res) || views_overlap(o.res, op.res))) {
+              ++readers;
+              if (o.kind == OP_PW && o.in.buf == op.res.buf && o.in.coff == op.res.coff && o.in.C == op.res.C && j < obi) conv1 = j;
+            }
+          }
+          bool fold = !no_fold && !no_fused2 && !op.acc_res && readers == 1 && conv1 >= 0 && net.act_dtype == JN_F32;
+          if (fold) {
+            const Op& c1 = net.ops[conv1];
+            const ConvW& cw1 = net.convs[c1.wslot];
+            fold = c1.acc_in && cw1.prefix2.empty() && pw_bwd_fused_supported(cw1.cout, cw1.cin);
+          }
+          if (fold) shortcut_grad[conv1] = op.out;
+          else launch_grad_copy(gptr(op.out), ld(op.out), gptr(op.res), ld(op.res), op.out.C, M, op.acc_res ? 1 : 0, s, sb);
+        }
         break;
       }
       case OP_SPP: {
@@ -1891,6 +1918,7 @@ static int launch_gpt_bwd(jn_ctx* ctx, GptBwdArgs& ba, hipStream_t s) {
 }
 
 }  // extern "C"
+static bool bf16_train_allowed() { static const bool on = std::getenv("JN_ALLOW_BF16_TRAIN") != nullptr; return on; }
 static int reinforce_backward_impl(jn_ctx* ctx, const jn_rollout_out* out, int S, int stop_early, hipStream_t s);
 static int check_train_outputs(jn_ctx* ctx, const jn_rollout_out* out) {
   JN_CHECK(out->logits_dev && out->actions_dev && out->returns_dev && out->logit_masks_dev && out->positions_dev &&
@@ -1898,8 +1926,9 @@ static int check_train_outputs(jn_ctx* ctx, const jn_rollout_out* out) {
            JN_EINVAL, "training needs logits/actions/returns/logit_masks/positions/final_emb/rewards/masks outputs");
   JN_CHECK(!ctx->cfg.no_patch_emb, JN_ESTATE, "training without a patch encoder is not supported");
   JN_CHECK(ctx->cfg.block_size <= 62, JN_EINVAL, "training supports block_size <= 62");
-  // batch-statistics BatchNorm on bf16-rounded pre-activations is ill-conditioned
-  JN_CHECK(ctx->cfg.act_dtype == JN_F32, JN_ESTATE, "training needs act_dtype = fp32 (bf16 is the inference mode)");
+  // batch-statistics BatchNorm on bf16-rounded pre-activations is ill-conditioned (JN_ALLOW_BF16_TRAIN=1
+  // lifts the refusal for the measurement behind that statement, tools/bf16_train_probe.py)
+  JN_CHECK(ctx->cfg.act_dtype == JN_F32 || bf16_train_allowed(), JN_ESTATE, "training needs act_dtype = fp32 (bf16 is the inference mode)");
   return JN_OK;
 }
 extern "C" {
@@ -2050,7 +2079,7 @@ static int supervised_forward_impl(jn_ctx* ctx, const float* patches_dev, const 
   JN_CHECK(ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
   const jn_config& c = ctx->cfg;
   JN_CHECK(!c.no_patch_emb, JN_ESTATE, "training without a patch encoder is not supported");
-  JN_CHECK(c.act_dtype == JN_F32, JN_ESTATE, "training needs act_dtype = fp32 (bf16 is the inference mode)");
+  JN_CHECK(c.act_dtype == JN_F32 || bf16_train_allowed(), JN_ESTATE, "training needs act_dtype = fp32 (bf16 is the inference mode)");
   JN_CHECK(T >= 1 && T <= c.block_size && c.block_size <= 62, JN_EINVAL, "sequence length %d out of range", T);
   JN_CHECK(B >= 1 && B * T <= c.max_batch, JN_EINVAL, "B*T = %d patches exceed max_batch = %d", B * T, c.max_batch);
   JN_CHECK(!c.use_pos_emb || positions_dev, JN_EINVAL, "positions are required when use_pos_emb is set");

@@ -190,6 +190,9 @@ struct PwBwdFusedArgs {
   SlotBatch sb;
   // optional: accumulate the BN-backward sums of the layer that produced the input (sole consumer, not accumulating)
   double* red_in; long long red_rep_stride;
+  // optional: a second gradient of the layer input, added while gx is written (the shortcut branch of a bottleneck:
+  // g[input] = W^T g_z + g[sum]); same pixel indexing as gx
+  const float* gadd; int gadd_ld;
 };
 struct DwBwdFusedArgs {                  // the depthwise counterpart (3x3, pad 1, stride 1 / 2)
   const float* g; int g_ld; const float* z; int z_ld; ChanTab ot; const float* save; const float* consts;

@@ -490,7 +490,8 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
     const float* __restrict__ g, int g_ld, const float* __restrict__ z, int z_ld, ChanTab ot,
     const float* __restrict__ save, const float* __restrict__ consts, const float* __restrict__ x, int x_ld,
     ChanTab it, const float* __restrict__ w, float* __restrict__ gx, int gx_ld, int accumulate,
-    float* __restrict__ gw, int rep, long long M, SlotBatch sb, double* __restrict__ red_in, long long red_rep_stride) {
+    float* __restrict__ gw, int rep, long long M, SlotBatch sb, double* __restrict__ red_in, long long red_rep_stride,
+    const float* __restrict__ gadd, int gadd_ld) {
   constexpr int N = 16 * CTN, K = 16 * CTK;          // output / input channels
   constexpr int LDG = N + 4, LDA = K + 4, LDW = N + 4;
   constexpr int NG = 64 * (N / 4) / 256, NA = 64 * (K / 4) / 256;     // f32x4 per thread per tile (may be 0 -> 1)
@@ -506,6 +507,7 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
     g += sl * sb.grad; z += sl * sb.act; x += sl * sb.act; gx += sl * sb.grad;
     save += sl * sb.save; consts += sl * sb.consts;
     if (RED) red_in += sl * sb.red;
+    if (gadd) gadd += sl * sb.grad;
     ot.sc += sl * sb.tab; ot.sh += sl * sb.tab;
     it.sc += sl * sb.tab; it.sh += sl * sb.tab; it.fl += sl * sb.tab;
   }
@@ -632,6 +634,8 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
         for (int b = 0; b < CTK; ++b) {
           float* op = gx + m * gx_ld + 16 * b + 4 * gq;
           f32x4 v = acc[b];
+          // shortcut of a bottleneck: the gradient of the sum joins here (the shortcut add's own backward pass is gone)
+          if (gadd) v += *reinterpret_cast<const f32x4*>(gadd + m * gadd_ld + 16 * b + 4 * gq);
           if (accumulate) v += *reinterpret_cast<const f32x4*>(op);
           *reinterpret_cast<f32x4*>(op) = v;
         }
@@ -783,7 +787,7 @@ static void launch_pw_bwd_fused_r(const PwBwdFusedArgs& a, hipStream_t s) {
   const int rep = (a.wpart && N * K <= JN_WPART_MAX) ? 1 : 0;
   hipLaunchKernelGGL((pw_bwd_fused_kernel<CTN, CTK, RED>), dim3((unsigned)bx, a.sb.n), dim3(256), smem, s, a.g, a.g_ld, a.z,
                      a.z_ld, a.ot, a.save, a.consts, a.x, a.x_ld, a.it, a.w, a.gx, a.gx_ld, a.accumulate,
-                     rep ? a.wpart : a.gw, rep, a.M, a.sb, a.red_in, a.red_rep_stride);
+                     rep ? a.wpart : a.gw, rep, a.M, a.sb, a.red_in, a.red_rep_stride, a.gadd, a.gadd_ld);
   if (rep) launch_wpart_reduce(a.gw, a.wpart, N * K, s);
 }
 
