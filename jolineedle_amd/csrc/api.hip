@@ -977,6 +977,43 @@ static int sole_producer(const Net& net, int obi) {
   return prod;
 }
 
+// Generalisation for the fused 1x1 kernels (round 3): the producer of channel segment [coff, coff + C) of buffer `buf` as
+// ONE BatchNorm conv — its whole output, or one half of a merged conv2|conv1 pair (half 0 = conv2 rows, 1 = conv1 rows) —
+// whose only reader is op `reader` (plus, optionally, the shortcut add `folded_addact` whose gradient copy the reader's
+// kernel has absorbed).  The reader then holds the FINAL gradient of the segment and can form that layer's BN-backward
+// sums in its epilogue.
+struct RedRun { int wslot = -1; int half = -1; };     // half -1: whole conv
+static bool red_segment(const Net& net, int reader, int buf, int coff, int C, int folded_addact, RedRun& out) {
+  View seg; seg.buf = buf; seg.coff = coff; seg.C = C;
+  for (int i = 0; i < 3; ++i)
+    if (views_overlap(seg, net.fpn[i])) return false;
+  int prod = -1;
+  for (int j = 0; j < (int)net.ops.size(); ++j) {
+    const Op& o = net.ops[j];
+    if (j != reader && views_overlap(o.in, seg)) return false;
+    if (j != reader && j != folded_addact && views_overlap(o.res, seg)) return false;
+    if (o.kind == OP_SPP && o.out.buf == buf) return false;
+    if (views_overlap(o.out, seg) || views_overlap(o.alias, seg)) {
+      if (prod >= 0 || j >= reader) return false;
+      prod = j;
+    }
+  }
+  if (prod < 0) return false;
+  const Op& po = net.ops[prod];
+  if (po.wslot < 0 || po.out.buf != buf || views_overlap(po.alias, seg)) return false;
+  const ConvW& pw = net.convs[po.wslot];
+  if (!pw.has_bn) return false;
+  if (pw.prefix2.empty()) {
+    if (po.out.coff != coff || po.out.C != C || pw.cout != C) return false;
+    out.wslot = po.wslot; out.half = -1;
+    return true;
+  }
+  if (pw.cout != 2 * C || 2 * pw.cout_first != pw.cout || po.out.C != 2 * C) return false;
+  if (coff == po.out.coff) out.half = 0; else if (coff == po.out.coff + C) out.half = 1; else return false;
+  out.wslot = po.wslot;
+  return true;
+}
+
 // Backward of `nsl` train-mode PAFPN passes (workspace slots slot .. slot + nsl - 1, N patches each; gradient
 // slots 0 .. nsl - 1): every kernel is launched ONCE for all the passes (SlotBatch), so a 20-step trajectory
 // costs the launches of one pass.  g[fpn views] must hold the incoming gradients; parameter gradients are
@@ -1005,7 +1042,9 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
   const ChanTab ident{ctx->ident, ctx->ident + 2048, ctx->ident + 4096};
   std::map<int, std::pair<int, View>> g_alias;      // conv output buffer -> (coff, gradient view to read instead)
   std::set<int> red_done;                           // conv slots whose BN-backward sums a consumer's kernel already formed
+  std::map<int, int> red_half;                      // merged pairs: bit h set = half h's sums were formed by its consumer
   std::map<int, View> shortcut_grad;                // op index of a bottleneck's conv1 -> gradient view of its shortcut sum
+  std::map<int, int> shortcut_addact;               // ... -> index of the shortcut add whose copy the conv1 kernel absorbs
   // Wide 1x1 layers (unfused path): the weight-gradient GEMM only feeds the optimiser, so it runs on a second stream
   // beside the data-gradient GEMM of the same layer and whatever follows; joined before this function returns.
   static const bool no_aux = std::getenv("JN_NO_AUX_STREAM") != nullptr;
@@ -1044,11 +1083,28 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
       if (dbg_plan)
         std::fprintf(stderr, "[bwd-plan] %-28s kind %d cout %4d cin %4d M/patch %6lld stride %d acc_in %d reduce %s\n", op.name.c_str(), (int)op.kind,
                      cw.cout, cw.cin, M / N, op.stride, (int)op.acc_in, red_done.count(op.wslot) ? "fused" : "SEPARATE");
-      if (!red_done.count(op.wslot))
-        launch_bn_bwd_reduce(gp_out, gld_out, ptr(op.out), net.act_dtype, ld(op.out), tab(op.out), save + 2 * cw.stat_off, cw.cout,
-                             M, red, rep_stride, s, sb);
-      launch_bn_bwd_consts(red, rep_stride, (double)M, cw.gamma_dev, save + 2 * cw.stat_off, consts,
-                           grad_of(ctx, cw.gamma_dev), grad_of(ctx, cw.beta_dev), cw.cout, s, sb, red_done.count(op.wslot) ? 1 : 0);
+      const int hmask = red_half.count(op.wslot) ? red_half[op.wslot] : 0;
+      if (hmask && !cw.prefix2.empty() && net.act_dtype == JN_F32) {
+        // merged pair with at least one half reduced by its consumer: the other half (if any) gets its own pass, and the
+        // constants are formed per half (consumer-made sums carry the RAW second moment)
+        const int h = cw.cout / 2;
+        for (int half = 0; half < 2; ++half) {
+          const int c0 = half * h;
+          ChanTab ot = tab(op.out);
+          ot.sc += c0; ot.sh += c0; ot.fl += c0;
+          if (!(hmask & (1 << half)))
+            launch_bn_bwd_reduce(gp_out + c0, gld_out, (const float*)ptr(op.out) + c0, net.act_dtype, ld(op.out), ot,
+                                 save + 2 * (cw.stat_off + c0), h, M, red + 2 * c0, rep_stride, s, sb);
+          launch_bn_bwd_consts(red + 2 * c0, rep_stride, (double)M, cw.gamma_dev + c0, save + 2 * (cw.stat_off + c0), consts + 3 * c0,
+                               grad_of(ctx, cw.gamma_dev) + c0, grad_of(ctx, cw.beta_dev) + c0, h, s, sb, (hmask >> half) & 1);
+        }
+      } else {
+        if (!red_done.count(op.wslot))
+          launch_bn_bwd_reduce(gp_out, gld_out, ptr(op.out), net.act_dtype, ld(op.out), tab(op.out), save + 2 * cw.stat_off, cw.cout,
+                               M, red, rep_stride, s, sb);
+        launch_bn_bwd_consts(red, rep_stride, (double)M, cw.gamma_dev, save + 2 * cw.stat_off, consts,
+                             grad_of(ctx, cw.gamma_dev), grad_of(ctx, cw.beta_dev), cw.cout, s, sb, red_done.count(op.wslot) ? 1 : 0);
+      }
       float* gw = grad_of(ctx, cw.w_dev);
       static const bool no_fused = std::getenv("JN_NO_FUSED_BWD") != nullptr;
       // a merged pair too wide for the fused kernel is differentiated as its two halves (independent output rows)
@@ -1067,15 +1123,38 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
           fa.gx = gptr(op.in); fa.gx_ld = ld(op.in); fa.accumulate = (op.acc_in || part > 0) ? 1 : 0;
           fa.gw = gw + (size_t)c0 * cw.cin; fa.wpart = ctx->wpart; fa.M = M; fa.cout = pc; fa.cin = cw.cin; fa.sb = sb;
           const auto sg = shortcut_grad.find(obi);
-          if (sg != shortcut_grad.end()) {      // the shortcut add's backward left its copy to this kernel (OP_ADDACT below)
+          const bool folded = sg != shortcut_grad.end();
+          if (folded) {                         // the shortcut add's backward left its copy to this kernel (OP_ADDACT below)
             fa.gadd = gptr(sg->second); fa.gadd_ld = ld(sg->second); fa.accumulate = 0;
           }
-          if (parts == 1 && !op.acc_in && !no_red_fusion && pw_bwd_fused_reduces_input(pc, cw.cin)) {
-            const int prod = sole_producer(net, obi);
-            if (prod >= 0) {
-              const ConvW& pcw = net.convs[net.ops[prod].wslot];
-              fa.red_in = net.bred + 2 * pcw.stat_off; fa.red_rep_stride = rep_stride;
-              red_done.insert(net.ops[prod].wslot);
+          // BN-backward sums of the input's producer(s) in this kernel's epilogue: it must write the FINAL gradient of
+          // the view (sole reader, or the shortcut folded in) — one run, or the two halves of a CSP conv3's input
+          if (parts == 1 && (!op.acc_in || folded) && !no_red_fusion && pw_bwd_fused_reduces_input(pc, cw.cin)) {
+            static const bool no_half = std::getenv("JN_NO_HALF_REDUCE") != nullptr;
+            const int fa_idx = folded ? shortcut_addact[obi] : -1;
+            auto base_of = [&](const RedRun& r) {
+              const ConvW& pcw = net.convs[r.wslot];
+              const int c0 = r.half > 0 ? pcw.cout / 2 : 0;
+              return net.bred + 2 * (pcw.stat_off + c0);
+            };
+            auto mark = [&](const RedRun& r) {
+              if (r.half < 0) red_done.insert(r.wslot); else red_half[r.wslot] |= 1 << r.half;
+            };
+            RedRun r0, r1;
+            if (red_segment(net, obi, op.in.buf, op.in.coff, op.in.C, fa_idx, r0) && (r0.half < 0 || !no_half)) {
+              fa.red_in = base_of(r0); fa.red_rep_stride = rep_stride; mark(r0);
+            } else if (!no_half && op.in.C % 32 == 0 && !folded) {
+              const int hC = op.in.C / 2;
+              const bool ok0 = red_segment(net, obi, op.in.buf, op.in.coff, hC, -1, r0);
+              const bool ok1 = red_segment(net, obi, op.in.buf, op.in.coff + hC, hC, -1, r1);
+              if (ok0 || ok1) {
+                fa.red_rep_stride = rep_stride; fa.red_split = hC;
+                if (ok0) { fa.red_in = base_of(r0); mark(r0); }
+                if (ok1) { fa.red_in2 = base_of(r1); mark(r1); }
+                if (!ok1) fa.red_in2 = nullptr;
+                // (a lone second run still needs the split: red_in stays null, red_in2 set)
+                if (!ok0 && ok1) fa.red_in = nullptr;
+              }
             }
           }
           launch_pw_bwd_fused(fa, s);
@@ -1199,7 +1278,21 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
             const ConvW& cw1 = net.convs[c1.wslot];
             fold = c1.acc_in && cw1.prefix2.empty() && pw_bwd_fused_supported(cw1.cout, cw1.cin);
           }
-          if (fold) shortcut_grad[conv1] = op.out;
+          if (fold) {
+            // g[sum] must still hold the gradient when that kernel runs: the conv that feeds the add reads it in place
+            // (g_alias above) before — fine for the fused 1x1 kernel, which leaves it alone, not for the unfused paths,
+            // whose bn_bwd_gz turns it into g_z IN PLACE (dense 3x3 bottlenecks of the non-depthwise encoders)
+            bool intact = false;
+            for (int j = 0; j < obi; ++j) {
+              const Op& o = net.ops[j];
+              if (o.wslot >= 0 && o.out.buf == op.in.buf && o.out.coff == op.in.coff && o.out.C == op.in.C) {
+                const ConvW& cwp = net.convs[o.wslot];
+                intact = o.kind == OP_PW && cwp.prefix2.empty() && pw_bwd_fused_supported(cwp.cout, cwp.cin);
+              }
+            }
+            fold = intact;
+          }
+          if (fold) { shortcut_grad[conv1] = op.out; shortcut_addact[conv1] = obi; }
           else launch_grad_copy(gptr(op.out), ld(op.out), gptr(op.res), ld(op.res), op.out.C, M, op.acc_res ? 1 : 0, s, sb);
         }
         break;

@@ -188,8 +188,10 @@ struct PwBwdFusedArgs {
   float* gw; float* wpart;
   long long M; int cout, cin;
   SlotBatch sb;
-  // optional: accumulate the BN-backward sums of the layer that produced the input (sole consumer, not accumulating)
-  double* red_in; long long red_rep_stride;
+  // optional: accumulate the BN-backward sums of the layer(s) that produced the input (this op writes the FINAL gradient
+  // of the view): channels [0, red_split) -> red_in, [red_split, cin) -> red_in2 (either may be null: that run is
+  // skipped); red_split == 0: one run over all of cin into red_in
+  double* red_in; long long red_rep_stride; double* red_in2; int red_split;
   // optional: a second gradient of the layer input, added while gx is written (the shortcut branch of a bottleneck:
   // g[input] = W^T g_z + g[sum]); same pixel indexing as gx
   const float* gadd; int gadd_ld;

@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
     const float* __restrict__ save, const float* __restrict__ consts, const float* __restrict__ x, int x_ld,
     ChanTab it, const float* __restrict__ w, float* __restrict__ gx, int gx_ld, int accumulate,
     float* __restrict__ gw, int rep, long long M, SlotBatch sb, double* __restrict__ red_in, long long red_rep_stride,
-    const float* __restrict__ gadd, int gadd_ld) {
+    const float* __restrict__ gadd, int gadd_ld, double* __restrict__ red_in2, int red_split) {
   constexpr int N = 16 * CTN, K = 16 * CTK;          // output / input channels
   constexpr int LDG = N + 4, LDA = K + 4, LDW = N + 4;
   constexpr int NG = 64 * (N / 4) / 256, NA = 64 * (K / 4) / 256;     // f32x4 per thread per tile (may be 0 -> 1)
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
     const long long sl = blockIdx.y;
     g += sl * sb.grad; z += sl * sb.act; x += sl * sb.act; gx += sl * sb.grad;
     save += sl * sb.save; consts += sl * sb.consts;
-    if (RED) red_in += sl * sb.red;
+    if (RED) { if (red_in) red_in += sl * sb.red; if (red_in2) red_in2 += sl * sb.red; }
     if (gadd) gadd += sl * sb.grad;
     ot.sc += sl * sb.tab; ot.sh += sl * sb.tab;
     it.sc += sl * sb.tab; it.sh += sl * sb.tab; it.fl += sl * sb.tab;
@@ -638,6 +638,7 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
           if (gadd) v += *reinterpret_cast<const f32x4*>(gadd + m * gadd_ld + 16 * b + 4 * gq);
           if (accumulate) v += *reinterpret_cast<const f32x4*>(op);
           *reinterpret_cast<f32x4*>(op) = v;
+          acc[b] = v;                                  // RED below sums the FINAL gradient of the input
         }
       }
       if constexpr (RED) {
@@ -716,10 +717,17 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
   if constexpr (RED) {
     // per-channel sums of the input layer's BN backward: the four waves' LDS slots -> fp64 atomics
     __syncthreads();
+    // (two channel runs: [0, red_split) -> red_in, [red_split, K) -> red_in2 — the input of a CSP's conv3 is
+    //  [bottleneck output | conv2 half of the pair]; either base may be null: that run's producer has no BatchNorm or
+    //  another reader)
     const float* rs = Cs + 7 * N + 3 * K;
-    if (tid < 2 * K)
-      atomicAdd(&red_in[(blockIdx.x % JN_NREP) * red_rep_stride + tid],
-                (double)(rs[tid] + rs[2 * K + tid] + rs[4 * K + tid] + rs[6 * K + tid]));
+    if (tid < 2 * K) {
+      const bool first = tid < 2 * red_split;
+      double* base = first ? red_in : red_in2;
+      if (base)
+        atomicAdd(&base[(blockIdx.x % JN_NREP) * red_rep_stride + (first ? tid : tid - 2 * red_split)],
+                  (double)(rs[tid] + rs[2 * K + tid] + rs[4 * K + tid] + rs[6 * K + tid]));
+    }
   }
   // cross-wave sum of dW (plain LDS read-modify-write, one round per wave that shares tiles), then one set of atomics
   if constexpr (DW_SPLIT) {
@@ -787,14 +795,15 @@ static void launch_pw_bwd_fused_r(const PwBwdFusedArgs& a, hipStream_t s) {
   const int rep = (a.wpart && N * K <= JN_WPART_MAX) ? 1 : 0;
   hipLaunchKernelGGL((pw_bwd_fused_kernel<CTN, CTK, RED>), dim3((unsigned)bx, a.sb.n), dim3(256), smem, s, a.g, a.g_ld, a.z,
                      a.z_ld, a.ot, a.save, a.consts, a.x, a.x_ld, a.it, a.w, a.gx, a.gx_ld, a.accumulate,
-                     rep ? a.wpart : a.gw, rep, a.M, a.sb, a.red_in, a.red_rep_stride, a.gadd, a.gadd_ld);
+                     rep ? a.wpart : a.gw, rep, a.M, a.sb, a.red_in, a.red_rep_stride, a.gadd, a.gadd_ld, a.red_in2,
+                     a.red_split > 0 ? a.red_split : K);
   if (rep) launch_wpart_reduce(a.gw, a.wpart, N * K, s);
 }
 
 template <int CTN, int CTK>
 static void launch_pw_bwd_fused_t(const PwBwdFusedArgs& a, hipStream_t s) {
   if constexpr (CTK <= 4) {
-    if (a.red_in) { launch_pw_bwd_fused_r<CTN, CTK, true>(a, s); return; }
+    if (a.red_in || a.red_in2) { launch_pw_bwd_fused_r<CTN, CTK, true>(a, s); return; }
   }
   launch_pw_bwd_fused_r<CTN, CTK, false>(a, s);
 }

@@ -18,6 +18,15 @@ using namespace jnr;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
+__global__ void null_kernel(int* p) { if (p && threadIdx.x == 9999) *p = 1; }
+// one dependent global round trip + one barrier per workgroup: the shape of every kernel's prologue
+__global__ void touch_kernel(const float* __restrict__ in, float* __restrict__ out) {
+  __shared__ float s;
+  if (threadIdx.x == 0) s = in[blockIdx.x * 64];
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x * 64] = s + 1.0f;
+}
+
 int main(int argc, char** argv) {
   struct Shape { int hw, K, N; };
   const Shape shapes[] = {{28, 64, 64}, {28, 64, 128}, {28, 128, 64}, {28, 128, 128}, {28, 256, 128}, {14, 128, 128}, {14, 128, 256},
@@ -50,6 +59,13 @@ int main(int argc, char** argv) {
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     return ms * 1e3f / iters;
   };
+  // floor of a dependent launch on this box: in-order stream, each kernel waits for the previous one (the forward pass
+  // is ~85 such launches); "touch" adds what every real kernel has at least — one global round trip and a barrier
+  for (int wgs : {196, 784}) {
+    const float t_null = time_it([&] { hipLaunchKernelGGL(null_kernel, dim3(wgs), dim3(256), 0, s, (int*)nullptr); });
+    const float t_touch = time_it([&] { hipLaunchKernelGGL(touch_kernel, dim3(wgs), dim3(256), 0, s, (const float*)x, out); });
+    printf("launch floor, %d workgroups: empty kernel %.2f us per dependent launch, one load + barrier + store %.2f us\n", wgs, t_null, t_touch);
+  }
   for (const Shape& sh : shapes) {
     const long long M = (long long)B * sh.hw * sh.hw;
     // deferred table: channel c of the input = BatchNorm channel c of a producer with the same pixel count; sums that
