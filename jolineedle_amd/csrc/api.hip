@@ -734,32 +734,32 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
   // consumers read the batch sums (ChanTab in jn_kernels.h), one finalize launch closes the pass
   if (train && !with_head && (rc = ensure_defer_tables(ctx, net))) return rc;
   const bool defer = train && !with_head && net.defer_ok;
-  auto deferred = [&](const Op& op) { return defer && (long long)N * op.out.H * op.out.W <= JN_DEFER_MAX_M; };
+  auto deferred = [&](const Op& op) { return defer && (long long)N * op.out.H * op.out.W <= jn_defer_max_m(); };
   auto ptr = [&](const View& v) { return view_ptr(net, slot, MB, v); };
   auto tab = [&](const View& v) {
     ChanTab t = view_tab(net, slot, v);
     bool any = false;                       // does the view hold a channel whose table is deferred in this pass?
     if (defer) {
       const int off = net.tab_off[v.buf] + v.coff;
-      for (int c = 0; c < v.C && !any; ++c) any = net.h_td_hw[off + c] > 0.0f && (double)N * net.h_td_hw[off + c] <= (double)JN_DEFER_MAX_M;
+      for (int c = 0; c < v.C && !any; ++c) any = net.h_td_hw[off + c] > 0.0f && (double)N * net.h_td_hw[off + c] <= (double)jn_defer_max_m();
     }
     if (any) {
       const int off = net.tab_off[v.buf] + v.coff;
       t.dsrc = net.td_src + off; t.dhw = net.td_hw + off; t.dgoff = net.td_goff + off; t.dboff = net.td_boff + off;
-      t.dparams = ctx->params; t.dstats = stats; t.drep_stride = rep_stride; t.dN = N;
+      t.dparams = ctx->params; t.dstats = stats; t.drep_stride = rep_stride; t.dN = N; t.dmax = jn_defer_max_m();
       // channel runs for the kernel arguments (at most four: a concat of a few producers); more: the arrays above
       int ns = 0;
       bool fits = true;
       for (int c = 0; c < v.C && fits;) {
         const int tc = off + c;
-        const bool d = net.h_td_hw[tc] > 0.0f && (double)N * net.h_td_hw[tc] <= (double)JN_DEFER_MAX_M;
+        const bool d = net.h_td_hw[tc] > 0.0f && (double)N * net.h_td_hw[tc] <= (double)jn_defer_max_m();
         int e = c + 1;
         if (d) {
           while (e < v.C && net.h_td_src[off + e] == net.h_td_src[tc] + (e - c) && net.h_td_goff[off + e] == net.h_td_goff[tc] + (e - c) &&
                  net.h_td_boff[off + e] == net.h_td_boff[tc] + (e - c) && net.h_td_hw[off + e] == net.h_td_hw[tc])
             ++e;
         } else {
-          while (e < v.C && !(net.h_td_hw[off + e] > 0.0f && (double)N * net.h_td_hw[off + e] <= (double)JN_DEFER_MAX_M)) ++e;
+          while (e < v.C && !(net.h_td_hw[off + e] > 0.0f && (double)N * net.h_td_hw[off + e] <= (double)jn_defer_max_m())) ++e;
         }
         if (ns == 4) { fits = false; break; }
         const ChanTab::Run run{c, e, d ? net.h_td_src[tc] : -1, net.h_td_goff[tc], net.h_td_boff[tc], net.h_td_hw[tc]};
@@ -898,7 +898,7 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
     fa.goff = net.fd_goff; fa.boff = net.fd_boff; fa.params = ctx->params; fa.t0 = net.fd_t0; fa.t1 = net.fd_t1;
     fa.tab = net.tab + (size_t)slot * 3 * net.tab_channels; fa.tab_channels = net.tab_channels; fa.save = save;
     fa.run_mean = net.fd_rm; fa.run_var = net.fd_rv; fa.eps = kBnEps; fa.momentum = kBnMomentum;
-    fa.skip_flag = skip_flag; fa.skip_when = skip_when;
+    fa.skip_flag = skip_flag; fa.skip_when = skip_when; fa.defer_max_m = jn_defer_max_m();
     launch_bn_finalize_all(fa, s);
   }
   JN_HIP(hipGetLastError());

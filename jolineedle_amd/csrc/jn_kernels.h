@@ -35,6 +35,7 @@ struct ChanTab {
   const double* dstats;    // [JN_NREP_DEFER used][drep_stride] batch sums of the workspace slot
   long long drep_stride;
   int dN;                  // patches in this pass
+  long long dmax;          // deferral limit in pixels (dN * dhw <= dmax: deferred), jn_defer_max_m()
   // The same information as up to four channel runs in the kernel arguments (scalar registers, no memory round trip
   // before the sums can be requested): channels [c0, c1) of the view are BatchNorm channels stat0 + (c - c0) with affine
   // at g0 / b0 + (c - c0) and pixel count dN * hw — or, with stat0 < 0, plain table entries.  nseg == 0: use the arrays.
@@ -44,7 +45,8 @@ struct ChanTab {
   int nseg;
   Run r0, r1, r2, r3;
 };
-constexpr long long JN_DEFER_MAX_M = 65536;   // output pixels (N * H * W) up to which a layer's table is deferred
+constexpr long long JN_DEFER_MAX_M = 65536;   // default of jn_defer_max_m(): output pixels (N * H * W) up to which a layer's table is deferred
+long long jn_defer_max_m();                   // the limit in force (env JN_DEFER_MAX_M overrides the default; read once)
 constexpr int JN_NREP_DEFER = 8;              // statistics replicas such a layer accumulates into (its consumers sum them)
 
 // Step batching of the backward: ONE launch covers `n` workspace slots (glimpse steps of a trajectory, each
@@ -128,6 +130,7 @@ struct BnAllArgs {
   float* const* run_mean; float* const* run_var;   // per-channel addresses of the running statistics
   float eps, momentum;
   const int* skip_flag; int skip_when;
+  long long defer_max_m;                 // layers with N * hw above it used all JN_NREP replicas
 };
 int launch_bn_finalize_all(const BnAllArgs& a, hipStream_t s);
 int launch_nhwc_to_nchw(const void* in, int dtype, int in_ld, ChanTab it, float* out, int C, int HW, int N,

@@ -64,7 +64,7 @@ __device__ __forceinline__ void tab_entry(const ChanTab& t, int c, float& sc, fl
   if (t.dsrc) {
     const int src = t.dsrc[c], go = t.dgoff[c], bo = t.dboff[c];
     const float hw = t.dhw[c];
-    if (src >= 0 && (long long)t.dN * (long long)hw <= JN_DEFER_MAX_M) {
+    if (src >= 0 && (long long)t.dN * (long long)hw <= t.dmax) {
       const float gamma = t.dparams[go], beta = t.dparams[bo];
       float m, is; double var;
       bn_from_sums(t.dstats, t.drep_stride, JN_NREP_DEFER, src, (double)t.dN * (double)hw, gamma, beta, 1e-3f, sc, sh, m, is, var);

@@ -1204,15 +1204,16 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
   gz += blockIdx.z * g_slot;
   // z != null: `gz` holds d loss / d activation and g_z is formed while staging (no bn_bwd_gz pass over the
   // largest map of the network)
-  f32x4 o_sc, o_sh, o_mean, o_istd, o_c1, o_c2, o_k;
+  // the seven per-channel constants of the 16 output channels sit in LDS (a thread reads its quad while staging): in 28
+  // registers they kept the kernel at two workgroups per CU
+  __shared__ __attribute__((aligned(16))) float Cq[7 * 16];
   if (z) {
     const long long sl = blockIdx.z;
     z += sl * sb.act; save += sl * sb.save; consts += sl * sb.consts; ot.sc += sl * sb.tab; ot.sh += sl * sb.tab;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = blockIdx.y * 16 + 4 * (threadIdx.x & 3) + q;
-      o_sc[q] = ot.sc[c]; o_sh[q] = ot.sh[c]; o_mean[q] = save[2 * c]; o_istd[q] = save[2 * c + 1];
-      o_c1[q] = consts[3 * c]; o_c2[q] = consts[3 * c + 1]; o_k[q] = consts[3 * c + 2];
+    if (threadIdx.x < 16) {
+      const int c = blockIdx.y * 16 + threadIdx.x;
+      Cq[threadIdx.x] = ot.sc[c]; Cq[16 + threadIdx.x] = ot.sh[c]; Cq[32 + threadIdx.x] = save[2 * c]; Cq[48 + threadIdx.x] = save[2 * c + 1];
+      Cq[64 + threadIdx.x] = consts[3 * c]; Cq[80 + threadIdx.x] = consts[3 * c + 1]; Cq[96 + threadIdx.x] = consts[3 * c + 2];
     }
   }
   __shared__ __attribute__((aligned(16))) float Gz[SB_TY * SB_GZROW];
@@ -1277,6 +1278,11 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
       const int i = tid + 256 * j;
       f32x4 v = pg[j];
       if (z) {                                   // pixels outside the map carry g = 0 -> gy = 0, but c1 must not leak in
+        const int cq = 4 * (i & 3);
+        const f32x4 o_sc = *reinterpret_cast<const f32x4*>(Cq + cq), o_sh = *reinterpret_cast<const f32x4*>(Cq + 16 + cq),
+                    o_mean = *reinterpret_cast<const f32x4*>(Cq + 32 + cq), o_istd = *reinterpret_cast<const f32x4*>(Cq + 48 + cq),
+                    o_c1 = *reinterpret_cast<const f32x4*>(Cq + 64 + cq), o_c2 = *reinterpret_cast<const f32x4*>(Cq + 80 + cq),
+                    o_k = *reinterpret_cast<const f32x4*>(Cq + 96 + cq);
         const int p = i >> 2, ty = p / SB_TX, tx = p % SB_TX;
         const int tr = tl % (tiles_x * tiles_y);
         const bool inside = (tr / tiles_x) * SB_TY + ty < OH && (tr % tiles_x) * SB_TX + tx < OH;
@@ -1294,15 +1300,30 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
     }
     __syncthreads();
     if (tl + (int)gridDim.x < n_tiles) fetch(tl + gridDim.x);
-#pragma unroll 2
-    for (int st = 0; st < SB_TY * SB_TX / 16; ++st) {
-      // the wave owns tile rows 2 wave, 2 wave + 1; k-slot g of this step = pixel (ty, 8 g + st % 8)
-      const int ty = 2 * wave + (st >> 3), tx = 8 * g + (st & 7);
-      const float av = Gz[ty * SB_GZROW + g * SB_GZG + (st & 7) * 16 + lm];     // A[i = oc][kk = pixel]
-      const int pbase = (2 * ty) * SB_IWP + 2 * tx;
+    // Software-pipelined over the 16 k-steps (round 3): the operands of step st + 1 are read from LDS BEFORE the seven
+    // MFMAs of step st issue.  Left to the compiler (unroll 2) every step's reads were issued right before its MFMAs and
+    // the first MFMA of each step waited out the LDS latency; the matrix pipe was busy 36 % of the kernel.
+    {
+      // the wave owns tile rows 2 wave, 2 wave + 1; k-slot g of step st = pixel (ty, 8 g + st % 8)
+      auto lds_step = [&](int st, float& av, float (&bv)[7]) {
+        const int ty = 2 * wave + (st >> 3), tx = 8 * g + (st & 7);
+        av = Gz[ty * SB_GZROW + g * SB_GZG + (st & 7) * 16 + lm];               // A[i = oc][kk = pixel]
+        const int pbase = (2 * ty) * SB_IWP + 2 * tx;
 #pragma unroll
-      for (int t = 0; t < 7; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, tile[pbase + koff[t]], acc[t], 0, 0, 0);
+        for (int t = 0; t < 7; ++t) bv[t] = tile[pbase + koff[t]];
+      };
+      float av_c, bv_c[7];
+      lds_step(0, av_c, bv_c);
+#pragma unroll
+      for (int st = 0; st < SB_TY * SB_TX / 16; ++st) {
+        float av_n = 0.0f, bv_n[7];
+        if (st + 1 < SB_TY * SB_TX / 16) lds_step(st + 1, av_n, bv_n);
+#pragma unroll
+        for (int t = 0; t < 7; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_c, bv_c[t], acc[t], 0, 0, 0);
+        av_c = av_n;
+#pragma unroll
+        for (int t = 0; t < 7; ++t) bv_c[t] = bv_n[t];
+      }
     }
   }
 #pragma unroll

@@ -588,7 +588,12 @@ int launch_dw(const ConvArgs& a, hipStream_t s) {
       else { if (bf) launch_dw_lds<1, 16, 8, bf16_t>(a, s); else launch_dw_lds<1, 16, 8, float>(a, s); }
     } else {
       // stride 2: 4-row tiles halve the LDS halo tile (9 x 33 pixels): twice the workgroups per CU
-      if (bf) launch_dw_lds<2, 16, 4, bf16_t>(a, s); else launch_dw_lds<2, 16, 4, float>(a, s);
+      // 32-channel blocks where the layer has them (round 3: a pixel of the halo tile is then a whole 128-byte line instead
+      // of half of one, and the launch has half the workgroups): 112 -> 56 layer 45.3 -> 39.8 us, 56 -> 28 25.4 -> 21.9 us;
+      // JN_DW_S2_CB32=0 restores the 16-channel blocks
+      static const int cb32 = std::getenv("JN_DW_S2_CB32") ? std::atoi(std::getenv("JN_DW_S2_CB32")) : 1;
+      if (!bf && cb32 && a.cin % 32 == 0) launch_dw_lds<2, 32, 4, float>(a, s);
+      else if (bf) launch_dw_lds<2, 16, 4, bf16_t>(a, s); else launch_dw_lds<2, 16, 4, float>(a, s);
     }
     return 0;
   }
@@ -1218,7 +1223,7 @@ __global__ __launch_bounds__(256) void bn_finalize_all_kernel(BnAllArgs a) {
   if (hw <= 0.0f) return;                                  // not a layer of this pass (detection head)
   // layers above the deferral limit spread their sums over all JN_NREP replicas and had their table written by their own
   // (table-only) finalize launch; their saved statistics and running averages are formed here with everybody else's
-  const int nrep = (long long)a.N * (long long)hw > JN_DEFER_MAX_M ? JN_NREP : JN_NREP_DEFER;
+  const int nrep = (long long)a.N * (long long)hw > a.defer_max_m ? JN_NREP : JN_NREP_DEFER;
   const double count = (double)a.N * (double)hw;
   float sc, sh, mean, invstd; double var;
   bn_from_sums(a.stats, a.rep_stride, nrep, i, count, a.params[a.goff[i]], a.params[a.boff[i]], a.eps, sc, sh, mean, invstd, var);
@@ -1230,6 +1235,11 @@ __global__ __launch_bounds__(256) void bn_finalize_all_kernel(BnAllArgs a) {
   float* rm = a.run_mean[i]; float* rv = a.run_var[i];
   *rm = (1.0f - a.momentum) * *rm + a.momentum * mean;
   *rv = (1.0f - a.momentum) * *rv + a.momentum * (float)unbiased;
+}
+
+long long jn_defer_max_m() {
+  static const long long v = std::getenv("JN_DEFER_MAX_M") ? std::atoll(std::getenv("JN_DEFER_MAX_M")) : JN_DEFER_MAX_M;
+  return v;
 }
 
 int launch_bn_finalize_all(const BnAllArgs& a, hipStream_t s) {
