@@ -774,8 +774,6 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
   auto ld = [&](const View& v) { return net.bufs[v.buf].C; };
   auto finalize = [&](const Op& op, const ConvW& cw) {
     if (!train || !cw.has_bn || deferred(op)) return;
-    static const bool dbg_skip = std::getenv("JN_DBG_SKIP_FINALIZE") != nullptr;   // timing experiment only
-    if (dbg_skip) return;
     ChanTab t1{nullptr, nullptr, nullptr};
     if (op.alias.buf >= 0) t1 = tab(op.alias);
     // with the end-of-pass finalize (defer): table only here, saved / running statistics there

@@ -1428,7 +1428,7 @@ __global__ __launch_bounds__(256) void spp_bwd_kernel(const AT* __restrict__ cat
 
 int launch_spp_bwd(const void* cat, int dtype, float* gcat, int ld, int h, int H, int W, int N, ChanTab it,
                    hipStream_t s, const SlotBatch& sb) {
-  static const int cb0 = std::getenv("JN_SPPB_CB") ? std::atoi(std::getenv("JN_SPPB_CB")) : 8;   // 16: 1068 us, 8: 847 us, 4: 888 us (B = 64, 20 steps)
+  const int cb0 = 8;   // channels per workgroup, measured at B = 64, 20 steps: 16: 1068 us, 8: 847 us, 4: 888 us
   int cb = cb0;
   while (cb > 4 && (size_t)H * W * cb * 4 * sizeof(float) > 60 * 1024) cb >>= 1;
   dim3 grid(h / cb, N, sb.n);

@@ -590,9 +590,7 @@ int launch_dw(const ConvArgs& a, hipStream_t s) {
       // stride 2: 4-row tiles halve the LDS halo tile (9 x 33 pixels): twice the workgroups per CU
       // 32-channel blocks where the layer has them (round 3: a pixel of the halo tile is then a whole 128-byte line instead
       // of half of one, and the launch has half the workgroups): 112 -> 56 layer 45.3 -> 39.8 us, 56 -> 28 25.4 -> 21.9 us;
-      // JN_DW_S2_CB32=0 restores the 16-channel blocks
-      static const int cb32 = std::getenv("JN_DW_S2_CB32") ? std::atoi(std::getenv("JN_DW_S2_CB32")) : 1;
-      if (!bf && cb32 && a.cin % 32 == 0) launch_dw_lds<2, 32, 4, float>(a, s);
+      if (!bf && a.cin % 32 == 0) launch_dw_lds<2, 32, 4, float>(a, s);
       else if (bf) launch_dw_lds<2, 16, 4, bf16_t>(a, s); else launch_dw_lds<2, 16, 4, float>(a, s);
     }
     return 0;
@@ -916,7 +914,7 @@ template <int CT, int KC>
 static void launch_pw_narrow_t(const ConvArgs& a, long long M, hipStream_t s) {
   constexpr int BM = (CT % 2 == 0) ? 64 : 128;
   const long long n_tiles = (M + BM - 1) / BM;
-  static const int cap = std::getenv("JN_PWN_GRID") ? std::atoi(std::getenv("JN_PWN_GRID")) : 1536;
+  const int cap = 1536;      // persistent workgroups (swept in round 1)
   const unsigned gx = (unsigned)std::min<long long>(n_tiles, cap);
   dim3 grid(gx, (unsigned)((a.cout + 16 * CT - 1) / (16 * CT)));
   const size_t smem = (size_t)(BM + 16 * CT) * (KC + 4) * sizeof(float) + (BM / 32) * 32 * CT * sizeof(float);
@@ -1084,7 +1082,7 @@ __global__ __launch_bounds__(256) void spp_kernel(AT* __restrict__ cat, int ld, 
 int launch_spp(void* cat, int dtype, int ld, int h, int H, int W, int N, ChanTab it, const int* skip_flag,
                int skip_when, hipStream_t s) {
   // channels per block: 2 * HW * cb floats of LDS; 8 -> 1024 workgroups at B = 64 (measured 40.9 us with 32 or 16, 31.9 us with 8)
-  static const int cb0 = std::getenv("JN_SPP_CB") ? std::atoi(std::getenv("JN_SPP_CB")) : 8;
+  const int cb0 = 8;
   int cb = cb0 > 64 ? 64 : cb0;
   while (cb > 4 && (size_t)H * W * cb * 2 * sizeof(float) > 48 * 1024) cb >>= 1;
   dim3 grid(h / cb, N);

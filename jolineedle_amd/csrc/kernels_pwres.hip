@@ -289,8 +289,6 @@ static void launch_pw_dir_t(const ConvArgs& a, long long M, hipStream_t s) {
   // old round-up-to-8 rule gave 640 workgroups for 512 places: a second round at a quarter of the occupancy)
   long long gx = std::max<long long>(1, 256LL * per_cu / ((long long)ny * nz));
   if (nz == 1 && ny > 1) gx = std::max<long long>(8, gx / 8 * 8);
-  static const int gx_div = std::getenv("JN_PW_DIR_GXDIV") ? std::atoi(std::getenv("JN_PW_DIR_GXDIV")) : 1;   // tuning aid
-  if (gx_div > 1 && nz == 1) gx = std::max<long long>(8, gx / gx_div);
   gx = std::min<long long>(gx, (n_tiles + 3) / 4);
   dim3 grid((unsigned)gx, (unsigned)ny, (unsigned)nz);
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, (const float*)a.in, a.in_ld, a.itab, a.w, WT ? a.cout : a.cin,
@@ -319,18 +317,14 @@ int launch_pw_dir(const ConvArgs& a, int ctw, int split, hipStream_t s) {
   if (pw_dir_lds(ctw, K, split != 0) > 160 * 1024) return -1;
   const bool wt = a.w_transposed != 0;
   // data gradients (transposed weights) collect no statistics: without the two sum registers per tile a third step of
-  // prefetch fits the 256-VGPR budget (JN_PW_WT_PF=2: the forward's depth; 4: one more)
-  static const int wt_pf = std::getenv("JN_PW_WT_PF") ? std::atoi(std::getenv("JN_PW_WT_PF")) : 4;
-  if (wt && !split && !a.stats && wt_pf >= 3 && (ctw == 4 || ctw == 2)) {
+  // prefetch fits the 256-VGPR budget (depth 4: measured best of 2 / 3 / 4 in round 2)
+  if (wt && !split && !a.stats && (ctw == 4 || ctw == 2)) {
     // (gradient views carry the identity table: the transform — two transcendentals and half a dozen VALU ops per value,
     //  as long as the MFMAs of the step, tools/pwdirbench.hip — is compiled out)
-    static const bool keep_tf = std::getenv("JN_PW_WT_TF") != nullptr;
-    if (a.in_identity && !keep_tf) {
+    if (a.in_identity) {
       if (ctw == 4) launch_pw_dir_t<4, true, false, 4, false, false>(a, M, s); else launch_pw_dir_t<2, true, false, 4, false, false>(a, M, s);
-    } else if (wt_pf >= 4) {
-      if (ctw == 4) launch_pw_dir_t<4, true, false, 4, false>(a, M, s); else launch_pw_dir_t<2, true, false, 4, false>(a, M, s);
     } else {
-      if (ctw == 4) launch_pw_dir_t<4, true, false, 3, false>(a, M, s); else launch_pw_dir_t<2, true, false, 3, false>(a, M, s);
+      if (ctw == 4) launch_pw_dir_t<4, true, false, 4, false>(a, M, s); else launch_pw_dir_t<2, true, false, 4, false>(a, M, s);
     }
     return 0;
   }
@@ -354,8 +348,7 @@ int launch_pw_dir(const ConvArgs& a, int ctw, int split, hipStream_t s) {
 // Shapes the resident-weight kernel takes (everything else stays with pw_mfma_kernel / pw_narrow_kernel): fp32, no
 // bias / activation epilogue, K a multiple of 64 (32 for K = 32 * odd), at least 64 input and output channels.
 bool pw_res_supported(const ConvArgs& a) {
-  static const bool off = std::getenv("JN_NO_PW_RES") != nullptr;
-  if (off || a.bf16_mfma || a.in_dtype != JN_F32 || a.out_dtype != JN_F32 || a.bias || a.act != ACT_NONE) return false;
+  if (a.bf16_mfma || a.in_dtype != JN_F32 || a.out_dtype != JN_F32 || a.bias || a.act != ACT_NONE) return false;
   if (a.cin < 64 || a.cout < 64 || a.cin % 32 != 0 || a.cout % 4 != 0 || a.cin > 1024) return false;
   return true;
 }
@@ -373,10 +366,10 @@ int launch_pw_wide(const ConvArgs& a, hipStream_t s) {
   if (off || !pw_res_supported(a) || a.cin % 64 != 0) return -1;
   const long long M = (long long)a.N * a.H * a.W * (a.n_slots > 1 ? a.n_slots : 1);
   if (a.cin == 64 && a.cout == 64 && M < 65536) return -1;
-  // JN_PW_WT_SPLIT=1 (experiment): split products for the data gradients only — the backward is linear in g, a GEMM
-  // error of ~5e-6 travels up the chain without the amplification a forward perturbation gets from BatchNorm statistics
-  static const bool wt_split = std::getenv("JN_PW_WT_SPLIT") != nullptr;
-  return launch_pw_dir(a, 0, (!exact || (wt_split && a.w_transposed && a.in_identity)) ? 1 : 0, s);
+  // (split products for the data gradients only — the backward is linear in g, so a GEMM error of ~5e-6 travels up the
+  //  chain without the amplification a forward perturbation gets — were measured in round 2: 3.30 -> 3.27 ms per step,
+  //  not taken)
+  return launch_pw_dir(a, 0, exact ? 0 : 1, s);
 }
 
 }  // namespace jnr

@@ -60,7 +60,7 @@ int main() {
     b.w_transposed = 1; b.in_identity = std::getenv("TFON") ? 0 : 1; b.n_slots = S; b.in_slot_stride = M * sh.K; b.out_slot_stride = M * sh.N; b.tab_slot_stride = 0;
     printf("%2dx%2d K=%3d N=%3d |", sh.hw, sh.hw, sh.K, sh.N);
     for (int pf : {2, 3, 4}) {
-      char v[8]; snprintf(v, sizeof v, "%d", pf); setenv("JN_PW_WT_PF", v, 1);
+      char v[8]; snprintf(v, sizeof v, "%d", pf); setenv("JN_PW_WT_PF", v, 1);   // (round 3: the library fixed the depth at 4; the switch is gone)
       // (launch_pw_dir reads the variable once: the first value wins inside one process, so run one pf per process)
       if (pf != (std::getenv("PF") ? atoi(std::getenv("PF")) : 3)) continue;
       if (launch_pw_dir(b, 0, 0, s) != 0 || hipDeviceSynchronize() != hipSuccess) { printf(" bwd pf%d n/a", pf); continue; }
