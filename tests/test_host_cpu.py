@@ -277,3 +277,29 @@ def test_config_json_round_trip_and_infer_helpers(tmp_path):
     f = tmp_path / "boxes.txt"
     f.write_text("0 10 20 30 40\n1 5 6 7 8 0.9\n\n")
     assert ja.load_bboxes(f) == [[10, 20, 30, 40], [5, 6, 7, 8]]
+
+
+def test_supervised_compute_metrics_matches_the_reference_formula():
+    """SupervisedTrainer.compute_metrics (src/supervised.py:138-198) is host-side torch arithmetic: weighted cross-entropy
+    (weight[STOP] = stop_weight, reduction none) averaged over the non-padding tokens, accuracy over the same tokens, the
+    detector's terms added under yolo_*, episode_length = mean number of real tokens."""
+    from jolineedle_amd.supervised import SupervisedTrainer
+    g = torch.Generator().manual_seed(3)
+    B, T, nA = 3, 5, 9
+    logits = torch.randn((B, T, nA), generator=g, requires_grad=True)
+    actions = torch.randint(0, nA, (B, T), generator=g)
+    actions[0, 2] = 8
+    masks = torch.ones((B, T), dtype=torch.long); masks[1, 3:] = 0; masks[2, 1:] = 0
+    tr = SupervisedTrainer.__new__(SupervisedTrainer)
+    tr.config, tr.stop_weight = ja.CfgNode(stop_enabled=True), 0.25
+    m = tr.compute_metrics(logits, actions, masks, {"total_loss": torch.tensor(0.5), "iou_loss": 0.125})
+    w = torch.ones(nA); w[8] = 0.25
+    keep = masks.flatten() == 1
+    ce = torch.nn.functional.cross_entropy(logits.reshape(-1, nA), actions.flatten(), weight=w, reduction="none")[keep].mean()
+    assert torch.allclose(m["action_loss"], ce) and torch.allclose(m["loss"], ce + 0.5)
+    acc = (logits.reshape(-1, nA).argmax(1)[keep] == actions.flatten()[keep]).float().mean()
+    assert torch.allclose(m["action_accuracy"], acc)
+    assert float(m["episode_length"]) == float(masks.sum(1).float().mean())
+    assert float(m["yolo_iou_loss"]) == 0.125 and float(m["yolo_loss"]) == 0.5
+    m["loss"].backward()
+    assert logits.grad is not None and float(logits.grad[2, 1:].abs().max()) == 0.0      # padding tokens carry no gradient
