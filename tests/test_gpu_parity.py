@@ -518,12 +518,13 @@ class _UlpSiLU(torch.nn.Module):
         return y * (1.0 + self.eps * torch.randn(y.shape, generator=self.gen, dtype=y.dtype))
 
 
-def _conditioning_probe(oracle, run, ref64, samples=1, eps=1e-7, l2=False):
+def _conditioning_probe(oracle, run, ref64, samples=1, eps=1e-7, l2=False, both=False):
     """{tensor: relative distance from fp64} of the fp32 oracle with ~1-ulp noise (`eps`) on every SiLU output (see the bars
     above; the worst of `samples` noise draws — whether a given near-tie flips is a matter of chance).
-    `run(model)` performs forward + backward on the model it is given.  l2=True: relative-L2 distances instead of max-norm."""
+    `run(model)` performs forward + backward on the model it is given.  l2=True: relative-L2 distances instead of max-norm;
+    both=True: (max-norm dict, relative-L2 dict) of the same draws."""
     import copy
-    out = {}
+    out, out2 = {}, {}
     for k in range(samples):
         o = copy.deepcopy(oracle)
         gen = torch.Generator().manual_seed(1234 + k)
@@ -538,12 +539,11 @@ def _conditioning_probe(oracle, run, ref64, samples=1, eps=1e-7, l2=False):
         run(o)
         for n, p in o.named_parameters():
             if p.grad is not None and n in ref64:
-                if l2:
-                    d = (p.grad.double() - ref64[n]).norm().item() / max(ref64[n].norm().item(), 1e-30)
-                else:
-                    d = (p.grad.double() - ref64[n]).abs().max().item() / max(ref64[n].abs().max().item(), 1e-30)
-                out[n] = max(out.get(n, 0.0), d)
-    return out
+                d2 = (p.grad.double() - ref64[n]).norm().item() / max(ref64[n].norm().item(), 1e-30)
+                dm = (p.grad.double() - ref64[n]).abs().max().item() / max(ref64[n].abs().max().item(), 1e-30)
+                out[n] = max(out.get(n, 0.0), d2 if (l2 and not both) else dm)
+                out2[n] = max(out2.get(n, 0.0), d2)
+    return (out, out2) if both else out
 
 
 def _check_grads(grads, oracle, skip_prefix=("yolox",), tag="", ref64=None, probe=None, full_size=None, probe_l2=None):
@@ -663,15 +663,28 @@ def test_reinforce_iteration_at_the_headline_kernel_mix_vs_oracle():
     images, bboxes, start = synth_batch(B, 2, 2, P, seed=43)
     forced = torch.randint(0, 8, (B, Tn), generator=torch.Generator().manual_seed(3))
     assert 21 * 56 * 56 > 65536 >= B * 28 * 28            # the boundary sits where the headline batch has it
-    ro, m = _oracle_reinforce_grads(oracle, images, bboxes, start, forced, P, Tn, True, 0.25, 1.5, 0.01)
+    # 48 patches: every gradient passes through 48 * 196 decision pixels and 13 x 13 arg-max windows — the regime in which ONE
+    # flipped near-tie moves whole tensors (see the bars above).  Measured on the CPU oracle for this input: fp32 vs fp64
+    # median 9.5e-4 / worst 1.9e-3 relative L2; with one-ulp SiLU noise 2.2e-3 / 4.7e-3; with 1e-6 7.8e-3 / 1.1e-2.  The
+    # engine was at 1.1e-3 in three runs of round 3 and at 1.6e-2 after a change that only re-grouped fp32 partial sums (two
+    # forward evaluations that agree to 1e-5 on the maps).  So: fp64 reference, probes at 2e-6 (both norms), forward
+    # pinned separately (logits within 1e-4 of fp64); a kernel-path bug at these launch shapes is O(1), not 1e-2.
+    import copy
+    run = lambda o, dt=torch.float32: _oracle_reinforce_grads(o, images.to(dt), bboxes, start, forced, P, Tn, True, 0.25, 1.5, 0.01)
+    o64 = copy.deepcopy(oracle).double()
+    ro64, _ = run(o64, torch.float64)
+    ref64 = _grads64(o64)
+    probe, probe_l2 = _conditioning_probe(oracle, run, ref64, samples=1, eps=2e-6, both=True)
+    ro, m = run(oracle)
     tr = ja.ReinforceTrainer(_cfg(T=Tn, learning_rate=1e-3, gradient_accumulation=1), product)
     tr.last_return_mean, tr.last_return_std = 0.25, 1.5
     env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True)
     got_m = tr.train_iteration(env, forced_actions=forced, start_positions=start, optimizer_step=False)
-    assert (tr._last_train_buffers["logits"].cpu() - ro["logits"].detach()).abs().max() < 1e-3
+    assert (tr._last_train_buffers["logits"].cpu().double() - ro64["logits"].detach()).abs().max() < 1e-4
     for k in ("action_loss", "entropy_loss", "loss", "returns", "episode_length"):
         assert abs(float(got_m[k]) - float(m[k].detach())) < 2e-4, (k, float(got_m[k]), float(m[k].detach()))
-    assert _check_grads(product.engine_grads(), oracle, tag=f"reinforce headline mix B={B} P={P} T={Tn}", full_size=True) > 150
+    assert _check_grads(product.engine_grads(), oracle, tag=f"reinforce headline mix B={B} P={P} T={Tn}", ref64=ref64, probe=probe,
+                        probe_l2=probe_l2) > 150
     # train-mode maps of the start patches (batch statistics over the 24 patches), all three FPN levels
     y0, x0 = start[:, 0], start[:, 1]
     patches0 = torch.stack([images[b, :, y0[b] * P:(y0[b] + 1) * P, x0[b] * P:(x0[b] + 1) * P] for b in range(B)])
@@ -756,8 +769,7 @@ def test_config5_training_at_its_patch_size_vs_oracle():
     # The dense 3x3 layers of yolox-s accumulate up to 4 608 products per output in fp32 MFMA order: the engine lands where
     # the oracle lands with eps ~ 3e-6 (its logits stay within 1e-4 of fp64, asserted below; the oracle's move by 4.5e-5 at
     # eps = 1e-6 and 4.4e-4 at 1e-5).  Probe at 4e-6, both norms.
-    probe = _conditioning_probe(oracle, run, ref64, samples=1, eps=4e-6)
-    probe_l2 = _conditioning_probe(oracle, run, ref64, samples=1, eps=4e-6, l2=True)
+    probe, probe_l2 = _conditioning_probe(oracle, run, ref64, samples=1, eps=4e-6, both=True)
     ro, m = run(oracle)
     tr = ja.ReinforceTrainer(_cfg(T=Tn, learning_rate=1e-3, gradient_accumulation=1), product)
     tr.last_return_mean, tr.last_return_std = 0.25, 1.5
@@ -1352,9 +1364,8 @@ def test_supervised_step_vs_oracle(B, T, P, stop_w):
         o64 = copy.deepcopy(oracle).double()
         logits64, _ = run_oracle(o64, torch.float64)
         ref64 = _grads64(o64)
-        probe = _conditioning_probe(oracle, lambda o: run_oracle(o, torch.float32), ref64, samples=3)
         # (relative L2 of the same three one-ulp draws: 4.8e-3 on the worst deep-FPN tensor when a 13 x 13 arg-max flips)
-        probe_l2 = _conditioning_probe(oracle, lambda o: run_oracle(o, torch.float32), ref64, samples=3, l2=True)
+        probe, probe_l2 = _conditioning_probe(oracle, lambda o: run_oracle(o, torch.float32), ref64, samples=3, both=True)
     logits, loss = run_oracle(oracle, torch.float32)
     acc = (logits.reshape(B * T, 9).argmax(1)[keep] == nxt.flatten()[keep]).float().mean()
     cfg = ja.CfgNode(stop_enabled=True, stop_weight=stop_w, learning_rate=1e-3, gradient_accumulation=1)
