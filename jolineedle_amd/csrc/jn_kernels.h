@@ -89,6 +89,7 @@ struct ConvArgs {
   const int* skip_flag; int skip_when;
   int n_slots;                           // pw: gridDim.z slots, pointers advance by the strides below (0 -> 1 slot)
   long long in_slot_stride, out_slot_stride, tab_slot_stride;
+  const void* w_x3;                      // 1x1, fp32: the weights split into three bf16 planes (launch_w_split3), or null
 };
 
 // eval-mode DWConv (depthwise 3x3 -> BN + SiLU -> pointwise 1x1) in one kernel; mtab = table of the depthwise output
@@ -109,6 +110,8 @@ int launch_pw_dir(const ConvArgs& a, int ctw, int split, hipStream_t s);
 int launch_pw_wide(const ConvArgs& a, hipStream_t s);   // production route: 0 when taken
 bool pw_xs_supported(const ConvArgs& a);               // kernels_pwxs.hip: pixel-stationary kernel for the small maps of a forward pass
 int launch_pw_xs(const ConvArgs& a, int pt, hipStream_t s, int wg_per_cu = 0);   // pt: pixel tiles per workgroup (0 = default)
+int launch_pw_x3(const ConvArgs& a, int pt, hipStream_t s, int wg_per_cu = 0);   // the same on the bf16 pipe (three-way split operands); needs a.w_x3
+void launch_w_split3(const float* w, void* w3, long long n_floats, hipStream_t s);   // w3: 6 bytes per weight
 int launch_spp(void* cat, int dtype, int ld, int h, int H, int W, int N, ChanTab it, const int* skip_flag,
                int skip_when, hipStream_t s);
 int launch_upsample(const void* in, int in_ld, void* out, int out_ld, int dtype, int C, int H, int W, int N,

@@ -242,4 +242,226 @@ int launch_pw_xs(const ConvArgs& a, int pt, hipStream_t s, int wg_per_cu) {
   return -1;
 }
 
+
+// ---- the same kernel on the bf16 matrix pipe at fp32 accuracy: "x3" -------------------------------------------------
+// gfx950 has no reduced-precision fast path for fp32 operands: v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 rate, and
+// on these shapes its 32-cycle instructions are HALF of the kernel's time (tools/pwxsbench.hip prints the floor).  An
+// fp32 value is exactly the sum of three bf16 values (8 + 8 + 8 significand bits: h = bf16(v), m = bf16(v - h),
+// l = bf16(v - h - m)), so  x * w = (xh + xm + xl)(wh + wm + wl); the three products with |.| <= 2^-25 |x w| (m*l, l*m,
+// l*l) are dropped and the other six run on v_mfma_f32_16x16x32_bf16 into the same fp32 accumulator: 6 x 16 cycles per
+// 32 k instead of 8 x 32.  The error against an fp64 sum is that of the fp32 fmaf chain (measured, pwxsbench).
+//   * the operand tile is split where it is transformed (once per element) and staged as three bf16 planes;
+//   * the weights are split once per pass for the whole parameter arena (w_split3_kernel): groups of 8 consecutive
+//     elements as [h x 8 | m x 8 | l x 8], i.e. the 48 bytes lane (row, g) needs for one 32-wide k step.
+__global__ __launch_bounds__(256) void w_split3_kernel(const float* __restrict__ w, bf16_t* __restrict__ w3, long long n8) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(w + 8 * i), b = *reinterpret_cast<const f32x4*>(w + 8 * i + 4);
+  bf16x8 h, m, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = e < 4 ? a[e] : b[e - 4];
+    const bf16_t vh = (bf16_t)v;
+    const float r1 = v - (float)vh;
+    const bf16_t vm = (bf16_t)r1;
+    const float r2 = r1 - (float)vm;
+    h[e] = vh; m[e] = vm; l[e] = (bf16_t)r2;
+  }
+  bf16x8* o = reinterpret_cast<bf16x8*>(w3 + 24 * i);
+  o[0] = h; o[1] = m; o[2] = l;
+}
+
+void launch_w_split3(const float* w, void* w3, long long n_floats, hipStream_t s) {
+  const long long n8 = n_floats / 8;
+  if (n8 <= 0) return;
+  hipLaunchKernelGGL(w_split3_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, w, (bf16_t*)w3, n8);
+}
+
+template <int K, int CTW, int PT, int D>
+__global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_kernel(
+    const float* __restrict__ x, int x_ld, ChanTab it, const bf16_t* __restrict__ w3, float* __restrict__ out, int out_ld,
+    long long M, double* __restrict__ stats, long long rep_stride, int nrep, const int* __restrict__ skip_flag,
+    int skip_when) {
+  if (skip_flag && *skip_flag >= skip_when) return;
+  constexpr int BM = 16 * PT, LDK = K + 8, KQ = K / 4, NJ = K / 32, N = 64 * CTW;
+  constexpr int NX = BM * KQ / 256;
+  constexpr int NXB = NX < 16 ? NX : 16;
+  static_assert(256 % KQ == 0 && NX >= 1 && NX % NXB == 0 && NJ % D == 0, "pw_x3 tile mapping");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Xp = reinterpret_cast<bf16_t*>(smem_raw);    // [3][BM][LDK]: h, m, l planes of the transformed operand
+  float* Tb = reinterpret_cast<float*>(Xp + 3 * BM * LDK);       // [3][K], later [N][2] statistics
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, g = lane >> 4;
+  const long long n_tiles = (M + BM - 1) / BM;
+
+  // weight fragments of k step j, channel tile c: 3 x bf16x8 at wrow[c] + 96 j (elements)
+  const bf16_t* wrow[CTW];
+#pragma unroll
+  for (int c = 0; c < CTW; ++c) wrow[c] = w3 + ((long long)((wave * CTW + c) * 16 + lm) * (K / 8) + g) * 24;
+  bf16x8 wr[D][CTW][3];
+#pragma unroll
+  for (int u = 0; u < D; ++u)
+#pragma unroll
+    for (int c = 0; c < CTW; ++c)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) wr[u][c][t] = *reinterpret_cast<const bf16x8*>(wrow[c] + 96 * u + 8 * t);
+
+  const int q = tid % KQ, r0 = tid / KQ;
+  constexpr int RS = 256 / KQ;
+  f32x4 xr[NXB];
+  auto fetch = [&](long long m0, int b) {
+#pragma unroll
+    for (int u = 0; u < NXB; ++u) {
+      long long m = m0 + r0 + (long long)(b * NXB + u) * RS;
+      m = m < M ? m : M - 1;
+      xr[u] = *reinterpret_cast<const f32x4*>(x + m * x_ld + 4 * q);
+    }
+  };
+  long long tile = blockIdx.x;
+  fetch(tile * BM, 0);
+  tab_to_lds(Tb, K, K, it, tid, 256);
+  __syncthreads();
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(Tb + 4 * q), sh = *reinterpret_cast<const f32x4*>(Tb + K + 4 * q),
+              fl = *reinterpret_cast<const f32x4*>(Tb + 2 * K + 4 * q);
+  f32x4 s1[CTW], s2[CTW];
+#pragma unroll
+  for (int c = 0; c < CTW; ++c) { s1[c] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[c] = s1[c]; }
+
+#pragma unroll 1
+  for (; tile < n_tiles; tile += gridDim.x) {
+    const long long m0 = tile * BM;
+#pragma unroll
+    for (int b = 0; b < NX / NXB; ++b) {
+      if (b > 0) fetch(m0, b);
+#pragma unroll
+      for (int u = 0; u < NXB; ++u) {
+        const int r = r0 + (b * NXB + u) * RS;
+        f32x4 v = tf4_tab(xr[u], sc, sh, fl);
+        if (m0 + r >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bf16x4 vh = __builtin_convertvector(v, bf16x4);
+        const f32x4 r1 = v - __builtin_convertvector(vh, f32x4);
+        const bf16x4 vm = __builtin_convertvector(r1, bf16x4);
+        const f32x4 r2 = r1 - __builtin_convertvector(vm, f32x4);
+        const bf16x4 vl = __builtin_convertvector(r2, bf16x4);
+        bf16_t* dst = Xp + r * LDK + 4 * q;
+        *reinterpret_cast<bf16x4*>(dst) = vh;
+        *reinterpret_cast<bf16x4*>(dst + BM * LDK) = vm;
+        *reinterpret_cast<bf16x4*>(dst + 2 * BM * LDK) = vl;
+      }
+    }
+    __syncthreads();
+    if (tile + gridDim.x < n_tiles) fetch((tile + gridDim.x) * BM, 0);
+
+    f32x4 acc[CTW][PT];
+#pragma unroll
+    for (int c = 0; c < CTW; ++c)
+#pragma unroll
+      for (int p = 0; p < PT; ++p) acc[c][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16_t* xrow = Xp + lm * LDK + 8 * g;
+#pragma unroll 1
+    for (int j0 = 0; j0 < NJ; j0 += D) {
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        const int j = j0 + u;
+        bf16x8 xa[PT][3], wa[CTW][3];
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) xa[p][t] = *reinterpret_cast<const bf16x8*>(xrow + t * BM * LDK + p * 16 * LDK + 32 * j);
+#pragma unroll
+        for (int c = 0; c < CTW; ++c)
+#pragma unroll
+          for (int t = 0; t < 3; ++t) wa[c][t] = wr[u][c][t];
+        if constexpr (D < NJ) {
+          const int jn = j + D < NJ ? j + D : j + D - NJ;
+#pragma unroll
+          for (int c = 0; c < CTW; ++c)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) wr[u][c][t] = *reinterpret_cast<const bf16x8*>(wrow[c] + 96 * jn + 8 * t);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // six products, the small ones first: (w, x) = (l, h) (h, l) (m, m) (m, h) (h, m) (h, h)
+        constexpr int TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int e = 0; e < 6; ++e)
+#pragma unroll
+          for (int c = 0; c < CTW; ++c)
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+              acc[c][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[c][TW[e]], xa[p][TX[e]], acc[c][p], 0, 0, 0);
+      }
+    }
+
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+      const int n = (wave * CTW + c) * 16 + 4 * g;
+#pragma unroll
+      for (int p = 0; p < PT; ++p) {
+        const long long m = m0 + 16 * p + lm;
+        const f32x4 v = acc[c][p];
+        if (m < M) *reinterpret_cast<f32x4*>(out + m * out_ld + n) = v;
+        s1[c] += v; s2[c] += v * v;
+      }
+    }
+    __syncthreads();
+  }
+
+  if (stats) {
+    float* red = Tb;
+    if constexpr (3 * K < 2 * N) red = reinterpret_cast<float*>(Xp);
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+      const int n = (wave * CTW + c) * 16 + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = row16_sum(s1[c][r]);
+        const float b = row16_sum(s2[c][r]);
+        if (lm == 0) { red[2 * (n + r)] = a; red[2 * (n + r) + 1] = b; }
+      }
+    }
+    __syncthreads();
+    double* st = stats + (blockIdx.x % nrep) * rep_stride;
+    for (int i = tid; i < 2 * N; i += 256) atomicAdd(st + i, (double)red[i]);
+  }
+}
+
+template <int K, int CTW, int PT, int D>
+static void launch_pw_x3_t(const ConvArgs& a, long long M, int wg_per_cu, hipStream_t s) {
+  constexpr int BM = 16 * PT;
+  const size_t smem = (size_t)3 * BM * (K + 8) * sizeof(bf16_t) + 3 * K * sizeof(float);
+  auto kern = pw_x3_kernel<K, CTW, PT, D>;
+  static int places = 0;
+  if (!places) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+    places = per_cu;
+  }
+  const long long n_tiles = (M + BM - 1) / BM;
+  const int per_cu = std::max(1, std::min(places, wg_per_cu > 0 ? wg_per_cu : 2));
+  const long long gx = std::min<long long>(n_tiles, 256LL * per_cu);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), smem, s, (const float*)a.in, a.in_ld, a.itab, (const bf16_t*)a.w_x3,
+                     (float*)a.out, a.out_ld, M, a.stats, a.stats_rep_stride, a.stats_nrep > 0 ? a.stats_nrep : JN_NREP,
+                     a.skip_flag, a.skip_when);
+}
+
+int launch_pw_x3(const ConvArgs& a, int pt, hipStream_t s, int wg_per_cu) {
+  if (!pw_xs_supported(a) || !a.w_x3) return -1;
+  const long long M = (long long)a.N * a.H * a.W;
+  const int K = a.cin, ctw = a.cout / 64;
+  if (pt == 0) { pt = 2; if (wg_per_cu == 0) wg_per_cu = K == 512 ? 1 : 2; }
+  if (K == 512) pt = 2;                                 // three planes of 64 x 520 bf16 do not fit the LDS
+#define JN_X3(K_, C_, D_)                                                          \
+  if (K == K_ && ctw == C_) {                                                      \
+    if (pt == 4) launch_pw_x3_t<K_, C_, 4, D_>(a, M, wg_per_cu, s); else launch_pw_x3_t<K_, C_, 2, D_>(a, M, wg_per_cu, s); \
+    return 0;                                                                      \
+  }
+  JN_X3(64, 1, 2) JN_X3(64, 2, 2)
+  JN_X3(128, 1, 4) JN_X3(128, 2, 4) JN_X3(128, 4, 2)
+  JN_X3(256, 2, 2) JN_X3(256, 4, 2)
+  if (K == 512 && ctw == 4) { launch_pw_x3_t<512, 4, 2, 2>(a, M, wg_per_cu, s); return 0; }
+#undef JN_X3
+  return -1;
+}
+
 }  // namespace jnr

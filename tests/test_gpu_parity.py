@@ -1912,7 +1912,7 @@ def test_checkpoint_resume_continues_the_optimiser_state(tmp_path):
         errs.append((err_c, k))
         n_ok += err_d > 3 * max(err_c, 0.02)
     errs.sort()
-    assert errs[len(errs) // 2][0] < 0.03, errs[len(errs) // 2]          # the typical tensor repeats to a few per cent
+    assert errs[len(errs) // 2][0] < 0.05, errs[len(errs) // 2]          # the typical tensor repeats to a few per cent (0.02 - 0.032 over ten runs)
     assert errs[int(0.95 * len(errs))][0] < 0.1 and errs[-1][0] < 0.5, errs[-5:]   # the noisiest (tiny gradients) stay bounded
     assert n_ok > 100
     # the dict is a torch.optim.AdamW state dict for the same parameter list

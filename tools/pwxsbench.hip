@@ -32,15 +32,16 @@ int main(int argc, char** argv) {
   const Shape shapes[] = {{28, 64, 64}, {28, 64, 128}, {28, 128, 64}, {28, 128, 128}, {28, 256, 128}, {14, 128, 128}, {14, 128, 256},
                           {14, 256, 128}, {14, 256, 256}, {14, 512, 256}, {56, 64, 64}, {56, 128, 64}};
   const int B = 64, iters = 50;
-  float *x, *w, *out, *out2, *tab, *params; double *stats, *dstats;
+  float *x, *w, *out, *out2, *tab, *params; double *stats, *dstats; void* w3;
   const size_t maxx = (size_t)B * 56 * 56 * 128 + (size_t)B * 14 * 14 * 512, maxo = (size_t)B * 56 * 56 * 64 + (size_t)B * 28 * 28 * 256;
-  CK(hipMalloc(&x, maxx * 4)); CK(hipMalloc(&out, maxo * 4)); CK(hipMalloc(&out2, maxo * 4)); CK(hipMalloc(&w, 512 * 512 * 4));
+  CK(hipMalloc(&x, maxx * 4)); CK(hipMalloc(&out, maxo * 4)); CK(hipMalloc(&out2, maxo * 4)); CK(hipMalloc(&w, 512 * 512 * 4)); CK(hipMalloc(&w3, 512 * 512 * 6));
   CK(hipMalloc(&tab, 3 * 2048 * 4)); CK(hipMalloc(&params, 4096 * 4));
   CK(hipMalloc(&stats, 32 * 2 * 4096 * 8)); CK(hipMalloc(&dstats, 8 * 2 * 4096 * 8));
   std::vector<float> h(maxx);
   for (size_t i = 0; i < maxx; ++i) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.0f - 0.5f;
   CK(hipMemcpy(x, h.data(), maxx * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(w, h.data(), 512 * 512 * 4, hipMemcpyHostToDevice));
+  launch_w_split3(w, w3, 512 * 512, nullptr); CK(hipDeviceSynchronize());
   std::vector<float> t(3 * 2048, 0.0f);
   for (int i = 0; i < 2048; ++i) { t[i] = 1.0f + 0.001f * (i % 7); t[2048 + i] = 0.01f * (i % 5); t[4096 + i] = 1.0f; }
   CK(hipMemcpy(tab, t.data(), t.size() * 4, hipMemcpyHostToDevice));
@@ -81,7 +82,7 @@ int main(int argc, char** argv) {
     ConvArgs a{};
     a.in = x; a.in_ld = sh.K; a.in_dtype = JN_F32; a.itab = plain; a.w = w; a.out = out; a.out_ld = sh.N;
     a.out_dtype = JN_F32; a.N = B; a.H = sh.hw; a.W = sh.hw; a.OH = sh.hw; a.OW = sh.hw; a.cin = sh.K; a.cout = sh.N; a.stride = 1;
-    a.act = ACT_NONE; a.stats = stats; a.stats_rep_stride = 2 * 4096; a.stats_nrep = 8;
+    a.w_x3 = w3; a.act = ACT_NONE; a.stats = stats; a.stats_rep_stride = 2 * 4096; a.stats_nrep = 8;
     const double mb = (double)M * (sh.K + sh.N) * 4 / 1e6, gf = 2.0 * M * sh.K * sh.N / 1e9;
     printf("%2dx%2d K=%3d N=%3d %6.1f MB %5.2f GF (fp32 MFMA floor %5.1f us)", sh.hw, sh.hw, sh.K, sh.N, mb, gf, gf / 122.0 * 1e3);
     for (int dt = 0; dt < 2; ++dt) {
@@ -97,6 +98,15 @@ int main(int argc, char** argv) {
           hipError_t e = hipDeviceSynchronize();
           if (e != hipSuccess) { printf(" xs%d %s\n", pt, hipGetErrorString(e)); return 1; }
           printf(" xs%d/%d %5.1f", pt, wg, time_it([&] { launch_pw_xs(a, pt, s, wg); }));
+        }
+      for (int pt : {2, 4})
+        for (int wg : {1, 2, 3}) {
+          if (dt == 0 && wg != 2) continue;
+          if (sh.K == 512 && pt == 4) continue;
+          if (launch_pw_x3(a, pt, s, wg) != 0) { printf(" x3 n/a"); continue; }
+          hipError_t e = hipDeviceSynchronize();
+          if (e != hipSuccess) { printf(" x3_%d %s\n", pt, hipGetErrorString(e)); return 1; }
+          printf(" x3_%d/%d %5.1f", pt, wg, time_it([&] { launch_pw_x3(a, pt, s, wg); }));
         }
     }
     // correctness: outputs bit for bit against pw_mfma_kernel (deferred table), statistics to fp64 rounding
@@ -122,6 +132,36 @@ int main(int argc, char** argv) {
         sd = std::max(sd, std::fabs(ar - ag)); sm = std::max(sm, std::fabs(ar));
       }
       printf(" | xs%d err %.1e stats %.1e/%.1e", pt, md, sd, sm);
+    }
+    // accuracy of both pipes against an fp64 sum of the SAME transformed operand (plain table: T is the identity flag 1 ->
+    // silu(sc z + sh) computed on the host in fp64 from the fp32 inputs): 4096 sampled outputs
+    {
+      a.itab = plain;
+      std::vector<float> o32((size_t)M * sh.N), o3((size_t)M * sh.N);
+      ConvArgs b = a; b.stats = nullptr;
+      b.out = out; launch_pw_xs(b, 0, s); CK(hipDeviceSynchronize());
+      CK(hipMemcpy(o32.data(), out, o32.size() * 4, hipMemcpyDeviceToHost));
+      b.out = out2; CK(hipMemset(out2, 0, o3.size() * 4));
+      if (launch_pw_x3(b, 0, s) == 0) {
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(o3.data(), out2, o3.size() * 4, hipMemcpyDeviceToHost));
+        double e32 = 0, e3 = 0, d = 0, nrm = 0; 
+        for (int smp = 0; smp < 4096; ++smp) {
+          const long long m = ((long long)smp * 2654435761LL) % M; const int n = (smp * 37) % sh.N;
+          double ref = 0, absum = 0;
+          for (int k = 0; k < sh.K; ++k) {
+            // the kernel's own fp32 transform, so that only the contraction differs
+            const float zf = h[(size_t)m * sh.K + k];
+            const float y = fmaf(zf, t[k], t[2048 + k]);
+            const float av = y * (1.0f / (1.0f + expf(-y)));
+            ref += (double)av * (double)h[(size_t)n * sh.K + k]; absum += std::fabs((double)av * (double)h[(size_t)n * sh.K + k]);
+          }
+          e32 = std::max(e32, std::fabs(o32[(size_t)m * sh.N + n] - ref) / absum);
+          e3 = std::max(e3, std::fabs(o3[(size_t)m * sh.N + n] - ref) / absum);
+          d = std::max(d, std::fabs((double)o3[(size_t)m * sh.N + n] - o32[(size_t)m * sh.N + n]) / absum); nrm += 1;
+        }
+        printf(" | vs fp64 / sum|ab|: fp32 pipe %.1e, x3 %.1e, x3 - fp32 %.1e", e32, e3, d);
+      }
     }
     printf("\n");
     fflush(stdout);
