@@ -74,6 +74,9 @@ int store_param(jn_ctx* ctx, const std::string& name, const std::vector<float>& 
   auto it = ctx->seg_index.find(name);
   if (it == ctx->seg_index.end()) {
     const size_t padded = (packed.size() + 3) / 4 * 4;
+    // tensors of 64 values and more start on a multiple of 8 floats (pw_x3_kernel's split weights come in groups of 8; the
+    // small ones — predictor rows and biases — stay back to back, the head kernels read them as one matrix)
+    if (packed.size() >= 64) ctx->arena_used = (ctx->arena_used + 7) / 8 * 8;
     JN_CHECK(ctx->params && ctx->arena_used + padded <= ctx->arena_size, JN_ENOMEM, "parameter arena exhausted at '%s'",
              name.c_str());
     ParamSeg sg;
@@ -517,11 +520,12 @@ int jn_load_weights(jn_ctx* ctx, const jn_tensor* tensors, size_t n) {
       if (e.info.dtype != 0 || e.info.is_buffer || !e.info.used) continue;
       size_t n = 1;
       for (int i = 0; i < e.info.ndim; ++i) n *= (size_t)e.info.shape[i];
-      total += (n + 3) / 4 * 4;
+      total += (n + 3) / 4 * 4 + (n >= 64 ? 4 : 0);
     }
     ctx->arena_size = total;
     if ((rc = dev_alloc(ctx, &ctx->params, total))) return rc;
     JN_HIP(hipMemset(ctx->params, 0, total * sizeof(float)));
+    if ((rc = dev_alloc(ctx, &ctx->params_x3, 3 * total))) return rc;
   }
   const jn_config& c = ctx->cfg;
   const int C = c.n_embd, nA = c.n_actions;
@@ -725,6 +729,24 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
   // between makes that state stale (the backward entry points then fail with JN_ESTATE instead of computing garbage)
   if (ni == ctx->enc_net) { if (slot == 0) ctx->sup_valid = false; else ctx->train_out_valid = false; }
   if (!train && (rc = refresh_eval_table(ctx, net, s))) return rc;
+  // fp32 passes: the 1x1 weights of this net as three bf16 planes for pw_x3_kernel, from the CURRENT parameters (one
+  // launch over the net's slice of the arena, ~4 us: cheaper and safer than tracking every writer of the arena)
+  const bool x3 = net.act_dtype == JN_F32 && ctx->params_x3 && !std::getenv("JN_NO_PW_X3");   // read per pass: tests flip it
+  if (x3) {
+    if (net.x3_hi == 0) {
+      size_t lo = ctx->arena_size, hi = 0;
+      for (const Op& op : net.ops) {
+        if (op.kind != OP_PW || op.wslot < 0) continue;
+        const ConvW& cw = net.convs[op.wslot];
+        if (!cw.w_dev) continue;
+        const size_t o = (size_t)(cw.w_dev - ctx->params);
+        lo = std::min(lo, o); hi = std::max(hi, o + (size_t)cw.cout * cw.cin);
+      }
+      net.x3_lo = lo / 8 * 8; net.x3_hi = hi > lo ? (hi + 7) / 8 * 8 : 0;
+    }
+    if (net.x3_hi > net.x3_lo)
+      launch_w_split3(ctx->params + net.x3_lo, ctx->params_x3 + 3 * net.x3_lo, (long long)(net.x3_hi - net.x3_lo), s);
+  }
   double* stats = train ? slot_stats(net, slot) : nullptr;
   float* save = train ? slot_save(net, slot) : nullptr;
   // (a train-mode rollout zeroes the statistics of all its slots with ONE memset up front)
@@ -835,6 +857,7 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
         ConvArgs a{};
         a.in = ptr(op.in); a.in_ld = ld(op.in); a.in_dtype = net.act_dtype; a.itab = tab(op.in); a.w = cw.w_dev;
         a.w_bf16 = cw.w_bf16;
+        if (x3 && op.kind == OP_PW && (cw.w_dev - ctx->params) % 8 == 0) a.w_x3 = ctx->params_x3 + 3 * (cw.w_dev - ctx->params);
         a.bias = cw.b_dev; a.out = ptr(op.out); a.out_ld = ld(op.out); a.out_dtype = net.act_dtype;
         a.bf16_mfma = net.act_dtype == JN_BF16;
         a.N = N; a.H = op.in.H; a.W = op.in.W; a.OH = op.out.H; a.OW = op.out.W;

@@ -99,6 +99,7 @@ struct Net {
   std::vector<ConvW> convs;
   View fpn[3];              // pan_out2, pan_out1, pan_out0
   int n_backbone_ops = -1;  // ops before the detection head (-1: no head, all ops)
+  size_t x3_lo = 0, x3_hi = 0;   // arena range of the 1x1 weights (multiples of 8 floats; hi == 0: not computed yet)
   int n_anchors = 0, head_hid = 0;
   float* pred_w[3] = {nullptr, nullptr, nullptr};   // [6][hid] reg(4), obj, cls predictor rows
   float* pred_b[3] = {nullptr, nullptr, nullptr};   // [6]
@@ -174,6 +175,7 @@ struct jn_ctx {
   const std::vector<jnr::ParamEntry>& params_table() const { return params_tab; }
   // flat trainable-parameter arena + gradient / AdamW mirrors
   float* params = nullptr; float* grads = nullptr; float* adam_m = nullptr; float* adam_v = nullptr;
+  uint16_t* params_x3 = nullptr;   // 3 bf16 per arena float: the 1x1 weights split for pw_x3_kernel (refreshed at the start of every fp32 pass)
   size_t arena_size = 0, arena_used = 0, gpt_arena_end = 0;   // [0, gpt_arena_end) = optim_gpt parameters
   int adam_step = 0, adam_step_yolox = 0;
   bool freeze_det_backbone = false;   // --freeze-image-processor: yolox.backbone.* keep their values (src/models/gpt.py:264-268)

@@ -445,21 +445,31 @@ static void launch_pw_x3_t(const ConvArgs& a, long long M, int wg_per_cu, hipStr
                      a.skip_flag, a.skip_when);
 }
 
+// Shapes the x3 kernel is built for — the ones where it beats pw_xs_kernel (tools/pwxsbench.hip, profiles/r03_x3bench.txt:
+// 8 - 21 %); with K >= 256 the weight fragments are streamed per tile and their 1.5x bytes cost more than the matrix
+// cycles saved, except for 256 -> 256 on 64-pixel tiles.
+bool pw_x3_preferred(const ConvArgs& a) {
+  if (!a.w_x3 || !pw_xs_supported(a)) return false;
+  const int K = a.cin, N = a.cout;
+  return (K == 64 && (N == 64 || N == 128)) || (K == 128 && (N == 64 || N == 128)) || (K == 256 && N == 256);
+}
+
 int launch_pw_x3(const ConvArgs& a, int pt, hipStream_t s, int wg_per_cu) {
   if (!pw_xs_supported(a) || !a.w_x3) return -1;
   const long long M = (long long)a.N * a.H * a.W;
   const int K = a.cin, ctw = a.cout / 64;
-  if (pt == 0) { pt = 2; if (wg_per_cu == 0) wg_per_cu = K == 512 ? 1 : 2; }
-  if (K == 512) pt = 2;                                 // three planes of 64 x 520 bf16 do not fit the LDS
-#define JN_X3(K_, C_, D_)                                                          \
-  if (K == K_ && ctw == C_) {                                                      \
-    if (pt == 4) launch_pw_x3_t<K_, C_, 4, D_>(a, M, wg_per_cu, s); else launch_pw_x3_t<K_, C_, 2, D_>(a, M, wg_per_cu, s); \
-    return 0;                                                                      \
+  if (pt == 0) {
+    // measured best per shape: 32-pixel tiles, two persistent workgroups per CU (one when there is at most a tile or two
+    // per workgroup anyway, or for 64 -> 128); 256 -> 256: 64-pixel tiles halve the weight stream
+    pt = K == 256 ? 4 : 2;
+    if (wg_per_cu == 0) wg_per_cu = (K == 256 || (K == 64 && ctw == 2) || (K == 128 && ctw == 2 && M <= 16384)) ? 1 : 2;
   }
-  JN_X3(64, 1, 2) JN_X3(64, 2, 2)
-  JN_X3(128, 1, 4) JN_X3(128, 2, 4) JN_X3(128, 4, 2)
-  JN_X3(256, 2, 2) JN_X3(256, 4, 2)
-  if (K == 512 && ctw == 4) { launch_pw_x3_t<512, 4, 2, 2>(a, M, wg_per_cu, s); return 0; }
+#define JN_X3(K_, C_, P_, D_) if (K == K_ && ctw == C_ && pt == P_) { launch_pw_x3_t<K_, C_, P_, D_>(a, M, wg_per_cu, s); return 0; }
+  JN_X3(64, 1, 2, 2) JN_X3(64, 2, 2, 2) JN_X3(128, 1, 2, 4) JN_X3(128, 2, 2, 4) JN_X3(256, 4, 4, 2)
+#ifdef JN_X3_ALL_SHAPES        // tools/pwxsbench.hip: every shape and tile size, to show where the kernel loses
+  JN_X3(64, 1, 4, 2) JN_X3(64, 2, 4, 2) JN_X3(128, 1, 4, 4) JN_X3(128, 2, 4, 4) JN_X3(128, 4, 2, 2) JN_X3(128, 4, 4, 2)
+  JN_X3(256, 2, 2, 2) JN_X3(256, 2, 4, 2) JN_X3(256, 4, 2, 2) JN_X3(512, 4, 2, 2)
+#endif
 #undef JN_X3
   return -1;
 }

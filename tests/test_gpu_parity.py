@@ -1,5 +1,6 @@
 """Parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the
 golden vectors.  Run on the MI355X box: python -m pytest tests -m gpu."""
+import copy
 import sys
 from pathlib import Path
 
@@ -713,6 +714,30 @@ def test_train_mode_backbone_pass_at_the_headline_batch_vs_oracle():
     for k in ("gpt_backbone.C3_n4.conv3.bn.running_var", "gpt_backbone.backbone.dark4.1.conv3.bn.running_mean",
               "gpt_backbone.backbone.dark2.0.pconv.bn.running_mean"):
         assert torch.allclose(product.state_dict()[k].cpu(), oracle.state_dict()[k], atol=1e-5, rtol=1e-3), k
+
+
+def test_three_way_split_1x1_kernels_are_as_accurate_as_the_fp32_matrix_pipe(monkeypatch):
+    """Round 3: the small-map 1x1 layers run on the bf16 matrix pipe with every fp32 operand split into three bf16 values
+    (pw_x3_kernel: six products per pair, the three below 2^-25 dropped).  The claim is fp32 accuracy: a train-mode pass
+    over 16 patches of 224 px (28x28 ... 7x7 maps, K, N = 64 ... 256 on that route) with the route on and off
+    (JN_NO_PW_X3=1: v_mfma_f32_16x16x4_f32) against the oracle in fp64 — the split route must not be further from fp64
+    than the fp32 pipe is (x 1.5 + one part in 1e6), and it must really have been taken (outputs differ)."""
+    N, P = 16, 224
+    product, oracle = make_pair(3, patch_size=P, block_size=2, with_detector=False, image_processor=None, max_batch=N)
+    x = torch.rand((N, 3, P, P), generator=torch.Generator().manual_seed(17))
+    oracle.train()
+    o64 = copy.deepcopy(oracle).double()
+    with torch.no_grad():
+        want = o64.gpt_backbone(x.double())
+    on = [t.cpu().double() for t in product.backbone_features(x, train=True)]
+    monkeypatch.setenv("JN_NO_PW_X3", "1")
+    off = [t.cpu().double() for t in product.backbone_features(x, train=True)]
+    monkeypatch.delenv("JN_NO_PW_X3")
+    assert any(not torch.equal(a, b) for a, b in zip(on, off))
+    for a, b, w in zip(on, off, want):
+        scale = w.abs().max().item()
+        e_on, e_off = (a - w).abs().max().item() / scale, (b - w).abs().max().item() / scale
+        assert e_off < 1e-4 and e_on < 1.5 * e_off + 1e-6, (e_on, e_off)
 
 
 def test_headline_shape_backward_does_not_depend_on_the_step_batching(monkeypatch):

@@ -15,7 +15,7 @@ import csv
 import re
 import sys
 
-CONV = ("stem_mfma_kernel", "dw3x3", "dwpw_eval_kernel", "pw_mfma_kernel", "pw_narrow_kernel", "pw_dir_kernel", "pw_res_kernel", "pw_xs_kernel", "addact_kernel",
+CONV = ("stem_mfma_kernel", "dw3x3", "dwpw_eval_kernel", "pw_mfma_kernel", "pw_narrow_kernel", "pw_dir_kernel", "pw_res_kernel", "pw_xs_kernel", "pw_x3_kernel", "w_split3_kernel", "addact_kernel",
         "spp_kernel", "upsample_kernel", "conv3_mfma", "bn_finalize_all_kernel")
 
 

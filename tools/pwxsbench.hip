@@ -1,7 +1,9 @@
 // Stand-alone timing of the pixel-stationary 1x1 kernel (kernels_pwxs.hip) against the weight-stationary pw_dir_kernel and
 // the generic pw_mfma_kernel on the small-map shapes of the nano PAFPN (B = 64, 448 px), with a plain table and with a
 // deferred (consumer-side BatchNorm) table as the train-mode pass uses it; results are compared bit for bit.
+// Round 3: the same shapes on the bf16 pipe with three-way split operands (pw_x3_kernel), timing and error against fp64.
 //   build: hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/pwxsbench.hip -o tools/pwxsbench
+#define JN_X3_ALL_SHAPES
 #include <hip/hip_runtime.h>
 
 #include <cmath>
