@@ -573,6 +573,144 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 2 ? 2 
       }
 }
 
+// ---- the same contraction with the operands split ONCE and read transposed (round 3) -----------------------------
+// conv3_bwd_weight_kernel<.., SP> splits every value into bf16 hi + lo on its way OUT of LDS: 8 strided scalar reads and
+// ~40 VALU operations per MFMA fragment, nine taps x two halves per k-step — the matrix pipe sat at 11 - 28 % busy under
+// the VALU (stride 2: 14 ms per launch at configs[4]).  Here the tiles are split when they are STAGED (once per value)
+// and kept as bf16 hi / lo planes in the layout the loads deliver, [pixel][channel]; a fragment — 8 pixels of one
+// channel per lane — is two ds_read_b64_tr_b16 (the hardware transposes a 4-pixel x 16-channel block per 16 lanes), with
+// per-lane row addresses, so tap shifts and stride 2 cost nothing.  Inside the loop: 4 transposed reads per 3 MFMAs,
+// no VALU.  Row strides (G 160 B, X 96 B at stride 1 / 80 B at stride 2) put the 8 pixel rows a 32-lane half reads at
+// once on 8 disjoint bank octets.  k of the 32-pixel step <-> pixel: k = 16 h + 8 b + 4 r + q  ->  tile row 2 ks + h,
+// column 8 r + 4 b + q (lane group g = 2 h + b, read r, row q of the block) — any bijection works as long as both
+// operands use it; this one makes the rows of a half consecutive pixels.
+typedef __attribute__((ext_vector_type(4))) short tr_s4;
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* r0, const bf16_t* r1) {
+  const tr_s4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_s4 __attribute__((address_space(3)))*)r0);
+  const tr_s4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_s4 __attribute__((address_space(3)))*)r1);
+  typedef __attribute__((ext_vector_type(8))) short s8;
+  const s8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int S>
+__global__ __launch_bounds__(256, 2) void conv3_bwd_weight_tr_kernel(const float* __restrict__ gz, int g_ld,
+                                                                     const float* __restrict__ x, int x_ld, ChanTab it,
+                                                                     float* __restrict__ gw, int H, int W, int OH, int OW,
+                                                                     int Co, int Ci, int tiles_x, int tiles_y, int n_tiles,
+                                                                     SlotBatch sb) {
+  constexpr int TH = 4, IH = TH * S + 2, IW = C3_TW * S + 2, NPIX = TH * C3_TW;
+  constexpr int GLD = 80, XLD = S == 1 ? 48 : 40;          // row strides in bf16 elements (see above)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_tr[];
+  bf16_t* Gh = reinterpret_cast<bf16_t*>(smem_tr);          // [NPIX][GLD]
+  bf16_t* Gl = Gh + NPIX * GLD;
+  bf16_t* Xh = Gl + NPIX * GLD;                             // [IH * IW][XLD]
+  bf16_t* Xl = Xh + IH * IW * XLD;
+  {
+    const long long sl = blockIdx.z / ((Ci + CW_BK - 1) / CW_BK);
+    gz += sl * sb.grad; x += sl * sb.act;
+    it.sc += sl * sb.tab; it.sh += sl * sb.tab; it.fl += sl * sb.tab;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, g = lane >> 4;
+  const int o0 = blockIdx.y * CW_BO, k0 = (blockIdx.z % ((Ci + CW_BK - 1) / CW_BK)) * CW_BK;
+  f32x4 acc[9][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+  constexpr int NGF = (NPIX * (CW_BO / 4) + 255) / 256, NXF = (IH * IW * (CW_BK / 4) + 255) / 256;
+  f32x4 pg[NGF], px[NXF];
+  f32x4 w_sc = {1.f, 1.f, 1.f, 1.f}, w_sh = {0.f, 0.f, 0.f, 0.f}, w_fl = {0.f, 0.f, 0.f, 0.f};
+  if (k0 + 4 * (tid % (CW_BK / 4)) < Ci) {
+    const int kq = k0 + 4 * (tid % (CW_BK / 4));
+    w_sc = *reinterpret_cast<const f32x4*>(it.sc + kq); w_sh = *reinterpret_cast<const f32x4*>(it.sh + kq);
+    w_fl = *reinterpret_cast<const f32x4*>(it.fl + kq);
+  }
+  auto fetch = [&](int tile) {
+    const int tr = tile % (tiles_x * tiles_y), n_img = tile / (tiles_x * tiles_y);
+    const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * C3_TW;
+#pragma unroll
+    for (int j = 0; j < NGF; ++j) {
+      const int i = tid + 256 * j, pix = i / (CW_BO / 4), q = i % (CW_BO / 4);
+      const int oy = oy0 + pix / C3_TW, ox = ox0 + pix % C3_TW;
+      pg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < NPIX * (CW_BO / 4) && oy < OH && ox < OW && o0 + 4 * q < Co)
+        pg[j] = *reinterpret_cast<const f32x4*>(gz + (((long long)n_img * OH + oy) * OW + ox) * g_ld + o0 + 4 * q);
+    }
+#pragma unroll
+    for (int j = 0; j < NXF; ++j) {
+      const int i = tid + 256 * j, pix = i / (CW_BK / 4), q = i % (CW_BK / 4);
+      const int iy = oy0 * S - 1 + pix / IW, ix = ox0 * S - 1 + pix % IW;
+      px[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < IH * IW * (CW_BK / 4) && iy >= 0 && iy < H && ix >= 0 && ix < W && k0 + 4 * q < Ci)
+        px[j] = *reinterpret_cast<const f32x4*>(x + (((long long)n_img * H + iy) * W + ix) * x_ld + k0 + 4 * q);
+    }
+  };
+  auto split_store = [](bf16_t* hi, bf16_t* lo, f32x4 v) {
+    const bf16x4 h = __builtin_convertvector(v, bf16x4);
+    const bf16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), bf16x4);
+    *reinterpret_cast<bf16x4*>(hi) = h; *reinterpret_cast<bf16x4*>(lo) = l;
+  };
+  // transposed-read addresses of this lane: row q = (lane & 15) >> 2 of the block, channels 4 p .. 4 p + 3
+  const int tq = (lane & 15) >> 2, tp = lane & 3, th = g >> 1, tb = g & 1;
+  // operand A (g_z): pixel (2 ks + th, 8 r + 4 tb + tq), channels 16 wave + 4 tp
+  const int a_off = (th * C3_TW + 4 * tb + tq) * GLD + 16 * wave + 4 * tp;
+  // operand B (input): halo pixel (S (2 ks + th) + ky, S (8 r + 4 tb + tq) + kx), channels 16 hh + 4 tp
+  const int b_off = ((S * th) * IW + S * (4 * tb + tq)) * XLD + 4 * tp;
+  if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int tr = tile % (tiles_x * tiles_y);
+    const int oy0 = (tr / tiles_x) * TH, ox0 = (tr % tiles_x) * C3_TW;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NGF; ++j) {
+      const int i = tid + 256 * j, pix = i / (CW_BO / 4), q = i % (CW_BO / 4);
+      if (i < NPIX * (CW_BO / 4)) split_store(Gh + pix * GLD + 4 * q, Gl + pix * GLD + 4 * q, pg[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NXF; ++j) {
+      const int i = tid + 256 * j, pix = i / (CW_BK / 4), q = i % (CW_BK / 4);
+      if (i < IH * IW * (CW_BK / 4)) {
+        const int iy = oy0 * S - 1 + pix / IW, ix = ox0 * S - 1 + pix % IW;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};                     // padding stays 0 (not silu(shift))
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W && k0 + 4 * q < Ci) v = tf4_d(px[j], w_sc, w_sh, w_fl);
+        split_store(Xh + pix * XLD + 4 * q, Xl + pix * XLD + 4 * q, v);
+      }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
+#pragma unroll
+    for (int ks = 0; ks < NPIX / 32; ++ks) {
+      const int ga = a_off + (2 * ks) * C3_TW * GLD;
+      const bf16x8 ah = tr_frag(Gh + ga, Gh + ga + 8 * GLD), al = tr_frag(Gl + ga, Gl + ga + 8 * GLD);
+      const int xb = b_off + (S * 2 * ks) * IW * XLD;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int xt = xb + ((t / 3) * IW + (t % 3)) * XLD;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const bf16x8 bh = tr_frag(Xh + xt + 16 * hh, Xh + xt + 16 * hh + 8 * S * XLD);
+          const bf16x8 bl = tr_frag(Xl + xt + 16 * hh, Xl + xt + 16 * hh + 8 * S * XLD);
+          f32x4 d = acc[t][hh];
+          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, d, 0, 0, 0);
+          acc[t][hh] = d;
+        }
+      }
+    }
+  }
+  // D[i = cout 4g + r][j = cin lm]: dW[tap][o][k], k contiguous
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = o0 + 16 * wave + 4 * g + r, k = k0 + 16 * h + lm;
+        if (o < Co && k < Ci) atomicAdd(&gw[((long long)t * Co + o) * Ci + k], acc[t][h][r]);
+      }
+}
+
 int launch_conv3_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, int x_ld, ChanTab it, float* gw, int H,
                             int W, int OH, int OW, int Co, int Ci, int N, int stride, hipStream_t s, const SlotBatch& sb) {
   const int TH = 4;
@@ -583,6 +721,26 @@ int launch_conv3_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtyp
   if (gx > n_tiles) gx = n_tiles;
   dim3 grid((unsigned)gx, nbo, nbk * sb.n);
   static const bool exact = std::getenv("JN_WW_EXACT") != nullptr;
+  static const bool no_tr = std::getenv("JN_NO_CONV3_WTR") != nullptr;
+  if (!exact && !no_tr && x_dtype == JN_F32 && Co % 16 == 0 && Ci % 4 == 0 && g_ld % 4 == 0 && x_ld % 4 == 0) {
+    // split planes + transposed LDS reads (conv3_bwd_weight_tr_kernel)
+#define JN_CWT(S_)                                                                                                      \
+    {                                                                                                                   \
+      constexpr int IHW = (4 * S_ + 2) * (C3_TW * S_ + 2);                                                              \
+      const size_t smem = ((size_t)2 * 4 * C3_TW * 80 + (size_t)2 * IHW * (S_ == 1 ? 48 : 40)) * sizeof(bf16_t);        \
+      static bool raised = false;                                                                                       \
+      if (!raised) {                                                                                                    \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bwd_weight_tr_kernel<S_>),                      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                               \
+        raised = true;                                                                                                  \
+      }                                                                                                                 \
+      hipLaunchKernelGGL((conv3_bwd_weight_tr_kernel<S_>), grid, dim3(256), smem, s, gz, g_ld, (const float*)x, x_ld, it, gw, \
+                         H, W, OH, OW, Co, Ci, tiles_x, tiles_y, n_tiles, sb);                                          \
+    }
+    if (stride == 1) JN_CWT(1) else JN_CWT(2)
+#undef JN_CWT
+    return 0;
+  }
 #define JN_CW(S_, T_, TH_, SP_)                                                                                       \
   {                                                                                                                   \
     const size_t smem = ((size_t)TH_ * C3_TW * CW_LDG + (size_t)(TH_ * S_ + 2) * (C3_TW * S_ + 2) * CW_LDX) * sizeof(float); \
