@@ -293,6 +293,212 @@ static void launch_conv3_bf16(const ConvArgs& a, hipStream_t s) {
                      a.out_ld, a.H, a.W, a.OH, a.OW, a.cin, a.cout, tiles_x, tiles_y, a.skip_flag, a.skip_when);
 }
 
+// ---- dense 3x3 on the bf16 matrix pipe at fp32 accuracy ("x3", round 3) --------------------------------------------
+// The fp32 kernel above runs AT the fp32 MFMA rate (configs[4]: 161 ms of a 367 ms iteration are its forward and
+// data-gradient launches) — 1/16 of the bf16 rate.  As in pw_x3_kernel (kernels_pwxs.hip): every fp32 operand is the exact
+// sum of three bf16 values, the six products above 2^-25 |x w| go to v_mfma_f32_16x16x32_bf16, small terms first.
+//   * K chunk = 32 (one MFMA k-step per tap and product); the halo tile is transformed and split ONCE per chunk into three
+//     bf16 planes [pixel][32 + 8];
+//   * the weight chunk goes through LDS one kernel ROW at a time (3 taps x 64 channels x 32 k x three planes = 46 KB; all
+//     nine taps would not fit beside the halo tile): three phases per chunk, the next phase's weights (and, during the
+//     last phase, the next chunk's halo tile) are in flight in registers while the matrix loop of the current one runs;
+//   * wave = PR rows x 16 pixels x 64 channels: per tap PR x 3 + 4 x 3 ds_read_b128 feed PR x 4 x 6 MFMAs.
+// WT: data gradient of a stride-1 layer (mirrored taps, transposed weight), as in conv3_mfma_kernel.
+// Eight waves (two per SIMD: one wave's operand reads run under the other's MFMAs — four waves on a CU of their own were
+// no faster than the fp32 kernel), two rows per wave: 16 x 16 pixels x 64 channels per workgroup.
+constexpr int C3X_KC = 32, C3X_LD = C3X_KC + 8;
+
+template <int S, bool WT, int PR, int NW>      // NW waves per workgroup, PR rows per wave: tile = NW PR x 16 pixels
+__global__ __launch_bounds__(64 * NW) void conv3_x3_kernel(const float* __restrict__ x, int x_ld, ChanTab it,
+                                                       const float* __restrict__ w, float* __restrict__ out, int out_ld,
+                                                       int H, int W, int OH, int OW, int K, int Nc, int tiles_x, int tiles_y,
+                                                       int accumulate, double* __restrict__ stats, long long rep_stride,
+                                                       const int* __restrict__ skip_flag, int skip_when, long long x_slot,
+                                                       long long out_slot) {
+  if (skip_flag && *skip_flag >= skip_when) return;
+  x += blockIdx.z * x_slot; out += blockIdx.z * out_slot;
+  constexpr int NT = 64 * NW, TH = NW * PR, IH = TH * S + 2, IW = C3_TW * S + 2, NP = IH * IW;
+  constexpr int XPL = NP * C3X_LD, WPL = 3 * C3_BN * C3X_LD;       // elements per plane
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_x3[];
+  bf16_t* Xp = reinterpret_cast<bf16_t*>(smem_x3);                  // [3 planes][NP][C3X_LD]
+  bf16_t* Wp = Xp + 3 * XPL;                                        // [3 planes][3 taps][C3_BN][C3X_LD]
+  float* red = reinterpret_cast<float*>(Wp + 3 * WPL);              // [NW waves][C3_BN][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x % (tiles_x * tiles_y);
+  const int n_img = blockIdx.x / (tiles_x * tiles_y);
+  const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * C3_TW;
+  const int n0 = blockIdx.y * C3_BN;
+  const float* xb = x + (long long)n_img * H * W * x_ld;
+  f32x4 acc[PR][4];
+#pragma unroll
+  for (int p = 0; p < PR; ++p)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int NXR = (NP * 8 + NT - 1) / NT;            // f32x4 of the halo tile per thread (8 quads per pixel)
+  constexpr int NWR = 3 * C3_BN * 8 / NT;             // f32x4 of one kernel row's weight chunk per thread (= 6)
+  f32x4 xr[NXR], wr[NWR];
+  f32x4 t_sc = {1.f, 1.f, 1.f, 1.f}, t_sh = {0.f, 0.f, 0.f, 0.f}, t_fl = {0.f, 0.f, 0.f, 0.f};
+  auto fetch_x = [&](int k0) {
+    const int kq = k0 + 4 * (tid & 7);                 // the thread's channel quad is the same for all its pixels
+    t_sc = *reinterpret_cast<const f32x4*>(it.sc + kq); t_sh = *reinterpret_cast<const f32x4*>(it.sh + kq);
+    t_fl = *reinterpret_cast<const f32x4*>(it.fl + kq);
+#pragma unroll
+    for (int j = 0; j < NXR; ++j) {
+      const int i = tid + NT * j, pix = i >> 3;
+      const int iy = oy0 * S - 1 + pix / IW, ix = ox0 * S - 1 + pix % IW;
+      xr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < NP * 8 && iy >= 0 && iy < H && ix >= 0 && ix < W)
+        xr[j] = *reinterpret_cast<const f32x4*>(xb + ((long long)iy * W + ix) * x_ld + kq);
+    }
+  };
+  auto fetch_w = [&](int k0, int ky) {
+#pragma unroll
+    for (int j = 0; j < NWR; ++j) {
+      const int i = tid + NT * j, q = i & 7, r = (i >> 3) % C3_BN, kx = i / (8 * C3_BN), tp = 3 * ky + kx;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n0 + r < Nc) {
+        if (WT) {
+          const float* wp = w + ((long long)(8 - tp) * K + k0 + 4 * q) * Nc + n0 + r;
+          v = f32x4{wp[0], wp[Nc], wp[2 * Nc], wp[3 * Nc]};
+        } else {
+          v = *reinterpret_cast<const f32x4*>(w + ((long long)tp * Nc + n0 + r) * K + k0 + 4 * q);
+        }
+      }
+      wr[j] = v;
+    }
+  };
+  auto split3 = [](bf16_t* dst, int plane_stride, f32x4 v) {
+    const bf16x4 h = __builtin_convertvector(v, bf16x4);
+    const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
+    const bf16x4 m = __builtin_convertvector(r1, bf16x4);
+    const bf16x4 l = __builtin_convertvector(r1 - __builtin_convertvector(m, f32x4), bf16x4);
+    *reinterpret_cast<bf16x4*>(dst) = h;
+    *reinterpret_cast<bf16x4*>(dst + plane_stride) = m;
+    *reinterpret_cast<bf16x4*>(dst + 2 * plane_stride) = l;
+  };
+  fetch_x(0);
+  fetch_w(0, 0);
+  for (int k0 = 0; k0 < K; k0 += C3X_KC) {
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {
+      __syncthreads();                                 // the previous phase's readers are done
+      if (ky == 0) {
+#pragma unroll
+        for (int j = 0; j < NXR; ++j) {
+          const int i = tid + NT * j, pix = i >> 3, q = i & 7;
+          if (i < NP * 8) {
+            const int iy = oy0 * S - 1 + pix / IW, ix = ox0 * S - 1 + pix % IW;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};              // padding stays 0 (not silu(shift))
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = tf4_d(xr[j], t_sc, t_sh, t_fl);
+            split3(Xp + pix * C3X_LD + 4 * q, XPL, v);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NWR; ++j) {
+        const int i = tid + NT * j, q = i & 7, r = (i >> 3) % C3_BN, kx = i / (8 * C3_BN);
+        split3(Wp + (kx * C3_BN + r) * C3X_LD + 4 * q, WPL, wr[j]);
+      }
+      __syncthreads();
+      // next phase's operands into registers under this phase's matrix loop
+      if (ky < 2) fetch_w(k0, ky + 1);
+      else if (k0 + C3X_KC < K) { fetch_w(k0 + C3X_KC, 0); fetch_x(k0 + C3X_KC); }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        bf16x8 xv[PR][3];
+#pragma unroll
+        for (int p = 0; p < PR; ++p)
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            xv[p][t] = *reinterpret_cast<const bf16x8*>(Xp + t * XPL + (((PR * wave + p) * S + ky) * IW + lm * S + kx) * C3X_LD + 8 * g);
+#pragma unroll
+        for (int c2 = 0; c2 < 4; c2 += 2) {              // two channel tiles at a time: 2 PR independent accumulators per product
+          bf16x8 wa[2][3];
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+              wa[cc][t] = *reinterpret_cast<const bf16x8*>(Wp + t * WPL + (kx * C3_BN + 16 * (c2 + cc) + lm) * C3X_LD + 8 * g);
+          constexpr int TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};     // (w, x): l h, h l, m m, m h, h m, h h
+#pragma unroll
+          for (int e = 0; e < 6; ++e)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+              for (int p = 0; p < PR; ++p)
+                acc[p][c2 + cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cc][TW[e]], xv[p][TX[e]], acc[p][c2 + cc], 0, 0, 0);
+        }
+      }
+    }
+  }
+  f32x4 s1[4], s2[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { s1[c] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[c] = s1[c]; }
+#pragma unroll
+  for (int p = 0; p < PR; ++p) {
+    const int oy = oy0 + PR * wave + p, ox = ox0 + lm;
+    if (oy >= OH || ox >= OW) continue;
+    float* op = out + (((long long)n_img * OH + oy) * OW + ox) * out_ld;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int n = n0 + 16 * c + 4 * g;
+      if (n < Nc) {
+        f32x4 v = acc[p][c];
+        if (accumulate) v += *reinterpret_cast<const f32x4*>(op + n);
+        *reinterpret_cast<f32x4*>(op + n) = v;
+        s1[c] += v;
+        s2[c] += v * v;
+      }
+    }
+  }
+  if (stats) {
+    wave_stats_to_lds<4>(s1, s2, red + wave * 2 * C3_BN, lane, Nc - n0);
+    __syncthreads();
+    if (tid < 2 * C3_BN && n0 + (tid >> 1) < Nc) {
+      float sum = 0.0f;
+#pragma unroll
+      for (int wv = 0; wv < NW; ++wv) sum += red[wv * 2 * C3_BN + tid];
+      atomicAdd(&stats[(blockIdx.x % JN_NREP) * rep_stride + 2 * n0 + tid], (double)sum);
+    }
+  }
+}
+
+template <int S, bool WT, int PR, int NW>
+static void launch_conv3_x3(const ConvArgs& a, hipStream_t s) {
+  constexpr int TH = NW * PR;
+  const int tiles_x = (a.OW + C3_TW - 1) / C3_TW, tiles_y = (a.OH + TH - 1) / TH;
+  dim3 grid(tiles_x * tiles_y * a.N, (a.cout + C3_BN - 1) / C3_BN, a.n_slots > 1 ? a.n_slots : 1);
+  const size_t smem = ((size_t)3 * (S * TH + 2) * (S * C3_TW + 2) * C3X_LD + (size_t)3 * 3 * C3_BN * C3X_LD) * sizeof(bf16_t) +
+                      (size_t)NW * 2 * C3_BN * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_x3_kernel<S, WT, PR, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3_x3_kernel<S, WT, PR, NW>), grid, dim3(64 * NW), smem, s, (const float*)a.in, a.in_ld, a.itab, a.w,
+                     (float*)a.out, a.out_ld, a.H, a.W, a.OH, a.OW, a.cin, a.cout, tiles_x, tiles_y, a.accumulate, a.stats,
+                     a.stats_rep_stride, a.skip_flag, a.skip_when, a.in_slot_stride, a.out_slot_stride);
+}
+
+// fp32 activations, K a multiple of 32 (every dense 3x3 layer of yolox-s / -m / -l); JN_NO_CONV3_X3=1: fp32 matrix pipe
+// fp32 activations, K a multiple of 32 (every dense 3x3 layer of yolox-s / -m / -l), stride 1; JN_NO_CONV3_X3=1 (read per
+// launch): fp32 matrix pipe.  Stride 2 stays on the fp32 kernel: its halo tile leaves room for one row per wave only, the
+// operand reads of the three planes then need more than the LDS delivers (measured: 5 % slower).
+// The x3 workgroup is 16 x 16 pixels on a whole CU (124 KB of LDS), the fp32 one 8 x 16 with two per CU; per 16 rows of
+// pixels the x3 kernel takes ~0.65 of the fp32 kernel's time (tools/c5_layers.sh: 80x80 64 -> 64: 91 -> 62 us; 20x20
+// 256 -> 256: 159 -> 107), but a launch is whole rounds of workgroups and a 40 x 40 map is 2.5 tiles high — pick per launch:
+// rounds x time per round (forward of 16 patches at 40 x 40: 480 fp32 workgroups = one round, 288 x3 workgroups = two).
+static bool conv3_x3_ok(const ConvArgs& a) {
+  if (std::getenv("JN_NO_CONV3_X3") || a.stride != 1 || a.in_dtype != JN_F32 || a.out_dtype != JN_F32 || a.cin % 32 || a.cout % 4 ||
+      a.in_ld % 4 || a.out_ld % 4 || a.bias || a.act != ACT_NONE)
+    return false;
+  const long long slots = a.n_slots > 1 ? a.n_slots : 1, nbo = (a.cout + C3_BN - 1) / C3_BN, tx = (a.OW + C3_TW - 1) / C3_TW;
+  const long long wg_f32 = tx * ((a.OH + 7) / 8) * a.N * nbo * slots, wg_x3 = tx * ((a.OH + 15) / 16) * a.N * nbo * slots;
+  const double cost_f32 = (double)((wg_f32 + 511) / 512), cost_x3 = 0.65 * (double)((wg_x3 + 255) / 256);
+  return cost_x3 < cost_f32;
+}
+
 template <int S, typename AT, bool WT>
 static void launch_conv3_t(const ConvArgs& a, hipStream_t s) {
   // 8 x 16 pixels per workgroup (2 rows per wave).  16 x 16 (PR = 4) halves the weight-tile staging per MFMA but
@@ -318,7 +524,7 @@ static void launch_conv3_t(const ConvArgs& a, hipStream_t s) {
 int launch_conv3(const ConvArgs& a, hipStream_t s) {
   if (a.w_transposed) {               // data gradient of a stride-1 layer (fp32 gradient buffers)
     if (a.stride != 1 || a.in_dtype != JN_F32 || a.cin % 4) return -1;
-    launch_conv3_t<1, float, true>(a, s);
+    if (conv3_x3_ok(a)) launch_conv3_x3<1, true, 2, 8>(a, s); else launch_conv3_t<1, float, true>(a, s);
     return 0;
   }
   static const bool no_bf16_conv3 = std::getenv("JN_NO_BF16_CONV3") != nullptr;
@@ -327,6 +533,7 @@ int launch_conv3(const ConvArgs& a, hipStream_t s) {
     return 0;
   }
   if (a.in_dtype == JN_BF16) { if (a.stride == 1) launch_conv3_t<1, bf16_t, false>(a, s); else launch_conv3_t<2, bf16_t, false>(a, s); }
+  else if (conv3_x3_ok(a)) launch_conv3_x3<1, false, 2, 8>(a, s);
   else { if (a.stride == 1) launch_conv3_t<1, float, false>(a, s); else launch_conv3_t<2, float, false>(a, s); }
   return 0;
 }
