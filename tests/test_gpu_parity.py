@@ -1136,6 +1136,28 @@ def test_detector_backbone_and_raw_head(P, ip):
     assert (got_raw.cpu()[..., 4:] - raw[..., 4:]).abs().max() < 1e-5                      # obj / cls probabilities
 
 
+def test_three_way_split_dense_3x3_is_as_accurate_as_the_fp32_matrix_pipe(monkeypatch):
+    """Round 3: the stride-1 dense 3x3 layers of the yolox-s nets run on the bf16 matrix pipe with three-way split operands
+    (conv3_x3_kernel) when whole rounds of its 16 x 16 tiles are the cheaper launch.  The eval-mode detector backbone
+    over 8 patches of 320 px (40x40 ... 10x10 maps) with the route on and off (JN_NO_CONV3_X3=1) against the oracle in
+    fp64: the split route is not further from fp64 than the fp32 pipe (x 1.5 + 1e-6), and it was taken (outputs differ)."""
+    P = 320
+    product, oracle = _detector_pair(P, 0.5, "yolox-s", max_batch=8)
+    x = torch.rand((8, 3, P, P), generator=torch.Generator().manual_seed(23))
+    o64 = copy.deepcopy(oracle).double()
+    with torch.no_grad():
+        want = o64.yolox.backbone(x.double())
+    on = [t.cpu().double() for t in product.backbone_features(x, net=_lib.JN_NET_DETECTOR)]
+    monkeypatch.setenv("JN_NO_CONV3_X3", "1")
+    off = [t.cpu().double() for t in product.backbone_features(x, net=_lib.JN_NET_DETECTOR)]
+    monkeypatch.delenv("JN_NO_CONV3_X3")
+    assert any(not torch.equal(a, b) for a, b in zip(on, off))
+    for a, b, w in zip(on, off, want):
+        scale = w.abs().max().item()
+        e_on, e_off = (a - w).abs().max().item() / scale, (b - w).abs().max().item() / scale
+        assert e_off < 1e-4 and e_on < 1.5 * e_off + 1e-6, (e_on, e_off)
+
+
 def _bf16_emulated_backbone(net, x):
     """The same graph with every conv's operands (activations, weights) and output rounded to bf16 on the CPU: what
     bf16 storage + bf16 MFMA operands cost on this network, independent of any kernel."""
