@@ -791,15 +791,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S == 2 ? 2 
 // once on 8 disjoint bank octets.  k of the 32-pixel step <-> pixel: k = 16 h + 8 b + 4 r + q  ->  tile row 2 ks + h,
 // column 8 r + 4 b + q (lane group g = 2 h + b, read r, row q of the block) — any bijection works as long as both
 // operands use it; this one makes the rows of a half consecutive pixels.
-typedef __attribute__((ext_vector_type(4))) short tr_s4;
-__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* r0, const bf16_t* r1) {
-  const tr_s4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_s4 __attribute__((address_space(3)))*)r0);
-  const tr_s4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_s4 __attribute__((address_space(3)))*)r1);
-  typedef __attribute__((ext_vector_type(8))) short s8;
-  const s8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-  return __builtin_bit_cast(bf16x8, v);
-}
-
 template <int S>
 __global__ __launch_bounds__(256, 2) void conv3_bwd_weight_tr_kernel(const float* __restrict__ gz, int g_ld,
                                                                      const float* __restrict__ x, int x_ld, ChanTab it,
