@@ -808,8 +808,8 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
   std::vector<hipEvent_t> lev;
   if (layer_profile) {
     lev.resize(n_ops + 1);
-    for (auto& e : lev) hipEventCreate(&e);
-    hipEventRecord(lev[0], s);
+    for (auto& e : lev) (void)hipEventCreate(&e);
+    (void)hipEventRecord(lev[0], s);
   }
   for (int oi = 0; oi < n_ops; ++oi) {
     const Op& op = net.ops[oi];
@@ -849,7 +849,7 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
               skip_ops = 2;
             }
             launch_dwpw(f, s);
-            if (layer_profile) for (int k = 1; k <= skip_ops + 1; ++k) hipEventRecord(lev[oi + k], s);
+            if (layer_profile) for (int k = 1; k <= skip_ops + 1; ++k) (void)hipEventRecord(lev[oi + k], s);
             oi += skip_ops;
             continue;
           }
@@ -888,10 +888,10 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
                          net.n_anchors, op.anchor0, N, s, train ? 1 : 0);
         break;
     }
-    if (layer_profile) hipEventRecord(lev[oi + 1], s);
+    if (layer_profile) (void)hipEventRecord(lev[oi + 1], s);
   }
   if (layer_profile) {
-    hipStreamSynchronize(s);
+    (void)hipStreamSynchronize(s);
     static const char* kn[] = {"stem", "pw", "dw", "conv3", "spp", "upsample", "addact", "pred"};
     const double esz = (double)act_esz(net);
     double tot_us = 0, tot_b = 0;
@@ -899,7 +899,7 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
     for (int oi = 0; oi < n_ops; ++oi) {
       const Op& op = net.ops[oi];
       float ms = 0;
-      hipEventElapsedTime(&ms, lev[oi], lev[oi + 1]);
+      (void)hipEventElapsedTime(&ms, lev[oi], lev[oi + 1]);
       const double in_e = op.kind == OP_STEM ? 3.0 * net.P * net.P * 4.0 / esz : (double)op.in.H * op.in.W * op.in.C;
       double out_e = (double)op.out.H * op.out.W * op.out.C;
       double elems = in_e + out_e;
@@ -911,7 +911,7 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
               op.in.H, op.in.W, op.in.C, op.out.H, op.out.W, op.out.C, op.stride, ms * 1e3, bytes / 1e6, bytes / (ms * 1e-3) / 1e9);
     }
     fprintf(stderr, "# total %.1f us, %.1f MB, %.0f GB/s\n", tot_us, tot_b / 1e6, tot_b / (tot_us * 1e-6) / 1e9);
-    for (auto& e : lev) hipEventDestroy(e);
+    for (auto& e : lev) (void)hipEventDestroy(e);
   }
   if (defer) {
     BnAllArgs fa{};
@@ -1079,13 +1079,13 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
   std::vector<hipEvent_t> bev;
   if (bwd_profile) {
     bev.resize(n_ops_b + 1);
-    for (auto& e : bev) hipEventCreate(&e);
+    for (auto& e : bev) (void)hipEventCreate(&e);
   }
   struct BwdProfileMark {        // records the event of op `i` when the loop body is left (continue / break / fall through)
     std::vector<hipEvent_t>& ev; int i; hipStream_t s;
-    ~BwdProfileMark() { if (!ev.empty()) hipEventRecord(ev[i], s); }
+    ~BwdProfileMark() { if (!ev.empty()) (void)hipEventRecord(ev[i], s); }
   };
-  if (bwd_profile) hipEventRecord(bev[n_ops_b], s);
+  if (bwd_profile) (void)hipEventRecord(bev[n_ops_b], s);
   for (int obi = n_ops_b - 1; obi >= 0; --obi) {
     const Op& op = net.ops[obi];
     BwdProfileMark mark{bev, obi, s};
@@ -1335,14 +1335,14 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
     JN_HIP(hipStreamWaitEvent(s, ctx->aux_join, 0));
   }
   if (bwd_profile) {
-    hipStreamSynchronize(s);
+    (void)hipStreamSynchronize(s);
     static const char* kn[] = {"stem", "pw", "dw", "conv3", "spp", "upsample", "addact", "pred"};
     double tot_us = 0, tot_b = 0;
     fprintf(stderr, "# backward profile: net %d, N=%d patches x %d steps; bytes = g_out + z_out + x read, g_in written (+ read when accumulated)\n", ni, N, nsl);
     for (int obi = n_ops_b - 1; obi >= 0; --obi) {
       const Op& op = net.ops[obi];
       float ms = 0;
-      hipEventElapsedTime(&ms, bev[obi + 1], bev[obi]);
+      (void)hipEventElapsedTime(&ms, bev[obi + 1], bev[obi]);
       const double in_e = op.kind == OP_STEM ? 0.0 : (double)op.in.H * op.in.W * op.in.C, out_e = (double)op.out.H * op.out.W * op.out.C;
       double elems;
       if (op.wslot >= 0) elems = 2.0 * out_e + (op.kind == OP_STEM ? 3.0 * net.P * net.P : 2.0 * in_e + (op.acc_in ? in_e : 0.0));
@@ -1355,7 +1355,7 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
               op.in.H, op.in.W, op.in.C, op.out.H, op.out.W, op.out.C, op.stride, (int)op.acc_in, ms * 1e3, bytes / 1e6, bytes / (ms * 1e-3) / 1e9);
     }
     fprintf(stderr, "# total %.1f us, %.1f MB, %.0f GB/s\n", tot_us, tot_b / 1e6, tot_b / (tot_us * 1e-6) / 1e9);
-    for (auto& e : bev) hipEventDestroy(e);
+    for (auto& e : bev) (void)hipEventDestroy(e);
   }
   JN_HIP(hipGetLastError());
   return JN_OK;

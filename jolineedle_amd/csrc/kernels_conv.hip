@@ -614,7 +614,6 @@ int launch_dw(const ConvArgs& a, hipStream_t s) {
 // BN-free layers (embed_fpn.0, head predictors).  D = W * X^T per 16x16 tile: channel on the
 // row, pixel on the lane -> each lane owns 4 consecutive channels of one pixel (dwordx4 store).
 // ------------------------------------------------------------------------------------
-constexpr int PW_BM = 128;     // pixels per workgroup (4 waves x 2 tiles of 16)
 
 // WT: `w` is stored [K][Nc] (the forward weight of the layer whose data-gradient is computed) and is
 // read transposed; accumulate: out += result (gradient buffers with several contributors).
