@@ -44,10 +44,14 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const AT* __restrict__ 
   x += blockIdx.z * x_slot; out += blockIdx.z * out_slot;          // step-batched gradient launches
   constexpr int TH = 4 * PR;
   constexpr int IH = TH * S + 2, IW = C3_TW * S + 2;
+  // row strides (floats): 96 B = 32 x odd makes the ds_read_b128 of 16 consecutive rows conflict-free (80 B: half of the LDS
+  // cycles were bank conflicts, PMC); at stride 2 the pixel rows are 2 x 80 B = 32 x 5 apart already, and 96-byte weight rows
+  // would cost the second workgroup per CU
+  constexpr int LDX = S == 1 ? 24 : C3_LD, LDW = S == 1 ? 24 : C3_LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Xs = smem;                              // [IH*IW][C3_LD]
-  float* Ws = smem + IH * IW * C3_LD;            // [9][C3_BN][C3_LD]
-  float* red = Ws + 9 * C3_BN * C3_LD;           // [4 waves][C3_BN][2]
+  float* Xs = smem;                              // [IH*IW][LDX]
+  float* Ws = smem + IH * IW * LDX;              // [9][C3_BN][LDW]
+  float* red = Ws + 9 * C3_BN * LDW;             // [4 waves][C3_BN][2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, g = lane >> 4;
   const int tile = blockIdx.x % (tiles_x * tiles_y);
@@ -107,13 +111,13 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const AT* __restrict__ 
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (iy >= 0 && iy < H && ix >= 0 && ix < W && kk < K)
           v = tf4_d(xr[j], t_sc, t_sh, t_fl);
-        *reinterpret_cast<f32x4*>(Xs + pix * C3_LD + 4 * q) = v;
+        *reinterpret_cast<f32x4*>(Xs + pix * LDX + 4 * q) = v;
       }
     }
 #pragma unroll
     for (int j = 0; j < NWR; ++j) {
       const int i = tid + 256 * j, q = i & 3, r = (i >> 2) % C3_BN, tp = i / (4 * C3_BN);
-      *reinterpret_cast<f32x4*>(Ws + (tp * C3_BN + r) * C3_LD + 4 * q) = wr[j];
+      *reinterpret_cast<f32x4*>(Ws + (tp * C3_BN + r) * LDW + 4 * q) = wr[j];
     }
     __syncthreads();
     if (k0 + C3_KC < K) fetch(k0 + C3_KC);
@@ -123,10 +127,10 @@ __global__ __launch_bounds__(256) void conv3_mfma_kernel(const AT* __restrict__ 
       f32x4 xbv[PR];
 #pragma unroll
       for (int p = 0; p < PR; ++p)
-        xbv[p] = *reinterpret_cast<const f32x4*>(Xs + (((PR * wave + p) * S + ky) * IW + lm * S + kx) * C3_LD + 4 * g);
+        xbv[p] = *reinterpret_cast<const f32x4*>(Xs + (((PR * wave + p) * S + ky) * IW + lm * S + kx) * LDX + 4 * g);
       f32x4 wa[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) wa[c] = *reinterpret_cast<const f32x4*>(Ws + (tp * C3_BN + 16 * c + lm) * C3_LD + 4 * g);
+      for (int c = 0; c < 4; ++c) wa[c] = *reinterpret_cast<const f32x4*>(Ws + (tp * C3_BN + 16 * c + lm) * LDW + 4 * g);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -306,7 +310,7 @@ static void launch_conv3_bf16(const ConvArgs& a, hipStream_t s) {
 // WT: data gradient of a stride-1 layer (mirrored taps, transposed weight), as in conv3_mfma_kernel.
 // Eight waves (two per SIMD: one wave's operand reads run under the other's MFMAs — four waves on a CU of their own were
 // no faster than the fp32 kernel), two rows per wave: 16 x 16 pixels x 64 channels per workgroup.
-constexpr int C3X_KC = 32, C3X_LD = C3X_KC + 8;
+constexpr int C3X_KC = 32, C3X_LD = C3X_KC + 16;     // 96-byte rows = 32 x 3: conflict-free ds_read_b128 (80-byte rows: half of the LDS cycles were bank conflicts, PMC)
 
 template <int S, bool WT, int PR, int NW>      // NW waves per workgroup, PR rows per wave: tile = NW PR x 16 pixels
 __global__ __launch_bounds__(64 * NW) void conv3_x3_kernel(const float* __restrict__ x, int x_ld, ChanTab it,
@@ -507,7 +511,8 @@ static void launch_conv3_t(const ConvArgs& a, hipStream_t s) {
   constexpr int PR = S == 2 ? 1 : 2, TH = 4 * PR;
   const int tiles_x = (a.OW + C3_TW - 1) / C3_TW, tiles_y = (a.OH + TH - 1) / TH;
   dim3 grid(tiles_x * tiles_y * a.N, (a.cout + C3_BN - 1) / C3_BN, a.n_slots > 1 ? a.n_slots : 1);
-  const size_t smem = (((size_t)(S * TH + 2) * (S * C3_TW + 2) + 9 * C3_BN) * C3_LD + 4 * 2 * C3_BN) * sizeof(float);
+  constexpr int LD = S == 1 ? 24 : C3_LD;
+  const size_t smem = (((size_t)(S * TH + 2) * (S * C3_TW + 2) + 9 * C3_BN) * LD + 4 * 2 * C3_BN) * sizeof(float);
   if (smem > 64 * 1024) {             // stride 2: 95 KB of the CU's 160 KB LDS, above the 64 KB default cap
     static bool attr_set = false;
     if (!attr_set) {
@@ -543,6 +548,7 @@ int launch_conv3(const ConvArgs& a, hipStream_t s) {
 // The input pixels of one parity class (iy & 1, ix & 1) over a 16 x 32 input tile form an 8 x 16 grid that maps 1:1
 // onto output pixels (a, b) = (iy >> 1, ix >> 1) (+1 for the odd taps): the same MFMA tile loop as the forward
 // kernel with 1 / 2 / 2 / 4 taps.  blockIdx.z = parity class (x slot); g_z tile (9 x 17 pixels) per K chunk in LDS.
+constexpr int C3S2_LD = 24;      // 96-byte rows: conflict-free ds_read_b128 (with 80-byte rows half of the LDS cycles were conflicts)
 __global__ __launch_bounds__(256) void conv3_bwd_data_s2_kernel(const float* __restrict__ gz, int g_ld,
                                                                 const float* __restrict__ w, float* __restrict__ gin,
                                                                 int gin_ld, int H, int W, int OH, int OW, int Co, int Ci,
@@ -550,8 +556,8 @@ __global__ __launch_bounds__(256) void conv3_bwd_data_s2_kernel(const float* __r
                                                                 long long g_slot) {
   constexpr int GH = C3_TH + 1, GW = C3_TW + 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Gs = smem;                              // [GH*GW][C3_LD]   g_z, K chunk of 16 output channels
-  float* Ws = smem + GH * GW * C3_LD;            // [4][C3_BN][C3_LD] the class's taps: [cin row][cout chunk]
+  float* Gs = smem;                              // [GH*GW][C3S2_LD]   g_z, K chunk of 16 output channels
+  float* Ws = smem + GH * GW * C3S2_LD;            // [4][C3_BN][C3S2_LD] the class's taps: [cin row][cout chunk]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, g = lane >> 4;
   const int cls = blockIdx.z & 3, py = cls >> 1, px = cls & 1;
@@ -575,7 +581,7 @@ __global__ __launch_bounds__(256) void conv3_bwd_data_s2_kernel(const float* __r
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (oy < OH && ox < OW && k0 + 4 * q < Co)
         v = *reinterpret_cast<const f32x4*>(gz + (((long long)n_img * OH + oy) * OW + ox) * g_ld + k0 + 4 * q);
-      *reinterpret_cast<f32x4*>(Gs + pix * C3_LD + 4 * q) = v;
+      *reinterpret_cast<f32x4*>(Gs + pix * C3S2_LD + 4 * q) = v;
     }
     for (int i = tid; i < nky * nkx * C3_BN * 4; i += 256) {
       const int q = i & 3, r = (i >> 2) % C3_BN, tq = i / (4 * C3_BN);
@@ -585,17 +591,17 @@ __global__ __launch_bounds__(256) void conv3_bwd_data_s2_kernel(const float* __r
         const float* wp = w + ((long long)(ky * 3 + kx) * Co + k0 + 4 * q) * Ci + n0 + r;      // w[tap][o][k]
         v = f32x4{wp[0], wp[Ci], wp[2 * Ci], wp[3 * Ci]};
       }
-      *reinterpret_cast<f32x4*>(Ws + (tq * C3_BN + r) * C3_LD + 4 * q) = v;
+      *reinterpret_cast<f32x4*>(Ws + (tq * C3_BN + r) * C3S2_LD + 4 * q) = v;
     }
     __syncthreads();
     for (int tq = 0; tq < nky * nkx; ++tq) {
       const int ky = py ? (tq / nkx) * 2 : 1, kx = px ? (tq % nkx) * 2 : 1;
       const int dy = ky == 0 ? 1 : 0, dx = kx == 0 ? 1 : 0;       // (iy + 1 - ky) / 2 - a
-      f32x4 xb0 = *reinterpret_cast<const f32x4*>(Gs + ((2 * wave + dy) * GW + lm + dx) * C3_LD + 4 * g);
-      f32x4 xb1 = *reinterpret_cast<const f32x4*>(Gs + ((2 * wave + 1 + dy) * GW + lm + dx) * C3_LD + 4 * g);
+      f32x4 xb0 = *reinterpret_cast<const f32x4*>(Gs + ((2 * wave + dy) * GW + lm + dx) * C3S2_LD + 4 * g);
+      f32x4 xb1 = *reinterpret_cast<const f32x4*>(Gs + ((2 * wave + 1 + dy) * GW + lm + dx) * C3S2_LD + 4 * g);
       f32x4 wa[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) wa[c] = *reinterpret_cast<const f32x4*>(Ws + (tq * C3_BN + 16 * c + lm) * C3_LD + 4 * g);
+      for (int c = 0; c < 4; ++c) wa[c] = *reinterpret_cast<const f32x4*>(Ws + (tq * C3_BN + 16 * c + lm) * C3S2_LD + 4 * g);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -627,7 +633,7 @@ int launch_conv3_bwd_data_s2(const float* gz, int g_ld, const float* w, float* g
   if (Co % 4 || Ci % 4) return -1;
   const int tiles_x = (OW + C3_TW - 1) / C3_TW, tiles_y = (OH + C3_TH - 1) / C3_TH;
   dim3 grid(tiles_x * tiles_y * N, (Ci + C3_BN - 1) / C3_BN, 4 * sb.n);
-  const size_t smem = ((size_t)(C3_TH + 1) * (C3_TW + 1) + 4 * C3_BN) * C3_LD * sizeof(float);
+  const size_t smem = ((size_t)(C3_TH + 1) * (C3_TW + 1) + 4 * C3_BN) * C3S2_LD * sizeof(float);
   hipLaunchKernelGGL(conv3_bwd_data_s2_kernel, grid, dim3(256), smem, s, gz, g_ld, w, gin, gin_ld, H, W, OH, OW, Co, Ci,
                      tiles_x, tiles_y, accumulate, sb.grad);
   return 0;

@@ -283,7 +283,9 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
     long long M, double* __restrict__ stats, long long rep_stride, int nrep, const int* __restrict__ skip_flag,
     int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
-  constexpr int BM = 16 * PT, LDK = K + 8, KQ = K / 4, NJ = K / 32, N = 64 * CTW;
+  // LDK: row stride 2 K + 32 bytes = 32 x odd: the 16-lane groups of a ds_read_b128 ({0-3, 12-15, 20-27}, ...: rows lm at
+  // 16 g bytes) then cover the 64 banks exactly once (with K + 8 the planes read at 37 - 39 % conflict cycles, PMC)
+  constexpr int BM = 16 * PT, LDK = K + 16, KQ = K / 4, NJ = K / 32, N = 64 * CTW;
   constexpr int NX = BM * KQ / 256;
   constexpr int NXB = NX < 16 ? NX : 16;
   static_assert(256 % KQ == 0 && NX >= 1 && NX % NXB == 0 && NJ % D == 0, "pw_x3 tile mapping");
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
 template <int K, int CTW, int PT, int D>
 static void launch_pw_x3_t(const ConvArgs& a, long long M, int wg_per_cu, hipStream_t s) {
   constexpr int BM = 16 * PT;
-  const size_t smem = (size_t)3 * BM * (K + 8) * sizeof(bf16_t) + 3 * K * sizeof(float);
+  const size_t smem = (size_t)3 * BM * (K + 16) * sizeof(bf16_t) + 3 * K * sizeof(float);
   auto kern = pw_x3_kernel<K, CTW, PT, D>;
   static int places = 0;
   if (!places) {
