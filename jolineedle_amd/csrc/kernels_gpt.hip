@@ -13,11 +13,14 @@
 
 namespace jnr {
 
-constexpr int GPT_THREADS = 1024;      // 16 waves per agent: every Linear splits K over all of them (256 threads left a 192 -> 576
-                                       // layer of gpt-mini with ONE K slice: 192 dependent loads per thread)
-constexpr int GPT_WAVES = GPT_THREADS / 64;
+// Threads per agent (template parameter NT of everything below): 1024 for wide models — 16 waves, every Linear splits K
+// over all of them (256 threads left a 192 -> 576 layer of gpt-mini with ONE K slice: 192 dependent loads per thread) — and
+// 256 for n_embd <= 64 (gpt-nano: its largest Linear is 48 x 192, the 1024-thread form only made every barrier and block
+// reduction four times as wide: 95.7 -> 119.4 us per step between rounds 1 and 2, back to the 256-thread form in round 3).
 
+template <int NT>
 __device__ __forceinline__ float block_sum(float v, float* red) {
+  constexpr int GPT_WAVES = NT / 64;
   // wave reduce by shuffles, then the waves' partials through LDS
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -33,14 +36,15 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 
 // y[n] = b[n] + sum_k x[k] * wt[k*N + n]   (x in LDS, wt transposed in global/L2).
 // All 256 threads work whatever N is: thread = (column quad, K slice); each slice walks K with stride `slices`
-// (independent dwordx4 loads), partials meet in LDS scratch `part` (>= 4 * GPT_THREADS floats).  With one thread per column a
+// (independent dwordx4 loads), partials meet in LDS scratch `part` (>= 4 * NT floats).  With one thread per column a
 // 192 -> 48 layer was 192 dependent loads on 48 threads: the whole step was a chain of L2 latencies.
+template <int NT>
 __device__ __forceinline__ void linear_t(float* y, const float* x, const float* __restrict__ wt,
                                          const float* __restrict__ b, int K, int N, float* part) {
   using f4 = __attribute__((ext_vector_type(4))) float;
   const int tid = threadIdx.x;
-  if ((N & 3) == 0 && N <= 4 * GPT_THREADS) {
-    const int nq = N >> 2, slices = GPT_THREADS / nq;
+  if ((N & 3) == 0 && N <= 4 * NT) {
+    const int nq = N >> 2, slices = NT / nq;
     const int q = tid % nq, sl = tid / nq;
     if (sl < slices) {
       f4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -50,13 +54,13 @@ __device__ __forceinline__ void linear_t(float* y, const float* x, const float* 
       *reinterpret_cast<f4*>(part + sl * N + 4 * q) = acc;
     }
     __syncthreads();
-    for (int n = tid; n < N; n += GPT_THREADS) {
+    for (int n = tid; n < N; n += NT) {
       float acc = b ? b[n] : 0.0f;
       for (int i = 0; i < slices; ++i) acc += part[i * N + n];
       y[n] = acc;
     }
-  } else if (N <= GPT_THREADS) {
-    const int slices = GPT_THREADS / N;
+  } else if (N <= NT) {
+    const int slices = NT / N;
     const int n = tid % N, sl = tid / N;
     if (sl < slices) {
       float acc = 0.0f;
@@ -70,7 +74,7 @@ __device__ __forceinline__ void linear_t(float* y, const float* x, const float* 
       y[tid] = acc;
     }
   } else {
-    for (int n = tid; n < N; n += GPT_THREADS) {
+    for (int n = tid; n < N; n += NT) {
       float acc = b ? b[n] : 0.0f;
       const float* wp = wt + n;
 #pragma unroll 4
@@ -80,16 +84,17 @@ __device__ __forceinline__ void linear_t(float* y, const float* x, const float* 
   }
 }
 
+template <int NT>
 __device__ __forceinline__ void layer_norm(float* y, const float* x, const float* __restrict__ w,
                                            const float* __restrict__ b, int C, float* red) {
   float s = 0.0f;
-  for (int i = threadIdx.x; i < C; i += GPT_THREADS) s += x[i];
-  const float mean = block_sum(s, red) / C;
+  for (int i = threadIdx.x; i < C; i += NT) s += x[i];
+  const float mean = block_sum<NT>(s, red) / C;
   float q = 0.0f;
-  for (int i = threadIdx.x; i < C; i += GPT_THREADS) { const float d = x[i] - mean; q += d * d; }
-  const float var = block_sum(q, red) / C;
+  for (int i = threadIdx.x; i < C; i += NT) { const float d = x[i] - mean; q += d * d; }
+  const float var = block_sum<NT>(q, red) / C;
   const float rstd = 1.0f / sqrtf(var + 1e-5f);
-  for (int i = threadIdx.x; i < C; i += GPT_THREADS) y[i] = (x[i] - mean) * rstd * w[i] + b[i];
+  for (int i = threadIdx.x; i < C; i += NT) y[i] = (x[i] - mean) * rstd * w[i] + b[i];
   __syncthreads();
 }
 
@@ -98,7 +103,9 @@ __device__ __forceinline__ float gelu_tanh(float x) {
   return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
 }
 
-__global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
+template <int NT>
+__global__ __launch_bounds__(NT) void gpt_step_kernel(GptStepArgs a) {
+  constexpr int GPT_WAVES = NT / 64;
   if (a.skip_flag && *a.skip_flag >= a.skip_when) {
     // every env was done before this step: stay skipped for the rest of the trajectory
     if (blockIdx.x == 0 && threadIdx.x == 0) a.n_done[a.step + 1] = a.skip_when;
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
   float* att = mlp + 4 * C;      // [n_head * Tmax]
   float* red = att + a.n_head * a.Tmax;   // [GPT_WAVES]
   float* lg = red + GPT_WAVES;   // [16]  logits
-  float* part = sm + ((9 * C + a.n_head * a.Tmax + GPT_WAVES + 16 + 3) & ~3);   // [4 * GPT_THREADS] split-K partials of linear_t (16-B aligned)
+  float* part = sm + ((9 * C + a.n_head * a.Tmax + GPT_WAVES + 16 + 3) & ~3);   // [4 * NT] split-K partials of linear_t (16-B aligned)
 
   const int t = a.step;
   const int hs = C / a.n_head;
@@ -125,10 +132,10 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
     // ---------------- token embedding ----------------
     const bool class_tok = (a.src_mode == GPT_SRC_CLASS) || (a.src_mode == GPT_SRC_ENV && t == 0 && j == 0);
     if (class_tok) {
-      for (int i = tid; i < C; i += GPT_THREADS) x[i] = a.embed_class[i];       // classes == 0 (reinforce.py:129)
+      for (int i = tid; i < C; i += NT) x[i] = a.embed_class[i];       // classes == 0 (reinforce.py:129)
     } else if (a.src_mode == GPT_SRC_GIVEN) {
       const float* gp = a.given_emb + ((long long)b * a.given_stride + a.given_index) * C;
-      for (int i = tid; i < C; i += GPT_THREADS) x[i] = gp[i];
+      for (int i = tid; i < C; i += NT) x[i] = gp[i];
     } else {
       int act, row, col;
       if (a.src_mode == GPT_SRC_ENV) {
@@ -144,14 +151,14 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
       row = min(max(row, 0), 255); col = min(max(col, 0), 255);
       float* parts = mlp;
       int p = 0;
-      for (int i = tid; i < C; i += GPT_THREADS) parts[i] = a.wte[act * C + i];
+      for (int i = tid; i < C; i += NT) parts[i] = a.wte[act * C + i];
       ++p;
-      for (int i = tid; i < C; i += GPT_THREADS)
+      for (int i = tid; i < C; i += NT)
         parts[p * C + i] = a.dec_pos_enc ? a.pos1d[a.pos_index * C + i] : a.wpe[a.pos_index * C + i];
       ++p;
       if (!a.no_patch_emb) {
         if (a.src_mode == GPT_SRC_ENV) {
-          for (int i = tid; i < C; i += GPT_THREADS) {
+          for (int i = tid; i < C; i += NT) {
             float s = a.efpn_lin_b[i];
             for (int ks = 0; ks < a.KS; ++ks) s += a.emb_part[((long long)b * a.KS + ks) * C + i];
             parts[p * C + i] = s;
@@ -159,20 +166,20 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
           }
         } else {
           const float* pe = a.tok_emb + ((long long)b * a.tok_emb_stride + a.tok_emb_index) * C;
-          for (int i = tid; i < C; i += GPT_THREADS) parts[p * C + i] = pe[i];
+          for (int i = tid; i < C; i += NT) parts[p * C + i] = pe[i];
         }
         ++p;
       }
       if (a.use_pos_emb) {
-        for (int i = tid; i < C; i += GPT_THREADS)
+        for (int i = tid; i < C; i += NT)
           parts[p * C + i] = (i < a.pe2_ch) ? a.pe2[col * a.pe2_ch + i] : a.pe2[row * a.pe2_ch + (i - a.pe2_ch)];
         ++p;
       }
       __syncthreads();
       if (a.concat_emb) {
-        linear_t(x, parts, a.proj_wt, a.proj_b, p * C, C, part);
+        linear_t<NT>(x, parts, a.proj_wt, a.proj_b, p * C, C, part);
       } else {
-        for (int i = tid; i < C; i += GPT_THREADS) {
+        for (int i = tid; i < C; i += NT) {
           float s = 0.0f;
           for (int q = 0; q < p; ++q) s += parts[q * C + i];
           x[i] = s / p;
@@ -181,11 +188,11 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
     }
     __syncthreads();
     if (a.out.final_emb)
-      for (int i = tid; i < C; i += GPT_THREADS) a.out.final_emb[((long long)b * a.emb_stride + len) * C + i] = x[i];
+      for (int i = tid; i < C; i += NT) a.out.final_emb[((long long)b * a.emb_stride + len) * C + i] = x[i];
     if (a.embed_only) { ++len; continue; }
     const bool drop = a.pdrop > 0.0f;
     if (drop) {                                           // x = transformer.drop(final_emb), gpt.py:525
-      for (int i = tid; i < C; i += GPT_THREADS) x[i] *= drop_scale(a.drop_seed, b, len, 0, 0, i, a.pdrop);
+      for (int i = tid; i < C; i += NT) x[i] *= drop_scale(a.drop_seed, b, len, 0, 0, i, a.pdrop);
       __syncthreads();
     }
 
@@ -194,13 +201,13 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
       const GptLayerPtrs L = a.layers[l];
       float* kc = a.kcache + (((long long)l * a.B + b) * a.Tmax) * C;
       float* vc = a.vcache + (((long long)l * a.B + b) * a.Tmax) * C;
-      layer_norm(h, x, L.ln1_w, L.ln1_b, C, red);
-      linear_t(qkv, h, L.qkv_wt, L.qkv_b, C, 3 * C, part);
+      layer_norm<NT>(h, x, L.ln1_w, L.ln1_b, C, red);
+      linear_t<NT>(qkv, h, L.qkv_wt, L.qkv_b, C, 3 * C, part);
       __syncthreads();
-      for (int i = tid; i < C; i += GPT_THREADS) { kc[len * C + i] = qkv[C + i]; vc[len * C + i] = qkv[2 * C + i]; }
+      for (int i = tid; i < C; i += NT) { kc[len * C + i] = qkv[C + i]; vc[len * C + i] = qkv[2 * C + i]; }
       __syncthreads();   // own-block global writes are visible to the block after the barrier
       const int nk = len + 1;
-      for (int e = tid; e < a.n_head * nk; e += GPT_THREADS) {
+      for (int e = tid; e < a.n_head * nk; e += NT) {
         const int hd = e / nk, s = e - hd * nk;
         const float* kp = (s == len) ? (qkv + C + hd * hs) : (kc + s * C + hd * hs);
         const float* qp = qkv + hd * hs;
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
           for (int s = 0; s < nk; ++s) ap[s] *= drop_scale(a.drop_seed, b, len, l, 1, tid * a.Tmax + s, a.pdrop);
       }
       __syncthreads();
-      for (int i = tid; i < C; i += GPT_THREADS) {
+      for (int i = tid; i < C; i += NT) {
         const int hd = i / hs;
         float acc = 0.0f;
         for (int s = 0; s < nk; ++s) {
@@ -231,18 +238,18 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
         h[i] = acc;
       }
       __syncthreads();
-      linear_t(qkv, h, L.proj_wt, L.proj_b, C, C, part);      // qkv[0:C] reused as scratch
+      linear_t<NT>(qkv, h, L.proj_wt, L.proj_b, C, C, part);      // qkv[0:C] reused as scratch
       __syncthreads();
-      for (int i = tid; i < C; i += GPT_THREADS) x[i] += drop ? qkv[i] * drop_scale(a.drop_seed, b, len, l, 2, i, a.pdrop) : qkv[i];
+      for (int i = tid; i < C; i += NT) x[i] += drop ? qkv[i] * drop_scale(a.drop_seed, b, len, l, 2, i, a.pdrop) : qkv[i];
       __syncthreads();
-      layer_norm(h, x, L.ln2_w, L.ln2_b, C, red);
-      linear_t(mlp, h, L.fc_wt, L.fc_b, C, 4 * C, part);
+      layer_norm<NT>(h, x, L.ln2_w, L.ln2_b, C, red);
+      linear_t<NT>(mlp, h, L.fc_wt, L.fc_b, C, 4 * C, part);
       __syncthreads();
-      for (int i = tid; i < 4 * C; i += GPT_THREADS) mlp[i] = gelu_tanh(mlp[i]);
+      for (int i = tid; i < 4 * C; i += NT) mlp[i] = gelu_tanh(mlp[i]);
       __syncthreads();
-      linear_t(qkv, mlp, L.fc2_wt, L.fc2_b, 4 * C, C, part);
+      linear_t<NT>(qkv, mlp, L.fc2_wt, L.fc2_b, 4 * C, C, part);
       __syncthreads();
-      for (int i = tid; i < C; i += GPT_THREADS) x[i] += drop ? qkv[i] * drop_scale(a.drop_seed, b, len, l, 3, i, a.pdrop) : qkv[i];
+      for (int i = tid; i < C; i += NT) x[i] += drop ? qkv[i] * drop_scale(a.drop_seed, b, len, l, 3, i, a.pdrop) : qkv[i];
       __syncthreads();
     }
     ++len;
@@ -253,8 +260,8 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
     return;
   }
   // ---------------- head on the newest token ----------------
-  layer_norm(h, x, a.lnf_w, a.lnf_b, C, red);
-  linear_t(lg, h, a.head_wt, nullptr, C, a.nA, part);
+  layer_norm<NT>(h, x, a.lnf_w, a.lnf_b, C, red);
+  linear_t<NT>(lg, h, a.head_wt, nullptr, C, a.nA, part);
   __syncthreads();
 
   if (a.src_mode != GPT_SRC_ENV) {
@@ -308,8 +315,10 @@ __global__ __launch_bounds__(GPT_THREADS) void gpt_step_kernel(GptStepArgs a) {
 }
 
 int launch_gpt_step(const GptStepArgs& a, hipStream_t s) {
-  const size_t smem = (size_t)(9 * a.C + a.n_head * a.Tmax + GPT_WAVES + 16 + 4 + 4 * GPT_THREADS) * sizeof(float);
-  hipLaunchKernelGGL(gpt_step_kernel, dim3(a.B), dim3(GPT_THREADS), smem, s, a);
+  const int nt = a.C <= 64 ? 256 : 1024;
+  const size_t smem = (size_t)(9 * a.C + a.n_head * a.Tmax + nt / 64 + 16 + 4 + 4 * nt) * sizeof(float);
+  if (nt == 256) hipLaunchKernelGGL(gpt_step_kernel<256>, dim3(a.B), dim3(256), smem, s, a);
+  else hipLaunchKernelGGL(gpt_step_kernel<1024>, dim3(a.B), dim3(1024), smem, s, a);
   return 0;
 }
 
