@@ -731,7 +731,8 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
   if (!train && (rc = refresh_eval_table(ctx, net, s))) return rc;
   // fp32 passes: the 1x1 weights of this net as three bf16 planes for pw_x3_kernel, from the CURRENT parameters (one
   // launch over the net's slice of the arena, ~4 us: cheaper and safer than tracking every writer of the arena)
-  const bool x3 = net.act_dtype == JN_F32 && ctx->params_x3 && !std::getenv("JN_NO_PW_X3");   // read per pass: tests flip it
+  // (bf16 inference mode uses the h plane alone: pw_x1)
+  const bool x3 = ctx->params_x3 && !std::getenv("JN_NO_PW_X3");   // read per pass: tests flip it
   if (x3) {
     if (net.x3_hi == 0) {
       size_t lo = ctx->arena_size, hi = 0;

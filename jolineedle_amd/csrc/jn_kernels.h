@@ -111,7 +111,9 @@ int launch_pw_wide(const ConvArgs& a, hipStream_t s);   // production route: 0 w
 bool pw_xs_supported(const ConvArgs& a);               // kernels_pwxs.hip: pixel-stationary kernel for the small maps of a forward pass
 int launch_pw_xs(const ConvArgs& a, int pt, hipStream_t s, int wg_per_cu = 0);   // pt: pixel tiles per workgroup (0 = default)
 int launch_pw_x3(const ConvArgs& a, int pt, hipStream_t s, int wg_per_cu = 0);   // the same on the bf16 pipe (three-way split operands); needs a.w_x3
-bool pw_x3_preferred(const ConvArgs& a);               // shapes on which the x3 kernel is the faster one
+bool pw_x3_preferred(const ConvArgs& a);
+bool pw_x1_supported(const ConvArgs& a);               // bf16 inference mode: single-plane form of the same kernel
+int launch_pw_x1(const ConvArgs& a, hipStream_t s);               // shapes on which the x3 kernel is the faster one
 void launch_w_split3(const float* w, void* w3, long long n_floats, hipStream_t s);   // w3: 6 bytes per weight
 int launch_spp(void* cat, int dtype, int ld, int h, int H, int W, int N, ChanTab it, const int* skip_flag,
                int skip_when, hipStream_t s);

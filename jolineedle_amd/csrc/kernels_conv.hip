@@ -1006,7 +1006,9 @@ static void launch_pw_types(const ConvArgs& a, hipStream_t s) {
 static int launch_pw_small_maps(const ConvArgs& a, hipStream_t s) {
   static const bool off = std::getenv("JN_NO_PW_XS") != nullptr;
   static const long long max_m = std::getenv("JN_XS_MAX_M") ? std::atoll(std::getenv("JN_XS_MAX_M")) : 262144;
-  if (off || (long long)a.N * a.H * a.W > max_m || !pw_xs_supported(a)) return -1;
+  if (off || (long long)a.N * a.H * a.W > max_m) return -1;
+  if (pw_x1_supported(a)) return launch_pw_x1(a, s);      // bf16 inference mode
+  if (!pw_xs_supported(a)) return -1;
   // fp32 operands as three bf16 planes on the bf16 matrix pipe where that is the faster kernel (a.w_x3 is null under
   // JN_NO_PW_X3=1: fp32 pipe)
   if (pw_x3_preferred(a) && launch_pw_x3(a, 0, s) == 0) return 0;

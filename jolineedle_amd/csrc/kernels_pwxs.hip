@@ -277,9 +277,11 @@ void launch_w_split3(const float* w, void* w3, long long n_floats, hipStream_t s
   hipLaunchKernelGGL(w_split3_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, w, (bf16_t*)w3, n8);
 }
 
-template <int K, int CTW, int PT, int D>
+// NP = 3, XT = float: the fp32 route.  NP = 1, XT = bf16: the bf16 inference mode on the same kernel — bf16 activations in
+// and out, ONE plane (the operand rounded to bf16, as that mode defines its products), the weights' h plane.
+template <int K, int CTW, int PT, int D, int NP, typename XT>
 __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_kernel(
-    const float* __restrict__ x, int x_ld, ChanTab it, const bf16_t* __restrict__ w3, float* __restrict__ out, int out_ld,
+    const XT* __restrict__ x, int x_ld, ChanTab it, const bf16_t* __restrict__ w3, XT* __restrict__ out, int out_ld,
     long long M, double* __restrict__ stats, long long rep_stride, int nrep, const int* __restrict__ skip_flag,
     int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
@@ -290,8 +292,8 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
   constexpr int NXB = NX < 16 ? NX : 16;
   static_assert(256 % KQ == 0 && NX >= 1 && NX % NXB == 0 && NJ % D == 0, "pw_x3 tile mapping");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16_t* Xp = reinterpret_cast<bf16_t*>(smem_raw);    // [3][BM][LDK]: h, m, l planes of the transformed operand
-  float* Tb = reinterpret_cast<float*>(Xp + 3 * BM * LDK);       // [3][K], later [N][2] statistics
+  bf16_t* Xp = reinterpret_cast<bf16_t*>(smem_raw);    // [NP][BM][LDK]: h, m, l planes of the transformed operand
+  float* Tb = reinterpret_cast<float*>(Xp + NP * BM * LDK);      // [3][K], later [N][2] statistics
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, g = lane >> 4;
   const long long n_tiles = (M + BM - 1) / BM;
@@ -300,13 +302,13 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
   const bf16_t* wrow[CTW];
 #pragma unroll
   for (int c = 0; c < CTW; ++c) wrow[c] = w3 + ((long long)((wave * CTW + c) * 16 + lm) * (K / 8) + g) * 24;
-  bf16x8 wr[D][CTW][3];
+  bf16x8 wr[D][CTW][NP];
 #pragma unroll
   for (int u = 0; u < D; ++u)
 #pragma unroll
     for (int c = 0; c < CTW; ++c)
 #pragma unroll
-      for (int t = 0; t < 3; ++t) wr[u][c][t] = *reinterpret_cast<const bf16x8*>(wrow[c] + 96 * u + 8 * t);
+      for (int t = 0; t < NP; ++t) wr[u][c][t] = *reinterpret_cast<const bf16x8*>(wrow[c] + 96 * u + 8 * t);
 
   const int q = tid % KQ, r0 = tid / KQ;
   constexpr int RS = 256 / KQ;
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
     for (int u = 0; u < NXB; ++u) {
       long long m = m0 + r0 + (long long)(b * NXB + u) * RS;
       m = m < M ? m : M - 1;
-      xr[u] = *reinterpret_cast<const f32x4*>(x + m * x_ld + 4 * q);
+      xr[u] = ld4(x + m * x_ld + 4 * q);
     }
   };
   long long tile = blockIdx.x;
@@ -341,14 +343,16 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
         f32x4 v = tf4_tab(xr[u], sc, sh, fl);
         if (m0 + r >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};
         const bf16x4 vh = __builtin_convertvector(v, bf16x4);
-        const f32x4 r1 = v - __builtin_convertvector(vh, f32x4);
-        const bf16x4 vm = __builtin_convertvector(r1, bf16x4);
-        const f32x4 r2 = r1 - __builtin_convertvector(vm, f32x4);
-        const bf16x4 vl = __builtin_convertvector(r2, bf16x4);
         bf16_t* dst = Xp + r * LDK + 4 * q;
         *reinterpret_cast<bf16x4*>(dst) = vh;
-        *reinterpret_cast<bf16x4*>(dst + BM * LDK) = vm;
-        *reinterpret_cast<bf16x4*>(dst + 2 * BM * LDK) = vl;
+        if constexpr (NP == 3) {
+          const f32x4 r1 = v - __builtin_convertvector(vh, f32x4);
+          const bf16x4 vm = __builtin_convertvector(r1, bf16x4);
+          const f32x4 r2 = r1 - __builtin_convertvector(vm, f32x4);
+          const bf16x4 vl = __builtin_convertvector(r2, bf16x4);
+          *reinterpret_cast<bf16x4*>(dst + BM * LDK) = vm;
+          *reinterpret_cast<bf16x4*>(dst + 2 * BM * LDK) = vl;
+        }
       }
     }
     __syncthreads();
@@ -365,27 +369,27 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
 #pragma unroll
       for (int u = 0; u < D; ++u) {
         const int j = j0 + u;
-        bf16x8 xa[PT][3], wa[CTW][3];
+        bf16x8 xa[PT][NP], wa[CTW][NP];
 #pragma unroll
         for (int p = 0; p < PT; ++p)
 #pragma unroll
-          for (int t = 0; t < 3; ++t) xa[p][t] = *reinterpret_cast<const bf16x8*>(xrow + t * BM * LDK + p * 16 * LDK + 32 * j);
+          for (int t = 0; t < NP; ++t) xa[p][t] = *reinterpret_cast<const bf16x8*>(xrow + t * BM * LDK + p * 16 * LDK + 32 * j);
 #pragma unroll
         for (int c = 0; c < CTW; ++c)
 #pragma unroll
-          for (int t = 0; t < 3; ++t) wa[c][t] = wr[u][c][t];
+          for (int t = 0; t < NP; ++t) wa[c][t] = wr[u][c][t];
         if constexpr (D < NJ) {
           const int jn = j + D < NJ ? j + D : j + D - NJ;
 #pragma unroll
           for (int c = 0; c < CTW; ++c)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) wr[u][c][t] = *reinterpret_cast<const bf16x8*>(wrow[c] + 96 * jn + 8 * t);
+            for (int t = 0; t < NP; ++t) wr[u][c][t] = *reinterpret_cast<const bf16x8*>(wrow[c] + 96 * jn + 8 * t);
           __builtin_amdgcn_sched_barrier(0);
         }
         // six products, the small ones first: (w, x) = (l, h) (h, l) (m, m) (m, h) (h, m) (h, h)
         constexpr int TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-        for (int e = 0; e < 6; ++e)
+        for (int e = (NP == 3 ? 0 : 5); e < 6; ++e)
 #pragma unroll
           for (int c = 0; c < CTW; ++c)
 #pragma unroll
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
       for (int p = 0; p < PT; ++p) {
         const long long m = m0 + 16 * p + lm;
         const f32x4 v = acc[c][p];
-        if (m < M) *reinterpret_cast<f32x4*>(out + m * out_ld + n) = v;
+        if (m < M) st4(out + m * out_ld + n, v);
         s1[c] += v; s2[c] += v * v;
       }
     }
@@ -427,11 +431,11 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
   }
 }
 
-template <int K, int CTW, int PT, int D>
+template <int K, int CTW, int PT, int D, int NP, typename XT>
 static void launch_pw_x3_t(const ConvArgs& a, long long M, int wg_per_cu, hipStream_t s) {
   constexpr int BM = 16 * PT;
-  const size_t smem = (size_t)3 * BM * (K + 16) * sizeof(bf16_t) + 3 * K * sizeof(float);
-  auto kern = pw_x3_kernel<K, CTW, PT, D>;
+  const size_t smem = (size_t)NP * BM * (K + 16) * sizeof(bf16_t) + 3 * K * sizeof(float);
+  auto kern = pw_x3_kernel<K, CTW, PT, D, NP, XT>;
   static int places = 0;
   if (!places) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -442,18 +446,41 @@ static void launch_pw_x3_t(const ConvArgs& a, long long M, int wg_per_cu, hipStr
   const long long n_tiles = (M + BM - 1) / BM;
   const int per_cu = std::max(1, std::min(places, wg_per_cu > 0 ? wg_per_cu : 2));
   const long long gx = std::min<long long>(n_tiles, 256LL * per_cu);
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), smem, s, (const float*)a.in, a.in_ld, a.itab, (const bf16_t*)a.w_x3,
-                     (float*)a.out, a.out_ld, M, a.stats, a.stats_rep_stride, a.stats_nrep > 0 ? a.stats_nrep : JN_NREP,
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), smem, s, (const XT*)a.in, a.in_ld, a.itab, (const bf16_t*)a.w_x3,
+                     (XT*)a.out, a.out_ld, M, a.stats, a.stats_rep_stride, a.stats_nrep > 0 ? a.stats_nrep : JN_NREP,
                      a.skip_flag, a.skip_when);
 }
 
 // Shapes the x3 kernel is built for — the ones where it beats pw_xs_kernel (tools/pwxsbench.hip, profiles/r03_x3bench.txt:
 // 8 - 21 %); with K >= 256 the weight fragments are streamed per tile and their 1.5x bytes cost more than the matrix
 // cycles saved, except for 256 -> 256 on 64-pixel tiles.
+static bool pw_xs_shape(int K, int N) {
+  if (!(K == 64 || K == 128 || K == 256 || K == 512) || !(N == 64 || N == 128 || N == 256)) return false;
+  return !(K == 64 && N == 256) && !(K == 512 && N != 256) && !(K == 256 && N == 64);
+}
+
 bool pw_x3_preferred(const ConvArgs& a) {
   if (!a.w_x3 || !pw_xs_supported(a)) return false;
   const int K = a.cin, N = a.cout;
   return (K == 64 && (N == 64 || N == 128)) || (K == 128 && (N == 64 || N == 128)) || (K == 256 && N == 256);
+}
+
+// bf16 inference mode (bf16 activations in and out, bf16 MFMA): the single-plane form of the kernel, every xs shape
+bool pw_x1_supported(const ConvArgs& a) {
+  return a.w_x3 && a.bf16_mfma && a.in_dtype == JN_BF16 && a.out_dtype == JN_BF16 && !a.bias && a.act == ACT_NONE && !a.w_transposed &&
+         !a.accumulate && a.n_slots <= 1 && pw_xs_shape(a.cin, a.cout) && a.in_ld % 4 == 0 && a.out_ld % 4 == 0;
+}
+
+int launch_pw_x1(const ConvArgs& a, hipStream_t s) {
+  if (!pw_x1_supported(a)) return -1;
+  const long long M = (long long)a.N * a.H * a.W;
+  const int K = a.cin, ctw = a.cout / 64;
+  const int wg = (K == 512 || ctw == 4) ? 1 : 2;
+#define JN_X1(K_, C_, P_, D_) if (K == K_ && ctw == C_) { launch_pw_x3_t<K_, C_, P_, D_, 1, bf16_t>(a, M, wg, s); return 0; }
+  JN_X1(64, 1, 2, 2) JN_X1(64, 2, 2, 2) JN_X1(128, 1, 2, 4) JN_X1(128, 2, 2, 4) JN_X1(128, 4, 2, 4)
+  JN_X1(256, 2, 4, 2) JN_X1(256, 4, 4, 2) JN_X1(512, 4, 4, 2)
+#undef JN_X1
+  return -1;
 }
 
 int launch_pw_x3(const ConvArgs& a, int pt, hipStream_t s, int wg_per_cu) {
@@ -466,7 +493,7 @@ int launch_pw_x3(const ConvArgs& a, int pt, hipStream_t s, int wg_per_cu) {
     pt = K == 256 ? 4 : 2;
     if (wg_per_cu == 0) wg_per_cu = (K == 256 || (K == 64 && ctw == 2) || (K == 128 && ctw == 2 && M <= 16384)) ? 1 : 2;
   }
-#define JN_X3(K_, C_, P_, D_) if (K == K_ && ctw == C_ && pt == P_) { launch_pw_x3_t<K_, C_, P_, D_>(a, M, wg_per_cu, s); return 0; }
+#define JN_X3(K_, C_, P_, D_) if (K == K_ && ctw == C_ && pt == P_) { launch_pw_x3_t<K_, C_, P_, D_, 3, float>(a, M, wg_per_cu, s); return 0; }
   JN_X3(64, 1, 2, 2) JN_X3(64, 2, 2, 2) JN_X3(128, 1, 2, 4) JN_X3(128, 2, 2, 4) JN_X3(256, 4, 4, 2)
 #ifdef JN_X3_ALL_SHAPES        // tools/pwxsbench.hip: every shape and tile size, to show where the kernel loses
   JN_X3(64, 1, 4, 2) JN_X3(64, 2, 4, 2) JN_X3(128, 1, 4, 4) JN_X3(128, 2, 4, 4) JN_X3(128, 4, 2, 2) JN_X3(128, 4, 4, 2)
