@@ -624,6 +624,17 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
       f32x4 acc[CTK];
 #pragma unroll
       for (int b = 0; b < CTK; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // RED2: the raw output of the conv behind the shortcut sum, in the layout of the accumulators (this lane's pixel,
+      // channels 16 b + 4 gq), requested BEFORE the matrix loop that hides its latency
+      f32x4 z2v[RED ? CTK : 1];
+      if constexpr (RED) {
+        const long long mz = m0 + wave * 16 + lm;
+#pragma unroll
+        for (int b = 0; b < CTK; ++b) {
+          z2v[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (red2_z && 16 * b < red_split && mz < M) z2v[b] = *reinterpret_cast<const f32x4*>(red2_z + mz * red2_ld + 16 * b + 4 * gq);
+        }
+      }
       const float* grow = Gs + (wave * 16 + lm) * LDG + 4 * gq;
       const float* wrow = Wt + lm * LDW + 4 * gq;
 #pragma unroll
@@ -659,7 +670,7 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
           f32x4 zv = *reinterpret_cast<const f32x4*>(As + (wave * 16 + lm) * LDA + ch);      // raw z of this pixel
           f32x4 i_sc = *reinterpret_cast<const f32x4*>(Cs + 7 * N + ch), i_sh = *reinterpret_cast<const f32x4*>(Cs + 7 * N + K + ch);
           if (red2_z && 16 * b < red_split) {          // (wave-uniform) RED2: the sums of this run go to the conv behind the shortcut sum
-            zv = m < M ? *reinterpret_cast<const f32x4*>(red2_z + m * red2_ld + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+            zv = z2v[b];
             i_sc = *reinterpret_cast<const f32x4*>(Cs + 7 * N + 11 * K + ch); i_sh = *reinterpret_cast<const f32x4*>(Cs + 7 * N + 12 * K + ch);
           }
 #pragma unroll
