@@ -90,7 +90,15 @@ struct ConvArgs {
   int n_slots;                           // pw: gridDim.z slots, pointers advance by the strides below (0 -> 1 slot)
   long long in_slot_stride, out_slot_stride, tab_slot_stride;
   const void* w_x3;                      // 1x1, fp32: the weights split into three bf16 planes (launch_w_split3), or null
+  // 1x1, train-mode forward: the first fold_C input channels are a bottleneck's shortcut sum that has NOT been formed yet:
+  // the kernel computes  sum = silu(fold_zsc * z + fold_zsh) + T_r(res)  while it stages its operand (the arithmetic of
+  // addact_kernel), writes it to its place (`in`) and uses it — the separate shortcut-add pass and its read-back are gone.
+  // Plain (finalised) tables only.  pw_narrow_fold_ok() tells whether the launch will be taken by a kernel that does this.
+  const float* fold_z; int fold_z_ld; const float* fold_zsc; const float* fold_zsh;
+  const float* fold_res; int fold_res_ld; const float* fold_rsc; const float* fold_rsh; const float* fold_rfl;
+  int fold_C;
 };
+bool pw_narrow_fold_ok(const ConvArgs& a);
 
 // eval-mode DWConv (depthwise 3x3 -> BN + SiLU -> pointwise 1x1) in one kernel; mtab = table of the depthwise output
 struct DwPwArgs {
