@@ -874,10 +874,10 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
           const Op& ad = net.ops[pending_add];
           pending_add = -1;
           const ChanTab zt = tab(ad.in), rt = tab(ad.res);
-          a.fold_z = (const float*)ptr(ad.in); a.fold_z_ld = ld(ad.in); a.fold_zsc = zt.sc; a.fold_zsh = zt.sh;
-          a.fold_res = (const float*)ptr(ad.res); a.fold_res_ld = ld(ad.res); a.fold_rsc = rt.sc; a.fold_rsh = rt.sh; a.fold_rfl = rt.fl;
+          a.fold_z = (const float*)ptr(ad.in); a.fold_z_ld = ld(ad.in); a.fold_zt = zt;
+          a.fold_res = (const float*)ptr(ad.res); a.fold_res_ld = ld(ad.res); a.fold_rt = rt;
           a.fold_C = ad.out.C;
-          if (op.kind != OP_PW || !pw_narrow_fold_ok(a)) {
+          if (op.kind != OP_PW || !pw_fold_ok(a)) {
             launch_addact(ptr(ad.in), ld(ad.in), zt, ptr(ad.res), ld(ad.res), rt, ptr(ad.out), ld(ad.out), net.act_dtype, ad.out.C,
                           (long long)N * ad.out.H * ad.out.W, skip_flag, skip_when, s);
             a.fold_C = 0; a.fold_z = nullptr; a.fold_res = nullptr;

@@ -948,8 +948,8 @@ static void launch_pw_narrow_t(const ConvArgs& a, long long M, hipStream_t s) {
   const unsigned gx = (unsigned)std::min<long long>(n_tiles, cap);
   dim3 grid(gx, (unsigned)((a.cout + 16 * CT - 1) / (16 * CT)));
   const size_t smem = (size_t)(BM + 16 * CT) * (KC + 4) * sizeof(float) + (BM / 32) * 32 * CT * sizeof(float);
-  const NarrowFold fold{a.fold_z, a.fold_z_ld, a.fold_zsc, a.fold_zsh, a.fold_res, a.fold_res_ld, a.fold_rsc, a.fold_rsh, a.fold_rfl,
-                        a.fold_C};
+  const NarrowFold fold{a.fold_z, a.fold_z_ld, a.fold_zt.sc, a.fold_zt.sh, a.fold_res, a.fold_res_ld, a.fold_rt.sc, a.fold_rt.sh,
+                        a.fold_rt.fl, a.fold_C};
   hipLaunchKernelGGL((pw_narrow_kernel<CT, KC>), grid, dim3(256), smem, s, (const float*)a.in, a.in_ld, a.itab, a.w,
                      (float*)a.out, a.out_ld, M, a.cout, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when,
                      a.stats_nrep > 0 ? a.stats_nrep : JN_NREP, fold);
@@ -961,7 +961,7 @@ static bool pw_narrow_shape(int nt, int K) {
 
 // will launch_pw hand this 1x1 layer to pw_narrow_kernel (the kernel that can form a shortcut sum while staging)?  The
 // routes ahead of it in launch_pw take K >= 64 only.
-bool pw_narrow_fold_ok(const ConvArgs& a) {
+static bool pw_narrow_fold_ok(const ConvArgs& a) {
   static const bool off = std::getenv("JN_NO_PW_NARROW") != nullptr || std::getenv("JN_NO_ADDACT_FOLD") != nullptr;
   if (off || a.bf16_mfma || a.in_dtype != JN_F32 || a.out_dtype != JN_F32 || a.w_transposed || a.accumulate || a.bias ||
       a.act != ACT_NONE || a.n_slots > 1 || a.cin > 32 || a.cout % 16)
@@ -1062,6 +1062,14 @@ static int launch_pw_small_maps(const ConvArgs& a, hipStream_t s) {
   // JN_NO_PW_X3=1: fp32 pipe)
   if (pw_x3_preferred(a) && launch_pw_x3(a, 0, s) == 0) return 0;
   return launch_pw_xs(a, 0, s);
+}
+
+bool pw_fold_ok(const ConvArgs& a) {
+  static const bool no_xs = std::getenv("JN_NO_PW_XS") != nullptr;
+  static const long long max_m = std::getenv("JN_XS_MAX_M") ? std::atoll(std::getenv("JN_XS_MAX_M")) : 262144;
+  if (!no_xs && (long long)a.N * a.H * a.W <= max_m && !pw_x1_supported(a) && pw_xs_supported(a))     // the small-map route takes it
+    return pw_x3_preferred(a) && pw_x3_fold_ok(a);
+  return pw_narrow_fold_ok(a);
 }
 
 int launch_pw(const ConvArgs& a, hipStream_t s) {
