@@ -485,7 +485,191 @@ static void launch_conv3_x3(const ConvArgs& a, hipStream_t s) {
                      a.stats_rep_stride, a.skip_flag, a.skip_when, a.in_slot_stride, a.out_slot_stride);
 }
 
-// fp32 activations, K a multiple of 32 (every dense 3x3 layer of yolox-s / -m / -l); JN_NO_CONV3_X3=1: fp32 matrix pipe
+// ---- stride 2 on the same scheme: parity classes -----------------------------------------------------------------
+// A stride-2 3x3 conv reads, per output pixel, input rows 2 oy - 1 .. 2 oy + 1: split the input into its four parity
+// classes (row parity py, column parity px) and every class is a STRIDE-1 problem on a (TH + 1) x 17 block grid with 4 / 2 /
+// 2 / 1 of the nine taps: class (1, 1): taps (0|2, 0|2); (1, 0): (0|2, 1); (0, 1): (1, 0|2); (0, 0): (1, 1) — tap k = 0 sits
+// one block back, k = 1, 2 in the output pixel's own block.  The class tile (17 x 17 pixels x 32 k x three planes = 83 KB) and
+// at most two taps of the weight chunk (37 KB) share the LDS: five phases per K chunk (class (1, 1) takes two), every input
+// value staged once, the next phase's tile / weights in flight under the matrix loop.  The stride-1 kernel's LDS halo tile at
+// stride 2 would be 34 x 34 pixels (333 KB); with one row per wave (the 4 x 16 tile that fits) the operand reads exceeded
+// the LDS rate (measured 5 % slower than the fp32 kernel).
+template <int PR, int NW>
+__global__ __launch_bounds__(64 * NW) void conv3_x3s2_kernel(const float* __restrict__ x, int x_ld, ChanTab it,
+                                                         const float* __restrict__ w, float* __restrict__ out, int out_ld,
+                                                         int H, int W, int OH, int OW, int K, int Nc, int tiles_x, int tiles_y,
+                                                         double* __restrict__ stats, long long rep_stride,
+                                                         const int* __restrict__ skip_flag, int skip_when) {
+  if (skip_flag && *skip_flag >= skip_when) return;
+  constexpr int NT = 64 * NW, TH = NW * PR, BH = TH + 1, BW = C3_TW + 1, NP = BH * BW;
+  constexpr int XPL = NP * C3X_LD, WPL = 2 * C3_BN * C3X_LD;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_x3[];
+  bf16_t* Xp = reinterpret_cast<bf16_t*>(smem_x3);                  // [3 planes][NP][C3X_LD]   one parity class
+  bf16_t* Wp = Xp + 3 * XPL;                                        // [3 planes][2 taps][C3_BN][C3X_LD]
+  float* red = reinterpret_cast<float*>(Wp + 3 * WPL);              // [NW waves][C3_BN][2]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, g = lane >> 4;
+  const int tile = blockIdx.x % (tiles_x * tiles_y);
+  const int n_img = blockIdx.x / (tiles_x * tiles_y);
+  const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * C3_TW;
+  const int n0 = blockIdx.y * C3_BN;
+  const float* xb = x + (long long)n_img * H * W * x_ld;
+  f32x4 acc[PR][4];
+#pragma unroll
+  for (int p = 0; p < PR; ++p)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int NXR = (NP * 8 + NT - 1) / NT;            // f32x4 of a class tile per thread
+  constexpr int NWR = (2 * C3_BN * 8 + NT - 1) / NT;     // f32x4 of two taps of the weight chunk per thread
+  f32x4 xr[NXR], wr[NWR];
+  f32x4 t_sc = {1.f, 1.f, 1.f, 1.f}, t_sh = {0.f, 0.f, 0.f, 0.f}, t_fl = {0.f, 0.f, 0.f, 0.f};
+  // phases of a K chunk: parity class (2 py + px), its taps (ky * 3 + kx; the second one repeated when there is one), whether
+  // the class tile is new
+  constexpr int PH_CLS[5] = {3, 3, 2, 1, 0}, PH_NTAP[5] = {2, 2, 2, 2, 1}, PH_T0[5] = {0, 6, 1, 3, 4}, PH_T1[5] = {2, 8, 7, 5, 4};
+  constexpr int PH_NEWX[5] = {1, 0, 1, 1, 1};
+  auto fetch_x = [&](int k0, int cls) {
+    const int py = cls >> 1, px = cls & 1;
+    const int kq = k0 + 4 * (tid & 7);
+    t_sc = *reinterpret_cast<const f32x4*>(it.sc + kq); t_sh = *reinterpret_cast<const f32x4*>(it.sh + kq);
+    t_fl = *reinterpret_cast<const f32x4*>(it.fl + kq);
+#pragma unroll
+    for (int j = 0; j < NXR; ++j) {
+      const int i = tid + NT * j, pix = i >> 3;
+      const int iy = 2 * (oy0 - 1 + pix / BW) + py, ix = 2 * (ox0 - 1 + pix % BW) + px;
+      xr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < NP * 8 && iy >= 0 && iy < H && ix >= 0 && ix < W)
+        xr[j] = *reinterpret_cast<const f32x4*>(xb + ((long long)iy * W + ix) * x_ld + kq);
+    }
+  };
+  auto fetch_w = [&](int k0, int t0, int t1) {
+#pragma unroll
+    for (int j = 0; j < NWR; ++j) {
+      const int i = tid + NT * j, q = i & 7, r = (i >> 3) % C3_BN, ti = i / (8 * C3_BN);
+      const int tp = ti == 0 ? t0 : t1;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (i < 2 * C3_BN * 8 && n0 + r < Nc) v = *reinterpret_cast<const f32x4*>(w + ((long long)tp * Nc + n0 + r) * K + k0 + 4 * q);
+      wr[j] = v;
+    }
+  };
+  auto split3 = [](bf16_t* dst, int plane_stride, f32x4 v) {
+    const bf16x4 h = __builtin_convertvector(v, bf16x4);
+    const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
+    const bf16x4 m = __builtin_convertvector(r1, bf16x4);
+    const bf16x4 l = __builtin_convertvector(r1 - __builtin_convertvector(m, f32x4), bf16x4);
+    *reinterpret_cast<bf16x4*>(dst) = h;
+    *reinterpret_cast<bf16x4*>(dst + plane_stride) = m;
+    *reinterpret_cast<bf16x4*>(dst + 2 * plane_stride) = l;
+  };
+  fetch_x(0, PH_CLS[0]);
+  fetch_w(0, PH_T0[0], PH_T1[0]);
+  for (int k0 = 0; k0 < K; k0 += C3X_KC) {
+#pragma unroll
+    for (int ph = 0; ph < 5; ++ph) {
+      __syncthreads();                                 // the previous phase's readers are done
+      if (PH_NEWX[ph]) {
+        const int py = PH_CLS[ph] >> 1, px = PH_CLS[ph] & 1;
+#pragma unroll
+        for (int j = 0; j < NXR; ++j) {
+          const int i = tid + NT * j, pix = i >> 3, q = i & 7;
+          if (i < NP * 8) {
+            const int iy = 2 * (oy0 - 1 + pix / BW) + py, ix = 2 * (ox0 - 1 + pix % BW) + px;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};              // padding stays 0 (not silu(shift))
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = tf4_d(xr[j], t_sc, t_sh, t_fl);
+            split3(Xp + pix * C3X_LD + 4 * q, XPL, v);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NWR; ++j) {
+        const int i = tid + NT * j, q = i & 7, r = (i >> 3) % C3_BN, ti = i / (8 * C3_BN);
+        if (i < 2 * C3_BN * 8) split3(Wp + (ti * C3_BN + r) * C3X_LD + 4 * q, WPL, wr[j]);
+      }
+      __syncthreads();
+      // next phase's operands into registers under this phase's matrix loop
+      if (ph < 4) {
+        fetch_w(k0, PH_T0[ph + 1], PH_T1[ph + 1]);
+        if (PH_NEWX[ph + 1]) fetch_x(k0, PH_CLS[ph + 1]);
+      } else if (k0 + C3X_KC < K) {
+        fetch_w(k0 + C3X_KC, PH_T0[0], PH_T1[0]);
+        fetch_x(k0 + C3X_KC, PH_CLS[0]);
+      }
+#pragma unroll
+      for (int ti = 0; ti < PH_NTAP[ph]; ++ti) {
+        const int tp = ti == 0 ? PH_T0[ph] : PH_T1[ph];
+        const int dr = (tp / 3) == 0 ? 0 : 1, dc = (tp % 3) == 0 ? 0 : 1;      // tap 0: one block back; taps 1, 2: this block
+        bf16x8 xv[PR][3];
+#pragma unroll
+        for (int p = 0; p < PR; ++p)
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            xv[p][t] = *reinterpret_cast<const bf16x8*>(Xp + t * XPL + ((PR * wave + p + dr) * BW + lm + dc) * C3X_LD + 8 * g);
+#pragma unroll
+        for (int c2 = 0; c2 < 4; c2 += 2) {
+          bf16x8 wa[2][3];
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+              wa[cc][t] = *reinterpret_cast<const bf16x8*>(Wp + t * WPL + (ti * C3_BN + 16 * (c2 + cc) + lm) * C3X_LD + 8 * g);
+          constexpr int TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+          for (int e = 0; e < 6; ++e)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+              for (int p = 0; p < PR; ++p)
+                acc[p][c2 + cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cc][TW[e]], xv[p][TX[e]], acc[p][c2 + cc], 0, 0, 0);
+        }
+      }
+    }
+  }
+  f32x4 s1[4], s2[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { s1[c] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[c] = s1[c]; }
+#pragma unroll
+  for (int p = 0; p < PR; ++p) {
+    const int oy = oy0 + PR * wave + p, ox = ox0 + lm;
+    if (oy >= OH || ox >= OW) continue;
+    float* op = out + (((long long)n_img * OH + oy) * OW + ox) * out_ld;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int n = n0 + 16 * c + 4 * g;
+      if (n < Nc) {
+        const f32x4 v = acc[p][c];
+        *reinterpret_cast<f32x4*>(op + n) = v;
+        s1[c] += v;
+        s2[c] += v * v;
+      }
+    }
+  }
+  if (stats) {
+    wave_stats_to_lds<4>(s1, s2, red + wave * 2 * C3_BN, lane, Nc - n0);
+    __syncthreads();
+    if (tid < 2 * C3_BN && n0 + (tid >> 1) < Nc) {
+      float sum = 0.0f;
+#pragma unroll
+      for (int wv = 0; wv < NW; ++wv) sum += red[wv * 2 * C3_BN + tid];
+      atomicAdd(&stats[(blockIdx.x % JN_NREP) * rep_stride + 2 * n0 + tid], (double)sum);
+    }
+  }
+}
+
+static void launch_conv3_x3s2(const ConvArgs& a, hipStream_t s) {
+  constexpr int PR = 2, NW = 8, TH = NW * PR;
+  const int tiles_x = (a.OW + C3_TW - 1) / C3_TW, tiles_y = (a.OH + TH - 1) / TH;
+  dim3 grid(tiles_x * tiles_y * a.N, (a.cout + C3_BN - 1) / C3_BN);
+  const size_t smem = ((size_t)3 * (TH + 1) * (C3_TW + 1) * C3X_LD + (size_t)3 * 2 * C3_BN * C3X_LD) * sizeof(bf16_t) +
+                      (size_t)NW * 2 * C3_BN * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_x3s2_kernel<PR, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3_x3s2_kernel<PR, NW>), grid, dim3(64 * NW), smem, s, (const float*)a.in, a.in_ld, a.itab, a.w,
+                     (float*)a.out, a.out_ld, a.H, a.W, a.OH, a.OW, a.cin, a.cout, tiles_x, tiles_y, a.stats, a.stats_rep_stride,
+                     a.skip_flag, a.skip_when);
+}
+
 // fp32 activations, K a multiple of 32 (every dense 3x3 layer of yolox-s / -m / -l), stride 1; JN_NO_CONV3_X3=1 (read per
 // launch): fp32 matrix pipe.  Stride 2 stays on the fp32 kernel: its halo tile leaves room for one row per wave only, the
 // operand reads of the three planes then need more than the LDS delivers (measured: 5 % slower).
@@ -500,6 +684,20 @@ static bool conv3_x3_ok(const ConvArgs& a) {
   const long long slots = a.n_slots > 1 ? a.n_slots : 1, nbo = (a.cout + C3_BN - 1) / C3_BN, tx = (a.OW + C3_TW - 1) / C3_TW;
   const long long wg_f32 = tx * ((a.OH + 7) / 8) * a.N * nbo * slots, wg_x3 = tx * ((a.OH + 15) / 16) * a.N * nbo * slots;
   const double cost_f32 = (double)((wg_f32 + 511) / 512), cost_x3 = 0.65 * (double)((wg_x3 + 255) / 256);
+  return cost_x3 < cost_f32;
+}
+
+// stride 2 forward on the parity-class kernel: whole rounds again (16 x 16 output tiles on a CU of their own against 4 x 16 fp32
+// tiles, two workgroups per CU); JN_NO_CONV3_X3S2=1 / JN_NO_CONV3_X3=1: fp32 matrix pipe
+static bool conv3_x3s2_ok(const ConvArgs& a) {
+  if (std::getenv("JN_NO_CONV3_X3") || std::getenv("JN_NO_CONV3_X3S2") || a.stride != 2 || a.in_dtype != JN_F32 || a.out_dtype != JN_F32 ||
+      a.cin % 32 || a.cout % 4 || a.in_ld % 4 || a.out_ld % 4 || a.bias || a.act != ACT_NONE || a.accumulate || a.n_slots > 1 ||
+      a.w_transposed)
+    return false;
+  const long long nbo = (a.cout + C3_BN - 1) / C3_BN, tx = (a.OW + C3_TW - 1) / C3_TW;
+  const long long wg_f32 = tx * ((a.OH + 3) / 4) * a.N * nbo, wg_x3 = tx * ((a.OH + 15) / 16) * a.N * nbo;
+  // an fp32 workgroup is 4 rows, two per CU: a round of 512 of them covers what 128 x3 workgroups cover
+  const double cost_f32 = (double)((wg_f32 + 511) / 512) * 0.5, cost_x3 = 0.65 * (double)((wg_x3 + 255) / 256);
   return cost_x3 < cost_f32;
 }
 
@@ -539,6 +737,7 @@ int launch_conv3(const ConvArgs& a, hipStream_t s) {
   }
   if (a.in_dtype == JN_BF16) { if (a.stride == 1) launch_conv3_t<1, bf16_t, false>(a, s); else launch_conv3_t<2, bf16_t, false>(a, s); }
   else if (conv3_x3_ok(a)) launch_conv3_x3<1, false, 2, 8>(a, s);
+  else if (conv3_x3s2_ok(a)) launch_conv3_x3s2(a, s);
   else { if (a.stride == 1) launch_conv3_t<1, float, false>(a, s); else launch_conv3_t<2, float, false>(a, s); }
   return 0;
 }
