@@ -812,7 +812,6 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
     for (auto& e : lev) (void)hipEventCreate(&e);
     (void)hipEventRecord(lev[0], s);
   }
-  int pending_add = -1;                                 // a shortcut add held back for the 1x1 layer that follows it
   for (int oi = 0; oi < n_ops; ++oi) {
     const Op& op = net.ops[oi];
     switch (op.kind) {
@@ -868,21 +867,6 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
         a.stats_rep_stride = rep_stride;
         a.stats_nrep = deferred(op) ? JN_NREP_DEFER : JN_NREP;
         a.skip_flag = skip_flag; a.skip_when = skip_when;
-        if (pending_add >= 0) {
-          // the shortcut add right before this 1x1 layer was held back: formed inside the layer's kernel if that kernel can
-          // (pw_narrow_kernel, plain tables), launched now otherwise
-          const Op& ad = net.ops[pending_add];
-          pending_add = -1;
-          const ChanTab zt = tab(ad.in), rt = tab(ad.res);
-          a.fold_z = (const float*)ptr(ad.in); a.fold_z_ld = ld(ad.in); a.fold_zt = zt;
-          a.fold_res = (const float*)ptr(ad.res); a.fold_res_ld = ld(ad.res); a.fold_rt = rt;
-          a.fold_C = ad.out.C;
-          if (op.kind != OP_PW || !pw_fold_ok(a)) {
-            launch_addact(ptr(ad.in), ld(ad.in), zt, ptr(ad.res), ld(ad.res), rt, ptr(ad.out), ld(ad.out), net.act_dtype, ad.out.C,
-                          (long long)N * ad.out.H * ad.out.W, skip_flag, skip_when, s);
-            a.fold_C = 0; a.fold_z = nullptr; a.fold_res = nullptr;
-          }
-        }
         if (op.kind == OP_PW) launch_pw(a, s); else if (op.kind == OP_DW) launch_dw(a, s); else launch_conv3(a, s);
         finalize(op, cw);
         break;
@@ -896,13 +880,6 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
                         skip_when, s);
         break;
       case OP_ADDACT:
-        // train mode, fp32: if the very next op is the 1x1 layer that reads this sum as the head of its input, hold the add
-        // back — that layer's kernel may form it while staging (ConvArgs::fold_*); the PW case launches it otherwise
-        if (train && net.act_dtype == JN_F32 && oi + 1 < n_ops && net.ops[oi + 1].kind == OP_PW &&
-            net.ops[oi + 1].in.buf == op.out.buf && net.ops[oi + 1].in.coff == op.out.coff && net.ops[oi + 1].in.C >= op.out.C) {
-          pending_add = oi;
-          break;
-        }
         launch_addact(ptr(op.in), ld(op.in), tab(op.in), ptr(op.res), ld(op.res), tab(op.res), ptr(op.out), ld(op.out),
                       net.act_dtype, op.out.C, (long long)N * op.out.H * op.out.W, skip_flag, skip_when, s);
         break;

@@ -90,15 +90,7 @@ struct ConvArgs {
   int n_slots;                           // pw: gridDim.z slots, pointers advance by the strides below (0 -> 1 slot)
   long long in_slot_stride, out_slot_stride, tab_slot_stride;
   const void* w_x3;                      // 1x1, fp32: the weights split into three bf16 planes (launch_w_split3), or null
-  // 1x1, train-mode forward: the first fold_C input channels are a bottleneck's shortcut sum that has NOT been formed yet:
-  // the kernel computes  sum = silu(fold_zsc * z + fold_zsh) + T_r(res)  while it stages its operand (the arithmetic of
-  // addact_kernel), writes it to its place (`in`) and uses it — the separate shortcut-add pass and its read-back are gone.
-  // pw_fold_ok() tells whether the launch will be taken by a kernel that does this.
-  const float* fold_z; int fold_z_ld; ChanTab fold_zt;
-  const float* fold_res; int fold_res_ld; ChanTab fold_rt;
-  int fold_C;
 };
-bool pw_fold_ok(const ConvArgs& a);        // the route launch_pw will take forms the shortcut sum (pw_narrow_kernel: plain tables; pw_x3_kernel)
 
 // eval-mode DWConv (depthwise 3x3 -> BN + SiLU -> pointwise 1x1) in one kernel; mtab = table of the depthwise output
 struct DwPwArgs {
@@ -118,7 +110,6 @@ int launch_pw_dir(const ConvArgs& a, int ctw, int split, hipStream_t s);
 int launch_pw_wide(const ConvArgs& a, hipStream_t s);   // production route: 0 when taken
 bool pw_xs_supported(const ConvArgs& a);               // kernels_pwxs.hip: pixel-stationary kernel for the small maps of a forward pass
 int launch_pw_xs(const ConvArgs& a, int pt, hipStream_t s, int wg_per_cu = 0);   // pt: pixel tiles per workgroup (0 = default)
-bool pw_x3_fold_ok(const ConvArgs& a);
 int launch_pw_x3(const ConvArgs& a, int pt, hipStream_t s, int wg_per_cu = 0);   // the same on the bf16 pipe (three-way split operands); needs a.w_x3
 bool pw_x3_preferred(const ConvArgs& a);
 bool pw_x1_supported(const ConvArgs& a);               // bf16 inference mode: single-plane form of the same kernel

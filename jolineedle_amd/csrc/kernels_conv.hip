@@ -791,21 +791,11 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
 // compute, then all store.  This variant is persistent over pixel tiles: the weight tile is staged ONCE, the next
 // tile's pixels are fetched into registers while the MFMAs and stores of the current one run, the per-thread table
 // quad sits in registers and the BatchNorm sums stay in registers across tiles (one set of fp64 atomics per workgroup).
-// Shortcut fold (round 3): the first fold.C input channels are formed here, while the operand is staged, from the raw
-// output z of the bottleneck's last pointwise conv and the residual (ConvArgs::fold_*), and written to their place as a
-// side output: bit for bit what addact_kernel computes, without its pass (2 reads + 1 write + a launch) and without
-// reading the sum back.
-struct NarrowFold {
-  const float* z; int z_ld; const float* zsc; const float* zsh;
-  const float* res; int res_ld; const float* rsc; const float* rsh; const float* rfl;
-  int C;
-};
-
 template <int CT, int KC>
 __global__ __launch_bounds__(256) void pw_narrow_kernel(
     const float* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, float* __restrict__ out, int out_ld,
     long long M, int Nc, double* __restrict__ stats, long long rep_stride, const int* __restrict__ skip_flag,
-    int skip_when, int nrep, NarrowFold fold) {
+    int skip_when, int nrep) {
   if (skip_flag && *skip_flag >= skip_when) return;
   // waves along the pixel dimension: 2 (64-pixel tiles, wave pairs split the channel tiles) or, for a single channel
   // tile, 4 (128-pixel tiles)
@@ -842,27 +832,13 @@ __global__ __launch_bounds__(256) void pw_narrow_kernel(
     t_fl = *reinterpret_cast<const f32x4*>(it.fl + 4 * q);
   }
   const long long n_tiles = (M + BM - 1) / BM;
-  const bool fq = 4 * q < fold.C;                      // this thread's quad belongs to the shortcut sum formed here
-  f32x4 z_sc = {1.f, 1.f, 1.f, 1.f}, z_sh = {0.f, 0.f, 0.f, 0.f}, r_sc = z_sc, r_sh = z_sh, r_fl = z_sh;
-  if (fq) {
-    z_sc = *reinterpret_cast<const f32x4*>(fold.zsc + 4 * q); z_sh = *reinterpret_cast<const f32x4*>(fold.zsh + 4 * q);
-    r_sc = *reinterpret_cast<const f32x4*>(fold.rsc + 4 * q); r_sh = *reinterpret_cast<const f32x4*>(fold.rsh + 4 * q);
-    r_fl = *reinterpret_cast<const f32x4*>(fold.rfl + 4 * q);
-  }
-  f32x4 xr[NX], xr2[NX];
+  f32x4 xr[NX];
   auto fetch = [&](long long m0) {
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
       const long long m = m0 + r0 + (256 / Q4) * j;
-      xr[j] = f32x4{0.f, 0.f, 0.f, 0.f}; xr2[j] = xr[j];
-      if (m < M) {
-        if (fq) {
-          xr[j] = *reinterpret_cast<const f32x4*>(fold.z + m * fold.z_ld + 4 * q);
-          xr2[j] = *reinterpret_cast<const f32x4*>(fold.res + m * fold.res_ld + 4 * q);
-        } else {
-          xr[j] = *reinterpret_cast<const f32x4*>(x + m * x_ld + 4 * q);
-        }
-      }
+      xr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (m < M) xr[j] = *reinterpret_cast<const f32x4*>(x + m * x_ld + 4 * q);
     }
   };
   f32x4 s1[CTW], s2[CTW];
@@ -877,14 +853,7 @@ __global__ __launch_bounds__(256) void pw_narrow_kernel(
     for (int j = 0; j < NX; ++j) {
       const int r = r0 + (256 / Q4) * j;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m0 + r < M) {
-        if (fq) {
-          v = tf4(xr[j], z_sc, z_sh, f32x4{1.f, 1.f, 1.f, 1.f}) + tf4(xr2[j], r_sc, r_sh, r_fl);
-          if (blockIdx.y == 0) *reinterpret_cast<f32x4*>(const_cast<float*>(x) + (m0 + r) * x_ld + 4 * q) = v;
-        } else {
-          v = tf4(xr[j], t_sc, t_sh, t_fl);
-        }
-      }
+      if (m0 + r < M) v = tf4(xr[j], t_sc, t_sh, t_fl);
       *reinterpret_cast<f32x4*>(Xs + r * LD + 4 * q) = v;
     }
     __syncthreads();
@@ -948,27 +917,9 @@ static void launch_pw_narrow_t(const ConvArgs& a, long long M, hipStream_t s) {
   const unsigned gx = (unsigned)std::min<long long>(n_tiles, cap);
   dim3 grid(gx, (unsigned)((a.cout + 16 * CT - 1) / (16 * CT)));
   const size_t smem = (size_t)(BM + 16 * CT) * (KC + 4) * sizeof(float) + (BM / 32) * 32 * CT * sizeof(float);
-  const NarrowFold fold{a.fold_z, a.fold_z_ld, a.fold_zt.sc, a.fold_zt.sh, a.fold_res, a.fold_res_ld, a.fold_rt.sc, a.fold_rt.sh,
-                        a.fold_rt.fl, a.fold_C};
   hipLaunchKernelGGL((pw_narrow_kernel<CT, KC>), grid, dim3(256), smem, s, (const float*)a.in, a.in_ld, a.itab, a.w,
                      (float*)a.out, a.out_ld, M, a.cout, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when,
-                     a.stats_nrep > 0 ? a.stats_nrep : JN_NREP, fold);
-}
-
-static bool pw_narrow_shape(int nt, int K) {
-  return (nt == 1 && K == 16) || (nt == 2 && (K == 16 || K == 32)) || (nt == 4 && (K == 32 || K == 64)) || (nt == 8 && K == 64);
-}
-
-// will launch_pw hand this 1x1 layer to pw_narrow_kernel (the kernel that can form a shortcut sum while staging)?  The
-// routes ahead of it in launch_pw take K >= 64 only.
-static bool pw_narrow_fold_ok(const ConvArgs& a) {
-  static const bool off = std::getenv("JN_NO_PW_NARROW") != nullptr || std::getenv("JN_NO_ADDACT_FOLD") != nullptr;
-  if (off || a.bf16_mfma || a.in_dtype != JN_F32 || a.out_dtype != JN_F32 || a.w_transposed || a.accumulate || a.bias ||
-      a.act != ACT_NONE || a.n_slots > 1 || a.cin > 32 || a.cout % 16)
-    return false;
-  const long long M = (long long)a.N * a.H * a.W;
-  const char* mm = std::getenv("JN_PWN_MIN_M");
-  return M >= (mm ? std::atoll(mm) : 65536) && M > jn_defer_max_m() && pw_narrow_shape(a.cout / 16, a.cin);
+                     a.stats_nrep > 0 ? a.stats_nrep : JN_NREP);
 }
 
 // true when the persistent narrow kernel took the launch
@@ -1062,14 +1013,6 @@ static int launch_pw_small_maps(const ConvArgs& a, hipStream_t s) {
   // JN_NO_PW_X3=1: fp32 pipe)
   if (pw_x3_preferred(a) && launch_pw_x3(a, 0, s) == 0) return 0;
   return launch_pw_xs(a, 0, s);
-}
-
-bool pw_fold_ok(const ConvArgs& a) {
-  static const bool no_xs = std::getenv("JN_NO_PW_XS") != nullptr;
-  static const long long max_m = std::getenv("JN_XS_MAX_M") ? std::atoll(std::getenv("JN_XS_MAX_M")) : 262144;
-  if (!no_xs && (long long)a.N * a.H * a.W <= max_m && !pw_x1_supported(a) && pw_xs_supported(a))     // the small-map route takes it
-    return pw_x3_preferred(a) && pw_x3_fold_ok(a);
-  return pw_narrow_fold_ok(a);
 }
 
 int launch_pw(const ConvArgs& a, hipStream_t s) {

@@ -279,17 +279,11 @@ void launch_w_split3(const float* w, void* w3, long long n_floats, hipStream_t s
 
 // NP = 3, XT = float: the fp32 route.  NP = 1, XT = bf16: the bf16 inference mode on the same kernel — bf16 activations in
 // and out, ONE plane (the operand rounded to bf16, as that mode defines its products), the weights' h plane.
-// Shortcut fold (ConvArgs::fold_*): the first fold.C operand channels are formed while staging — silu(bn(z)) + T(res), the
-// arithmetic of addact_kernel — and written to their place; tables may be deferred (derived here like the operand's own).
-struct XFold {
-  const float* z; int z_ld; ChanTab zt; const float* res; int res_ld; ChanTab rt; int C;
-};
-
 template <int K, int CTW, int PT, int D, int NP, typename XT>
 __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_kernel(
     const XT* __restrict__ x, int x_ld, ChanTab it, const bf16_t* __restrict__ w3, XT* __restrict__ out, int out_ld,
     long long M, double* __restrict__ stats, long long rep_stride, int nrep, const int* __restrict__ skip_flag,
-    int skip_when, XFold fold) {
+    int skip_when) {
   if (skip_flag && *skip_flag >= skip_when) return;
   // LDK: row stride 2 K + 32 bytes = 32 x odd: the 16-lane groups of a ds_read_b128 ({0-3, 12-15, 20-27}, ...: rows lm at
   // 16 g bytes) then cover the 64 banks exactly once (with K + 8 the planes read at 37 - 39 % conflict cycles, PMC)
@@ -299,7 +293,7 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
   static_assert(256 % KQ == 0 && NX >= 1 && NX % NXB == 0 && NJ % D == 0, "pw_x3 tile mapping");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Xp = reinterpret_cast<bf16_t*>(smem_raw);    // [NP][BM][LDK]: h, m, l planes of the transformed operand
-  float* Tb = reinterpret_cast<float*>(Xp + NP * BM * LDK);      // [3][K], later [N][2] statistics; fold: + [3][K] + [3][K]
+  float* Tb = reinterpret_cast<float*>(Xp + NP * BM * LDK);      // [3][K], later [N][2] statistics
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, g = lane >> 4;
   const long long n_tiles = (M + BM - 1) / BM;
@@ -318,40 +312,21 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
 
   const int q = tid % KQ, r0 = tid / KQ;
   constexpr int RS = 256 / KQ;
-  constexpr bool FOLD = NP == 3;                     // fp32 train-mode route only
-  const bool fq = FOLD && 4 * q < fold.C;            // this thread's quad belongs to the shortcut sum formed here
-  f32x4 xr[NXB], xr2[FOLD ? NXB : 1];
+  f32x4 xr[NXB];
   auto fetch = [&](long long m0, int b) {
 #pragma unroll
     for (int u = 0; u < NXB; ++u) {
       long long m = m0 + r0 + (long long)(b * NXB + u) * RS;
       m = m < M ? m : M - 1;
-      if constexpr (FOLD) {
-        if (fq) {
-          xr[u] = *reinterpret_cast<const f32x4*>(fold.z + m * fold.z_ld + 4 * q);
-          xr2[u] = *reinterpret_cast<const f32x4*>(fold.res + m * fold.res_ld + 4 * q);
-          continue;
-        }
-      }
       xr[u] = ld4(x + m * x_ld + 4 * q);
     }
   };
   long long tile = blockIdx.x;
   fetch(tile * BM, 0);
   tab_to_lds(Tb, K, K, it, tid, 256);
-  if (FOLD && fold.C > 0) {
-    tab_to_lds(Tb + 3 * K, K, fold.C, fold.zt, tid, 256);
-    tab_to_lds(Tb + 6 * K, K, fold.C, fold.rt, tid, 256);
-  }
   __syncthreads();
   const f32x4 sc = *reinterpret_cast<const f32x4*>(Tb + 4 * q), sh = *reinterpret_cast<const f32x4*>(Tb + K + 4 * q),
               fl = *reinterpret_cast<const f32x4*>(Tb + 2 * K + 4 * q);
-  f32x4 z_sc = sc, z_sh = sh, r_sc = sc, r_sh = sh, r_fl = fl;
-  if (fq) {
-    z_sc = *reinterpret_cast<const f32x4*>(Tb + 3 * K + 4 * q); z_sh = *reinterpret_cast<const f32x4*>(Tb + 4 * K + 4 * q);
-    r_sc = *reinterpret_cast<const f32x4*>(Tb + 6 * K + 4 * q); r_sh = *reinterpret_cast<const f32x4*>(Tb + 7 * K + 4 * q);
-    r_fl = *reinterpret_cast<const f32x4*>(Tb + 8 * K + 4 * q);
-  }
   f32x4 s1[CTW], s2[CTW];
 #pragma unroll
   for (int c = 0; c < CTW; ++c) { s1[c] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[c] = s1[c]; }
@@ -365,14 +340,7 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
 #pragma unroll
       for (int u = 0; u < NXB; ++u) {
         const int r = r0 + (b * NXB + u) * RS;
-        f32x4 v;
-        if (fq) {
-          v = tf4_tab(xr[u], z_sc, z_sh, f32x4{1.f, 1.f, 1.f, 1.f}) + tf4_tab(xr2[FOLD ? u : 0], r_sc, r_sh, r_fl);
-          if constexpr (FOLD)
-            if (m0 + r < M) *reinterpret_cast<f32x4*>(const_cast<float*>(reinterpret_cast<const float*>(x)) + (m0 + r) * x_ld + 4 * q) = v;
-        } else {
-          v = tf4_tab(xr[u], sc, sh, fl);
-        }
+        f32x4 v = tf4_tab(xr[u], sc, sh, fl);
         if (m0 + r >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};
         const bf16x4 vh = __builtin_convertvector(v, bf16x4);
         bf16_t* dst = Xp + r * LDK + 4 * q;
@@ -466,7 +434,7 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
 template <int K, int CTW, int PT, int D, int NP, typename XT>
 static void launch_pw_x3_t(const ConvArgs& a, long long M, int wg_per_cu, hipStream_t s) {
   constexpr int BM = 16 * PT;
-  const size_t smem = (size_t)NP * BM * (K + 16) * sizeof(bf16_t) + (NP == 3 ? 9 : 3) * K * sizeof(float);
+  const size_t smem = (size_t)NP * BM * (K + 16) * sizeof(bf16_t) + 3 * K * sizeof(float);
   auto kern = pw_x3_kernel<K, CTW, PT, D, NP, XT>;
   static int places = 0;
   if (!places) {
@@ -480,7 +448,7 @@ static void launch_pw_x3_t(const ConvArgs& a, long long M, int wg_per_cu, hipStr
   const long long gx = std::min<long long>(n_tiles, 256LL * per_cu);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), smem, s, (const XT*)a.in, a.in_ld, a.itab, (const bf16_t*)a.w_x3,
                      (XT*)a.out, a.out_ld, M, a.stats, a.stats_rep_stride, a.stats_nrep > 0 ? a.stats_nrep : JN_NREP,
-                     a.skip_flag, a.skip_when, XFold{a.fold_z, a.fold_z_ld, a.fold_zt, a.fold_res, a.fold_res_ld, a.fold_rt, a.fold_C});
+                     a.skip_flag, a.skip_when);
 }
 
 // Shapes the x3 kernel is built for — the ones where it beats pw_xs_kernel (tools/pwxsbench.hip, profiles/r03_x3bench.txt:
@@ -495,12 +463,6 @@ bool pw_x3_preferred(const ConvArgs& a) {
   if (!a.w_x3 || !pw_xs_supported(a)) return false;
   const int K = a.cin, N = a.cout;
   return (K == 64 && (N == 64 || N == 128)) || (K == 128 && (N == 64 || N == 128)) || (K == 256 && N == 256);
-}
-
-// the x3 route forms a shortcut sum while staging (ConvArgs::fold_*; JN_NO_ADDACT_FOLD=1: the separate pass)
-bool pw_x3_fold_ok(const ConvArgs& a) {
-  static const bool off = std::getenv("JN_NO_ADDACT_FOLD") != nullptr || std::getenv("JN_NO_X3_FOLD") != nullptr;
-  return !off && pw_x3_preferred(a) && a.fold_C > 0 && a.fold_C % 4 == 0 && a.fold_C <= a.cin && a.fold_z_ld % 4 == 0 && a.fold_res_ld % 4 == 0;
 }
 
 // bf16 inference mode (bf16 activations in and out, bf16 MFMA): the single-plane form of the kernel, every xs shape
