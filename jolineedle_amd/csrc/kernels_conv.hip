@@ -913,7 +913,16 @@ template <int CT, int KC>
 static void launch_pw_narrow_t(const ConvArgs& a, long long M, hipStream_t s) {
   constexpr int BM = (CT % 2 == 0) ? 64 : 128;
   const long long n_tiles = (M + BM - 1) / BM;
-  const int cap = 1536;      // persistent workgroups (swept in round 1)
+  // persistent workgroups: whole resident rounds (what the occupancy API says fits, x 256 CUs).  Round 1 had swept a fixed
+  // 1536; the kernel's registers have changed since (84 VGPRs at <2, 32>: five workgroups per CU, so 1536 was a round of 1280 and a
+  // tail of 256) — forward 1.842 -> 1.822 ms per pass (tools/ab_fwd.sh, 1024 / 1280 / 1536 / 2048 / resident swept)
+  static int cap = 0;
+  if (!cap) {
+    int per_cu = 0;
+    const size_t sm = (size_t)(BM + 16 * CT) * (KC + 4) * sizeof(float) + (BM / 32) * 32 * CT * sizeof(float);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&pw_narrow_kernel<CT, KC>), 256, sm) != hipSuccess || per_cu < 1) per_cu = 4;
+    cap = per_cu * 256;
+  }
   const unsigned gx = (unsigned)std::min<long long>(n_tiles, cap);
   dim3 grid(gx, (unsigned)((a.cout + 16 * CT - 1) / (16 * CT)));
   const size_t smem = (size_t)(BM + 16 * CT) * (KC + 4) * sizeof(float) + (BM / 32) * 32 * CT * sizeof(float);
