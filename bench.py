@@ -335,7 +335,7 @@ def main():
         n_ranks_seen = dist.get_world_size()
 
     import jolineedle_amd as ja
-    from tests.helpers import model_config
+    from jolineedle_amd.config import model_config
 
     B, T, P, G = args.batch, args.seq_len, args.patch_size, args.grid
     torch.manual_seed(12345)

@@ -146,3 +146,18 @@ def args_to_config(args):
     m.block_size, m.n_channels, m.patch_size, m.image_cols = t.max_seq_len, 3, t.patch_size, t.image_cols
     m.no_recurrent_embedding = args.no_recurrent_embedding
     return t, m
+
+
+def model_config(**kw):
+    """Reference-style ``model_config`` node (main.py:367-386) with the defaults of BASELINE configs[2] (gpt-nano +
+    yolox-nano patch encoder + yolox-s detector, 448 px, block size 20); keyword arguments override fields,
+    ``nclasses`` sizes the categorical action head."""
+    from .common import ActionInfo
+    cfg = dict(model_type="gpt-nano", n_layer=None, n_head=None, n_embd=None, block_size=20, patch_size=448,
+               image_processor="yolox-s", gpt_backbone="yolox-nano", use_pos_emb=True, no_patch_emb=False,
+               concat_emb=True, decoder_pos_encoding=True, pos_emb_size=25, dropout=0.0,
+               detector_conf_threshold=0.5, no_recurrent_embedding=False, with_detector=True, nclasses=9)
+    cfg.update(kw)
+    n = cfg.pop("nclasses")
+    cfg["actions_info"] = [ActionInfo("categorical", n)]
+    return CfgNode(**cfg)

@@ -40,17 +40,7 @@ def synth_tokens(B, T, P, nA, grid, seed):
     return patches, actions, positions
 
 
-def model_config(**kw):
-    """Reference-style model_config (main.py:367-386) for the product GPT."""
-    import jolineedle_amd as ja
-    cfg = dict(model_type="gpt-nano", n_layer=None, n_head=None, n_embd=None, block_size=20, patch_size=448,
-               image_processor="yolox-s", gpt_backbone="yolox-nano", use_pos_emb=True, no_patch_emb=False,
-               concat_emb=True, decoder_pos_encoding=True, pos_emb_size=25, dropout=0.0,
-               detector_conf_threshold=0.5, no_recurrent_embedding=False, with_detector=True, nclasses=9)
-    cfg.update(kw)
-    n = cfg.pop("nclasses")
-    cfg["actions_info"] = [ja.ActionInfo("categorical", n)]
-    return ja.CfgNode(**cfg)
+from jolineedle_amd.config import model_config  # noqa: E402,F401  (kept importable from here for the tests)
 
 
 def make_pair(seed=0, bn_seed=5, max_batch=8, **kw):

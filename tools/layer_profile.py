@@ -4,7 +4,7 @@ one line per op (HIP events around every launch) on stderr.   usage: JN_LAYER_PR
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 import jolineedle_amd as ja
-from helpers import model_config
+from jolineedle_amd.config import model_config
 dt = sys.argv[1] if len(sys.argv) > 1 else "f32"
 train = len(sys.argv) > 2 and sys.argv[2] == "train"
 P, N = 448, 64
