@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define JN_ABI_VERSION 1
+#define JN_ABI_VERSION 2
 
 enum {
   JN_OK = 0,
@@ -246,25 +246,28 @@ int jn_optimizer_steps(jn_ctx* ctx, int group, int* steps, int set);
 
 /* One supervised (teacher-forced) step minus the optimiser: SupervisedTrainer.run body
  * (src/supervised.py:863-902) with the detector term off.  patches [B,T,3,P,P], current_actions /
- * next_actions [B,T] int64, positions [B,T,2] int64, masks [B,T] u8 (1 = token, 0 = padding); B*T <=
+ * next_actions [B,T] int64, classes [B] int64 (src/supervised.py:852, 866; NULL = class 0), positions [B,T,2] int64,
+ * masks [B,T] u8 (1 = token, 0 = padding); B*T <=
  * max_batch.  GPT.forward runs on the full sequence in train mode (BatchNorm statistics over the B*T
  * patches), loss = CrossEntropy(weight[STOP] = stop_weight, reduction none) averaged over non-padding
  * tokens (:138-177); gradients ACCUMULATE in the arena.  logits_out_dev [B,T,n_actions] optional;
  * metrics_dev[4] = action_loss, action_accuracy, episode_length. */
 int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* current_actions_dev,
-                       const int64_t* next_actions_dev, const int64_t* positions_dev, const uint8_t* masks_dev,
-                       int B, int T, float stop_weight, float* logits_out_dev, float* metrics_dev, void* stream);
+                       const int64_t* next_actions_dev, const int64_t* classes_dev, const int64_t* positions_dev,
+                       const uint8_t* masks_dev, int B, int T, float stop_weight, float* logits_out_dev,
+                       float* metrics_dev, void* stream);
 /* Supervised autograd bridge — the two halves of jn_supervised_step around the CALLER's loss, so that the reference's
  * supervised loop runs unchanged (src/supervised.py:863-868: `action_logits, embeddings = model(patches, current_actions,
  * classes=classes, positions=positions)`, then :138-177 its cross-entropy, then :897 `loss.backward()`):
  * jn_supervised_forward = GPT.forward (src/models/gpt.py:481-534, full-sequence, train mode: BatchNorm statistics over
  * the B*T patches, running statistics updated, dropout) -> logits_out_dev [B,T,n_actions], final_emb_out_dev [B,T+1,C]
  * (optional); jn_supervised_backward = the backward of that forward for GIVEN d loss / d logits [B,T,n_actions],
- * gradients ACCUMULATE in the arena.  patches / actions / positions must stay alive until the backward; any pass over
+ * gradients ACCUMULATE in the arena (the class token's gradient goes to row classes[b] of embed_class).  patches /
+ * actions / classes / positions must stay alive until the backward; any pass over
  * the patch encoder in between makes the saved activations stale and the backward fails with JN_ESTATE. */
 int jn_supervised_forward(jn_ctx* ctx, const float* patches_dev, const int64_t* current_actions_dev,
-                          const int64_t* positions_dev, int B, int T, float* logits_out_dev, float* final_emb_out_dev,
-                          void* stream);
+                          const int64_t* classes_dev, const int64_t* positions_dev, int B, int T, float* logits_out_dev,
+                          float* final_emb_out_dev, void* stream);
 int jn_supervised_backward(jn_ctx* ctx, const float* dlogits_dev, void* stream);
 /* clip_grad_value_(clip_value) + AdamW (torch defaults) over the optim_gpt parameters
  * (src/reinforce.py:344-346, src/models/gpt.py:552-557); grad_scale multiplies the gradients first
@@ -283,11 +286,12 @@ int jn_read_grad(jn_ctx* ctx, const char* name, float* host_out, size_t numel);
 
 /* GPT.forward (src/models/gpt.py:481-534), eval mode.  patches [B,T,3,P,P] f32 (NULL with
  * no_patch_emb), actions [B,T] int64, positions [B,T,2] int64 (y,x; NULL unless use_pos_emb),
- * prev_embeddings [B,Tp,C] or NULL.  Without prev_embeddings all T tokens are embedded
+ * classes [B] int64 = row of embed_class behind every agent's class token (gpt.py:476-478; NULL = class 0, ids are
+ * clamped to the table's 100 rows), prev_embeddings [B,Tp,C] or NULL.  Without prev_embeddings all T tokens are embedded
  * (1-D positions 0..T-1); with it only the last one is (1-D position 0, the reference's
  * recurrent quirk gpt.py:431-449) and appended.  L = prev ? Tp+1 : T+1.
  * Outputs: logits [B, L-1, n_actions], final_emb [B, L, n_embd] (either may be NULL). */
-int jn_gpt_forward(jn_ctx* ctx, const float* patches_dev, const int64_t* actions_dev,
+int jn_gpt_forward(jn_ctx* ctx, const float* patches_dev, const int64_t* actions_dev, const int64_t* classes_dev,
                    const int64_t* positions_dev, const float* prev_emb_dev, int B, int T, int Tp,
                    float* logits_dev, float* final_emb_dev, void* stream);
 /* NeedleYOLOX.forward inference branch (src/models/yolox.py:24-57, 74-113): boxes

@@ -57,6 +57,8 @@ class JnRolloutOut(C.Structure):
         "det_counts_dev")]
 
 
+ABI_VERSION = 2      # JN_ABI_VERSION of include/jnroll.h
+
 # name -> (restype, argtypes); every symbol include/jnroll.h declares
 SIGNATURES = {
     "jn_abi_version": (C.c_int, []),
@@ -83,10 +85,10 @@ SIGNATURES = {
     "jn_embed_patches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "jn_reinforce_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,
                                     C.POINTER(JnTrainOpts), C.POINTER(JnRolloutOut), C.c_void_p, C.c_void_p]),
-    "jn_supervised_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                     C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "jn_supervised_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
-                                        C.c_void_p, C.c_void_p]),
+    "jn_supervised_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jn_supervised_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "jn_supervised_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "jn_optimizer_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "jn_arena_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
@@ -96,7 +98,7 @@ SIGNATURES = {
     "jn_backbone_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
     "jn_read_grad": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
-    "jn_gpt_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+    "jn_gpt_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "jn_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "jn_rollout": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int,
@@ -132,8 +134,8 @@ def load_library(path=None):
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.jn_abi_version() != 1:
-        raise JnError(f"libjnroll ABI {lib.jn_abi_version()} != 1")
+    if lib.jn_abi_version() != ABI_VERSION:
+        raise JnError(f"libjnroll ABI {lib.jn_abi_version()} != {ABI_VERSION}")
     if path is None:
         _LIB = lib
     return lib

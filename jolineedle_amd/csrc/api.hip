@@ -1447,9 +1447,9 @@ static void fill_gpt_weights(const jn_ctx* ctx, GptStepArgs& a) {
   a.n_done = ctx->n_done;
 }
 
-int jn_gpt_forward(jn_ctx* ctx, const float* patches_dev, const int64_t* actions_dev, const int64_t* positions_dev,
-                   const float* prev_emb_dev, int B, int T, int Tp, float* logits_dev, float* final_emb_dev,
-                   void* stream) {
+int jn_gpt_forward(jn_ctx* ctx, const float* patches_dev, const int64_t* actions_dev, const int64_t* classes_dev,
+                   const int64_t* positions_dev, const float* prev_emb_dev, int B, int T, int Tp, float* logits_dev,
+                   float* final_emb_dev, void* stream) {
   JN_CHECK(ctx && actions_dev, JN_EINVAL, "jn_gpt_forward: null argument");
   JN_CHECK(ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
   const jn_config& c = ctx->cfg;
@@ -1481,6 +1481,7 @@ int jn_gpt_forward(jn_ctx* ctx, const float* patches_dev, const int64_t* actions
   JN_HIP(hipMemsetAsync(ctx->cache_len, 0, (size_t)B * sizeof(int32_t), s));
   GptStepArgs a{};
   fill_gpt_weights(ctx, a);
+  a.classes = classes_dev;
   a.B = B; a.T = L; a.emb_stride = L; a.out.final_emb = final_emb_dev; a.logits_stride = (L - 1) * nA;
   for (int tok = 0; tok < L; ++tok) {
     a.step = tok;
@@ -2189,8 +2190,8 @@ static int reinforce_backward_impl(jn_ctx* ctx, const jn_rollout_out* out, int S
 // bridge): the forward runs GPT.forward on the full sequence (B*T patches through the encoder in ONE train-mode pass,
 // 1-D positions 0..T-1) and leaves the logits in ctx->sup_logits; the backward takes d loss / d logits in ctx->dlogits.
 static int supervised_forward_impl(jn_ctx* ctx, const float* patches_dev, const int64_t* current_actions_dev,
-                                   const int64_t* positions_dev, int B, int T, float* logits_out_dev, float* final_emb_out_dev,
-                                   hipStream_t s) {
+                                   const int64_t* classes_dev, const int64_t* positions_dev, int B, int T, float* logits_out_dev,
+                                   float* final_emb_out_dev, hipStream_t s) {
   JN_CHECK(ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
   const jn_config& c = ctx->cfg;
   JN_CHECK(!c.no_patch_emb, JN_ESTATE, "training without a patch encoder is not supported");
@@ -2228,6 +2229,7 @@ static int supervised_forward_impl(jn_ctx* ctx, const float* patches_dev, const 
   GptStepArgs a{};
   fill_gpt_weights(ctx, a);
   a.pdrop = ctx->pdrop; a.drop_seed = ctx->drop_seed_used;
+  a.classes = classes_dev;
   a.B = B; a.T = L; a.emb_stride = L; a.out.final_emb = ctx->sup_final_emb; a.logits_stride = T * nA;
   for (int tok = 0; tok < L; ++tok) {
     a.step = tok;
@@ -2246,7 +2248,7 @@ static int supervised_forward_impl(jn_ctx* ctx, const float* patches_dev, const 
     JN_HIP(hipMemcpyAsync(logits_out_dev, ctx->sup_logits, (size_t)N * nA * sizeof(float), hipMemcpyDeviceToDevice, s));
   if (final_emb_out_dev)
     JN_HIP(hipMemcpyAsync(final_emb_out_dev, ctx->sup_final_emb, (size_t)B * L * C * sizeof(float), hipMemcpyDeviceToDevice, s));
-  ctx->sup = {patches_dev, current_actions_dev, positions_dev, B, T};
+  ctx->sup = {patches_dev, current_actions_dev, positions_dev, classes_dev, B, T};
   ctx->sup_valid = true;      // (run_net on slot 0 of the encoder cleared it: set last)
   JN_HIP(hipGetLastError());
   return JN_OK;
@@ -2272,6 +2274,7 @@ static int supervised_backward_impl(jn_ctx* ctx, hipStream_t s) {
   ba.dec_pos_enc = c.decoder_pos_encoding; ba.pe2_ch = (int)std::ceil(C / 4.0) * 2;
   ba.n_done = ctx->n_done; ba.final_emb = ctx->sup_final_emb; ba.dlogits = ctx->dlogits; ba.actions = current_actions_dev;
   ba.tok_actions = current_actions_dev; ba.positions = positions_dev; ba.pos_tokens = T; ba.pos1d_by_token = 1;
+  ba.classes = ctx->sup.classes;
   ba.tok_emb = ctx->tok_emb_train; ba.d_tok_emb = ctx->d_tok_emb; ba.dte_stride_b = T; ba.dte_stride_t = 1;
   ba.wte = g.wte; ba.wpe = g.wpe; ba.proj_wt = g.proj_wt; ba.pos1d = g.pos1d; ba.pe2 = g.pos2d_col; ba.head_wt = g.head_wt;
   ba.lnf_w = g.lnf_w; ba.lnf_b = g.lnf_b; ba.layers = ctx->layers_dev; ba.g_layers = ctx->g_layers_dev;
@@ -2317,12 +2320,13 @@ static int supervised_backward_impl(jn_ctx* ctx, hipStream_t s) {
 // One supervised (teacher-forced) training step minus the optimiser: forward, CrossEntropy(weight[STOP] = stop_weight)
 // over non-padding tokens, backward.
 int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* current_actions_dev,
-                       const int64_t* next_actions_dev, const int64_t* positions_dev, const uint8_t* masks_dev, int B,
-                       int T, float stop_weight, float* logits_out_dev, float* metrics_dev, void* stream) {
+                       const int64_t* next_actions_dev, const int64_t* classes_dev, const int64_t* positions_dev,
+                       const uint8_t* masks_dev, int B, int T, float stop_weight, float* logits_out_dev, float* metrics_dev,
+                       void* stream) {
   JN_CHECK(ctx && patches_dev && current_actions_dev && next_actions_dev && masks_dev && metrics_dev, JN_EINVAL,
            "jn_supervised_step: null argument");
   hipStream_t s = (hipStream_t)stream;
-  int rc = supervised_forward_impl(ctx, patches_dev, current_actions_dev, positions_dev, B, T, logits_out_dev, nullptr, s);
+  int rc = supervised_forward_impl(ctx, patches_dev, current_actions_dev, classes_dev, positions_dev, B, T, logits_out_dev, nullptr, s);
   if (rc) return rc;
   launch_ce_loss(ctx->sup_logits, next_actions_dev, masks_dev, stop_weight, ctx->dlogits, metrics_dev, B * T, ctx->cfg.n_actions, T, s);
   return supervised_backward_impl(ctx, s);
@@ -2331,11 +2335,11 @@ int jn_supervised_step(jn_ctx* ctx, const float* patches_dev, const int64_t* cur
 // Supervised autograd bridge: GPT.forward(patches [B,T,3,P,P], actions [B,T], classes = 0, positions [B,T,2]) in train
 // mode (src/models/gpt.py:481-534 as called by src/supervised.py:863-868) -> logits [B,T,nA], final_emb [B,T+1,C].  The
 // input buffers must stay alive until jn_supervised_backward.
-int jn_supervised_forward(jn_ctx* ctx, const float* patches_dev, const int64_t* current_actions_dev, const int64_t* positions_dev,
-                          int B, int T, float* logits_out_dev, float* final_emb_out_dev, void* stream) {
+int jn_supervised_forward(jn_ctx* ctx, const float* patches_dev, const int64_t* current_actions_dev, const int64_t* classes_dev,
+                          const int64_t* positions_dev, int B, int T, float* logits_out_dev, float* final_emb_out_dev, void* stream) {
   JN_CHECK(ctx && patches_dev && current_actions_dev && logits_out_dev, JN_EINVAL, "jn_supervised_forward: null argument");
-  return supervised_forward_impl(ctx, patches_dev, current_actions_dev, positions_dev, B, T, logits_out_dev, final_emb_out_dev,
-                                 (hipStream_t)stream);
+  return supervised_forward_impl(ctx, patches_dev, current_actions_dev, classes_dev, positions_dev, B, T, logits_out_dev,
+                                 final_emb_out_dev, (hipStream_t)stream);
 }
 
 // ... and its backward for GIVEN d loss / d logits [B,T,nA] (what torch hands to the logits node when the caller's

@@ -235,7 +235,7 @@ struct jn_ctx {
   jn_rollout_out train_out{};     // output buffers of the most recent train-mode rollout (jn_reinforce_backward reads them)
   bool train_out_valid = false;   // cleared by every entry point that overwrites what jn_reinforce_backward reads
   // supervised autograd bridge: inputs of the most recent supervised forward (caller-owned, alive until the backward)
-  struct SupState { const float* patches; const int64_t* actions; const int64_t* positions; int B, T; } sup{};
+  struct SupState { const float* patches; const int64_t* actions; const int64_t* positions; const int64_t* classes; int B, T; } sup{};
   bool sup_valid = false;         // cleared by every pass over workspace slot 0 of the patch encoder
   jnr::ArenaSeg* segs_dev = nullptr; int segs_dev_n = 0;   // device copy of `segs` for the layout-conversion kernel
   std::vector<hipEvent_t> conv_ev;   // pairs per step when profiling

@@ -281,6 +281,7 @@ struct GptLayerPtrs {
   float *ln1_w, *ln1_b, *qkv_wt, *qkv_b, *proj_wt, *proj_b, *ln2_w, *ln2_b, *fc_wt, *fc_b, *fc2_wt, *fc2_b;
 };
 
+constexpr int JN_N_CLASS_ROWS = 100;   // rows of embed_class (src/models/gpt.py:227)
 enum { GPT_SRC_ENV = 0, GPT_SRC_TEACH = 1, GPT_SRC_GIVEN = 2, GPT_SRC_CLASS = 3 };
 
 struct GptStepArgs {
@@ -288,6 +289,7 @@ struct GptStepArgs {
   int use_pos_emb, no_patch_emb, concat_emb, dec_pos_enc, n_parts;
   int pe2_ch;                       // channels per axis of the 2-D sinusoid table
   const float *wte, *wpe, *embed_class, *proj_wt, *proj_b, *pos1d, *pe2, *head_wt, *lnf_w, *lnf_b;
+  const int64_t* classes;           // [B] class id of every agent's class token (gpt.py:476-478), or null = class 0
   const GptLayerPtrs* layers;       // device array [n_layer]
   const float* emb_part; int KS; const float* efpn_lin_b;   // patch-embedding split-K partials [B][KS][C]
   float *kcache, *vcache;           // [L][B][Tmax][C]
@@ -340,6 +342,7 @@ struct GptBwdArgs {
   const int64_t* actions;           // [B][T] actions taken (rollout)
   const int64_t* tok_actions;       // [B][T] action token of every patch token (teacher-forced mode) or null
   const int64_t* positions;         // [B][pos_tokens][2]
+  const int64_t* classes;           // [B] class ids of the forward being differentiated, or null = class 0
   int pos_tokens;                   // T + 1 (rollout history) or T
   int pos1d_by_token;               // 1: token t has 1-D position t (full-sequence forward)
   const float* tok_emb;             // [B][T][C] patch embeddings

@@ -132,7 +132,9 @@ __global__ __launch_bounds__(NT) void gpt_step_kernel(GptStepArgs a) {
     // ---------------- token embedding ----------------
     const bool class_tok = (a.src_mode == GPT_SRC_CLASS) || (a.src_mode == GPT_SRC_ENV && t == 0 && j == 0);
     if (class_tok) {
-      for (int i = tid; i < C; i += NT) x[i] = a.embed_class[i];       // classes == 0 (reinforce.py:129)
+      // embed_class(classes) (gpt.py:476-478); the rollout passes no ids: class 0 (reinforce.py:128-129)
+      const int cls = a.classes ? min(max((int)a.classes[b], 0), JN_N_CLASS_ROWS - 1) : 0;
+      for (int i = tid; i < C; i += NT) x[i] = a.embed_class[(long long)cls * C + i];
     } else if (a.src_mode == GPT_SRC_GIVEN) {
       const float* gp = a.given_emb + ((long long)b * a.given_stride + a.given_index) * C;
       for (int i = tid; i < C; i += NT) x[i] = gp[i];

@@ -424,7 +424,11 @@ __global__ __launch_bounds__(GT) void gptb_parts_kernel(GptBwdArgs a, const floa
   for (int c = tid; c < C; c += GT) {
     float v = live ? dX[(long long)m * C + c] : 0.0f;
     if (live && a.pdrop > 0.0f) v *= drop_scale(a.drop_seed, b, i, 0, 0, c, a.pdrop);     // through transformer.drop
-    if (i == 0) { if (live) atomicAdd(&a.g_embed_class[c], v); v = 0.0f; }                 // class token id 0
+    if (i == 0) {                                                                         // class token: row classes[b]
+      const int cls = a.classes ? min(max((int)a.classes[b], 0), JN_N_CLASS_ROWS - 1) : 0;
+      if (live) atomicAdd(&a.g_embed_class[(long long)cls * C + c], v);
+      v = 0.0f;
+    }
     dXe[(long long)m * C + c] = v;
   }
   float* pr = PARTS + (long long)m * np * C;

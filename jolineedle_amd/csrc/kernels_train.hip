@@ -560,7 +560,10 @@ __global__ __launch_bounds__(GB) void gpt_backward_kernel(GptBwdArgs a) {
     for (int e = tid; e < L * C; e += GB) dX[e] *= drop_scale(dseed, b, e / C, 0, 0, e % C, pd);
     __syncthreads();
   }
-  for (int c = tid; c < C; c += GB) atomicAdd(&a.g_embed_class[c], dX[c]);          // class token id 0
+  {                                                                                 // class token: row classes[b]
+    const int cls = a.classes ? min(max((int)a.classes[b], 0), JN_N_CLASS_ROWS - 1) : 0;
+    for (int c = tid; c < C; c += GB) atomicAdd(&a.g_embed_class[(long long)cls * C + c], dX[c]);
+  }
   for (int i = 1; i < L; ++i) {
     const int t = i - 1;
     // rollout: token i carries the action taken BEFORE its patch (BOS = 0); teacher-forced full sequence:

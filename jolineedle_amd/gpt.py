@@ -204,8 +204,9 @@ class GPT(nn.Module):
 
     # ---- forward ----------------------------------------------------------------------
     def forward(self, patches, actions, classes, positions=None, prev_embeddings=None):
-        """Same contract as src/models/gpt.py:481-534.  ``classes`` must be 0 (the reference never passes anything else,
-        src/reinforce.py:128-129).  Eval mode / no-grad: BatchNorm running statistics, no graph.  ``model.train()`` + grad
+        """Same contract as src/models/gpt.py:481-534.  ``classes`` [B] int64 selects the row of ``embed_class`` behind each
+        sequence's class token (gpt.py:476-478; the RL loop passes zeros, src/reinforce.py:128-129, the supervised loop the
+        batch's class ids, src/supervised.py:852, 866); ``None`` = class 0.  Eval mode / no-grad: BatchNorm running statistics, no graph.  ``model.train()`` + grad
         mode on a full sequence (no ``prev_embeddings``: the supervised loop's call, src/supervised.py:863-868): train-mode
         numerics — BatchNorm statistics over the B*T patches, running statistics updated, dropout — and the logits carry a
         graph whose backward is the engine's teacher-forced backward (``jn_supervised_forward`` / ``_backward``)."""
@@ -223,6 +224,12 @@ class GPT(nn.Module):
         patches = None if self.no_patch_emb else patches.to(dev, torch.float32).contiguous()
         actions = actions.to(dev, torch.int64).contiguous()
         positions = None if positions is None else positions.to(dev, torch.int64).contiguous()
+        if classes is not None:
+            classes = torch.as_tensor(classes)
+            assert classes.shape == (B,), f"classes must be [B] = [{B}], got {tuple(classes.shape)}"
+            if classes.device.type == "cpu":          # nn.Embedding raises on an id outside its table; checked where it is free
+                assert int(classes.min()) >= 0 and int(classes.max()) < 100, "class id outside embed_class (100 rows)"
+            classes = classes.to(dev, torch.int64).contiguous()
         if self.training and torch.is_grad_enabled() and prev_embeddings is None and not self.no_patch_emb:
             assert B * seq_len <= self.max_batch, \
                 f"train-mode forward: B*T = {B * seq_len} patches exceed max_batch = {self.max_batch} (BatchNorm statistics need one pass)"
@@ -230,11 +237,11 @@ class GPT(nn.Module):
             self._rollout_gen += 1
             logits = torch.empty((B, seq_len, nA), device=dev, dtype=torch.float32)
             final_emb = torch.empty((B, seq_len + 1, C), device=dev, dtype=torch.float32)
-            check(self._engine.lib.jn_supervised_forward(self._engine.handle, ptr(patches), ptr(actions), ptr(positions), B,
-                                                         seq_len, ptr(logits), ptr(final_emb), _lib.current_stream(dev)),
-                  "jn_supervised_forward")
+            check(self._engine.lib.jn_supervised_forward(self._engine.handle, ptr(patches), ptr(actions), ptr(classes),
+                                                         ptr(positions), B, seq_len, ptr(logits), ptr(final_emb),
+                                                         _lib.current_stream(dev)), "jn_supervised_forward")
             anchor = next(p for p in self.parameters() if p.requires_grad)
-            logits = _ForwardGraph.apply(anchor, self, self._rollout_gen, logits, (patches, actions, positions))
+            logits = _ForwardGraph.apply(anchor, self, self._rollout_gen, logits, (patches, actions, classes, positions))
             return logits, final_emb
         Tp = 0
         if prev_embeddings is not None:
@@ -244,7 +251,7 @@ class GPT(nn.Module):
         logits = torch.empty((B, L - 1, nA), device=dev, dtype=torch.float32)
         final_emb = torch.empty((B, L, C), device=dev, dtype=torch.float32)
         lib = self._engine.lib
-        check(lib.jn_gpt_forward(self._engine.handle, ptr(patches), ptr(actions), ptr(positions),
+        check(lib.jn_gpt_forward(self._engine.handle, ptr(patches), ptr(actions), ptr(classes), ptr(positions),
                                  ptr(prev_embeddings), B, seq_len, Tp, ptr(logits), ptr(final_emb),
                                  _lib.current_stream(dev)), "jn_gpt_forward")
         return logits, final_emb

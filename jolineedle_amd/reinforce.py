@@ -161,6 +161,7 @@ class ReinforceTrainer:
         os.environ["MASTER_PORT"] = str(port)
         if not dist.is_initialized():
             dist.init_process_group(backend=backend or "nccl", rank=rank, world_size=world_size)
+            self._owns_process_group = True           # run() only tears down a group it created itself
 
     def training_step(self, batch, optim_gpt, optim_yolox=None, sync_gradients: bool = True, **rollout_kw):
         """The body of the reference's loop, statement for statement (src/reinforce.py:302-353): env -> rollout ->
@@ -249,8 +250,9 @@ class ReinforceTrainer:
                 it = iter(batches)
                 batch = next(it)
             metrics = self.training_step(batch, optim_gpt, optim_yolox, sync_gradients=world_size > 1)
-        if dist.is_available() and dist.is_initialized() and (world_size > 1 or backend):
-            dist.destroy_process_group()
+        if getattr(self, "_owns_process_group", False) and dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()                 # src/reinforce.py:362 / src/supervised.py:911
+            self._owns_process_group = False
         return metrics
 
     def init_detection(self, **kw):

@@ -85,7 +85,7 @@ class SupervisedTrainer:
             B_, T_ = cur.shape
             tr["patches"] = aug(tr["patches"].flatten(0, 1)).view(B_, T_, *tr["patches"].shape[2:])
             tr["patches_yolox"] = aug(tr["patches_yolox"])
-        res = self.train_step(tr["patches"], cur, ref_actions, tr["positions"], masks, optimizer_step=False)
+        res = self.train_step(tr["patches"], cur, ref_actions, tr["positions"], masks, optimizer_step=False, classes=tr["class_id"])
         ga = int(getattr(cfg, "gradient_accumulation", 1))
         if detection:
             _, _, yolo = self.model.yolox(tr["patches_yolox"], tr["bboxes_yolox"], loss_scale=1.0)
@@ -119,6 +119,7 @@ class SupervisedTrainer:
         os.environ["MASTER_PORT"] = str(port)
         if not dist.is_initialized():
             dist.init_process_group(backend=backend or "nccl", rank=rank, world_size=world_size)
+            self._owns_process_group = True           # run() only tears down a group it created itself
 
     def compute_metrics(self, action_logits, actions, masks, yolo_loss: Optional[dict] = None) -> Dict[str, torch.Tensor]:
         """src/supervised.py:138-198: CrossEntropy(weight[STOP] = stop_weight, reduction none) over the non-padding tokens,
@@ -217,13 +218,15 @@ class SupervisedTrainer:
                 it = iter(batches)
                 batch = next(it)
             metrics = self.training_step(batch, optim_gpt, optim_yolox, seed=None if seed is None else seed + i)
-        if dist.is_available() and dist.is_initialized() and (world_size > 1 or backend):
-            dist.destroy_process_group()
+        if getattr(self, "_owns_process_group", False) and dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()                 # src/reinforce.py:362 / src/supervised.py:911
+            self._owns_process_group = False
         return metrics
 
     def train_step(self, patches, current_actions, next_actions, positions, masks, optimizer_step: bool = True,
-                   process_group=None) -> Dict[str, torch.Tensor]:
-        """model(patches, current_actions, classes=0, positions) -> CE vs next_actions -> backward -> AdamW."""
+                   process_group=None, classes=None) -> Dict[str, torch.Tensor]:
+        """model(patches, current_actions, classes, positions) -> CE vs next_actions -> backward -> AdamW
+        (``classes`` [B] class ids as in src/supervised.py:852, 866; None = class 0)."""
         model, dev = self.model, self.device
         model.sync_weights()
         eng = model.engine()
@@ -233,10 +236,12 @@ class SupervisedTrainer:
         patches, cur, nxt = f(patches, torch.float32), f(current_actions, torch.int64), f(next_actions, torch.int64)
         pos = None if positions is None else f(positions, torch.int64)
         msk = f(masks, torch.uint8)
+        cls = None if classes is None else f(torch.as_tensor(classes), torch.int64)
+        assert cls is None or cls.shape == (B,), "classes must be [B]"
         logits = torch.empty((B, T, eng.cfg.n_actions), device=dev, dtype=torch.float32)
         metrics = torch.zeros(4, device=dev, dtype=torch.float32)
         stream = _lib.current_stream(dev)
-        check(eng.lib.jn_supervised_step(eng.handle, ptr(patches), ptr(cur), ptr(nxt), ptr(pos), ptr(msk), B, T,
+        check(eng.lib.jn_supervised_step(eng.handle, ptr(patches), ptr(cur), ptr(nxt), ptr(cls), ptr(pos), ptr(msk), B, T,
                                          self.stop_weight, ptr(logits), ptr(metrics), stream), "jn_supervised_step")
         self.iter_num += 1
         ga = int(getattr(self.config, "gradient_accumulation", 1))

@@ -75,11 +75,14 @@ def supervised(rank, world, port, outdir, case):
     optim_gpt.zero_grad()
     params = {k: v.detach().cpu().clone() for k, v in product.named_parameters()}
     world_seen = dist.get_world_size()
-    # ... and run() itself for two more iterations on the same group (it tears the group down at the end)
+    # ... and run() itself for two more iterations on the same group (main() created it, so run() must leave it alone)
     m = trainer.run(rank, world, port, batches=[batch], max_iters=2, backend="gloo", seed=7 + rank)
+    assert dist.is_initialized(), "run() destroyed a process group it did not create"
     torch.save({"local": local, "mean": mean, "world_seen": world_seen, "params": params,
                 "trajectories": {k: v.detach().cpu() for k, v in tr.items() if isinstance(v, torch.Tensor)},
                 "run_iters": trainer.iter_num, "run_loss_finite": bool(torch.isfinite(m["loss"]))}, outdir / f"rank{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -238,9 +238,10 @@ def test_gpt_forward_variants_vs_oracle(kw):
     product, oracle = make_pair(7, **base)
     nA = base.get("nclasses", 9)
     patches, actions, positions = synth_tokens(2, 5, 64, nA, 5, seed=11)
-    classes = torch.zeros(2, dtype=torch.long)
+    classes = torch.tensor([37, 0])              # embed_class(classes), src/models/gpt.py:476-478 (class token of each sequence)
     with torch.no_grad():
         rl, re = oracle(patches, actions, classes, positions)
+        assert (oracle(patches, actions, torch.zeros(2, dtype=torch.long), positions)[0] - rl).abs().max() > 10 * TOL_LOGIT
     lg, emb = product(patches, actions, classes, positions)
     assert (lg.cpu() - rl).abs().max() < TOL_LOGIT and (emb.cpu() - re).abs().max() < TOL_LOGIT
     with torch.no_grad():
@@ -258,6 +259,8 @@ def test_gpt_forward_asserts_like_reference():
         product(patches, actions, torch.zeros(1, dtype=torch.long), positions)
     with pytest.raises(AssertionError):
         product(patches[:, :2], actions[:, :2], torch.zeros(1, dtype=torch.long), None)
+    with pytest.raises(AssertionError, match="class id outside embed_class"):      # nn.Embedding(100, C) raises on such an id
+        product(patches[:, :2], actions[:, :2], torch.tensor([100]), positions[:, :2])
 
 
 # --------------------------------------------------------------------------------------
@@ -1396,11 +1399,14 @@ def test_supervised_step_vs_oracle(B, T, P, stop_w):
     masks[1, T - 2:] = 0                                      # padded tail
     w = torch.ones(9); w[8] = stop_w
     keep = masks.flatten() == 1
+    # class ids as the supervised loop passes them (src/supervised.py:852, 866): a repeated id (its embed_class row collects
+    # two sequences' gradients), the table's last row, and 0
+    classes = torch.tensor([3, 99, 3, 0][:B]) if P < 448 else torch.zeros(B, dtype=torch.long)
 
     def run_oracle(o, dt):
         o.train()
         o.zero_grad()
-        lg, _ = o(patches.to(dt), cur, torch.zeros(B, dtype=torch.long), positions)
+        lg, _ = o(patches.to(dt), cur, classes, positions)
         ce_ = torch.nn.functional.cross_entropy(lg.reshape(B * T, 9), nxt.flatten(), weight=w.to(dt), reduction="none")
         ls = ce_[keep].mean()
         ls.backward()
@@ -1417,8 +1423,12 @@ def test_supervised_step_vs_oracle(B, T, P, stop_w):
     acc = (logits.reshape(B * T, 9).argmax(1)[keep] == nxt.flatten()[keep]).float().mean()
     cfg = ja.CfgNode(stop_enabled=True, stop_weight=stop_w, learning_rate=1e-3, gradient_accumulation=1)
     tr = ja.SupervisedTrainer(cfg, product)
-    m = tr.train_step(patches, cur, nxt, positions, masks, optimizer_step=False)
+    m = tr.train_step(patches, cur, nxt, positions, masks, optimizer_step=False, classes=classes)
     assert (m["logits"].cpu() - logits.detach()).abs().max() < 1e-3        # train-mode BN over B*T patches
+    if P < 448:                                          # the gradient of a class token lands on ITS row of the table
+        ge = product.engine_grads()["embed_class.weight"]
+        rows = ge.abs().amax(dim=1) > 0
+        assert rows.nonzero().flatten().tolist() == sorted(set(classes.tolist()))
     assert abs(float(m["loss"]) - float(loss)) < 2e-4
     assert abs(float(m["action_accuracy"]) - float(acc)) < 1e-6
     assert abs(float(m["episode_length"]) - float(masks.sum(1).float().mean())) < 1e-6
@@ -1648,7 +1658,8 @@ def test_reference_supervised_loop_on_the_autograd_bridge():
     w = torch.ones(9); w[8] = stop_w
     keep = masks.flatten() == 1
     oracle.train(); oracle.zero_grad()
-    lg, _ = oracle(patches, cur, torch.zeros(B, dtype=torch.long), positions)
+    classes = torch.tensor([5, 61])                       # batch["class_id"] of a multi-class dataset (src/dataset.py:289-295)
+    lg, _ = oracle(patches, cur, classes, positions)
     loss_o = torch.nn.functional.cross_entropy(lg.reshape(B * T, 9), nxt.flatten(), weight=w, reduction="none")[keep].mean()
     loss_o.backward()
     ograds = {n: p.grad.detach().clone() for n, p in oracle.named_parameters() if p.grad is not None}
@@ -1660,7 +1671,7 @@ def test_reference_supervised_loop_on_the_autograd_bridge():
     assert optim_yolox is None
     product.train()
     dev = lambda t: t.to(DEV)
-    action_logits, embeddings = product(dev(patches), dev(cur), classes=torch.zeros(B, dtype=torch.long), positions=dev(positions))
+    action_logits, embeddings = product(dev(patches), dev(cur), classes=dev(classes), positions=dev(positions))
     assert action_logits.grad_fn is not None and action_logits.shape == (B, T, 9) and embeddings.shape == (B, T + 1, product.n_embd)
     assert (action_logits.detach().cpu() - lg.detach()).abs().max() < 1e-3
     metrics = trainer.compute_metrics(action_logits, dev(nxt), dev(masks))
@@ -1679,7 +1690,7 @@ def test_reference_supervised_loop_on_the_autograd_bridge():
     optim_gpt.step()
     optim_gpt.zero_grad()
     # ---- the same step inside the engine (train_step) and through torch on the oracle: no clipping anywhere ----
-    ja.SupervisedTrainer(cfg, product_b).train_step(patches, cur, nxt, positions, masks, optimizer_step=True)
+    ja.SupervisedTrainer(cfg, product_b).train_step(patches, cur, nxt, positions, masks, optimizer_step=True, classes=classes)
     product_b.pull_parameters()
     oparams = [p for n, p in oracle.named_parameters()]
     torch.optim.AdamW(oparams, lr=1e-3).step()

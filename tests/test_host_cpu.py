@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.jn_abi_version() == 1
+    assert lib.jn_abi_version() == _lib.ABI_VERSION == 2
 
 
 def test_struct_layout_matches_header():
