@@ -104,7 +104,7 @@ def bench_detector(args, ja, model_config, dev, rank, world, dist):
 
     def step():
         model.engine_zero_grad()
-        _, _, losses = model.yolox(patches, tg)
+        losses = model.yolox.loss_and_backward(patches, tg)
         _lib.check(eng.lib.jn_optimizer_step_group(eng.handle, 1, 1e-4, 0.01, 1.0, 1.0, _lib.current_stream(dev)), "opt")
         return losses
 

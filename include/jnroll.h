@@ -310,6 +310,25 @@ int jn_detect(jn_ctx* ctx, const float* patches_dev, int N, float* boxes_dev,
  * num_fg (foreground anchors per ground-truth box). */
 int jn_detector_step(jn_ctx* ctx, const float* patches_dev, int N, const float* targets_dev, int nb,
                      float loss_scale, float* metrics_dev, void* stream);
+/* Detector autograd bridge — NeedleYOLOX.forward(patches, targets) (src/models/yolox.py:24-91) as the two halves of
+ * jn_detector_step around the CALLER's autograd, so that the reference's loop runs as written (src/reinforce.py:330-341:
+ * `_, _, yolo_loss = yolox(patches_yolox, bboxes_yolox); loss += yolo_loss["total_loss"]; (loss / ga).backward()`; the
+ * same in src/supervised.py:881-897).
+ * jn_detector_forward: PAFPN + head in train mode on N <= max_batch patches (batch-statistics BatchNorm, running
+ * statistics updated), SimOTA loss -> metrics_dev float32[8] as above.  The activations and d loss / d raw stay resident
+ * as pass `pass` of `n_pass` (a detection batch above max_batch is fed in n_pass chunks, each with its own workspace
+ * slot; pass 0 sizes the workspace for n_pass) until jn_detector_backward(pass).  Optional outputs of the rest of the
+ * reference's forward: boxes_dev [N, max_det_per_patch, 7] + counts_dev [N] = the EVAL-mode head on the train-mode FPN
+ * maps, postprocessed and clamped (yolox.py:74-91; both NULL: skipped), fpn{0,1,2}_dev = fpn_outs [N, C_i, H_i, W_i]
+ * (activated, NCHW; NULL: skipped).  patches_dev must stay alive until the backward.
+ * jn_detector_backward: the backward of pass `pass` for d L / d total_loss = dloss_dev[0] (device scalar, what torch hands
+ * to the loss node; NULL = 1) times the host factor `scale` (the chunk's share N_pass / N_total of the batch mean);
+ * yolox.* gradients ACCUMULATE in the arena.  One backward per forward; a later pass over the same slot or a second
+ * backward fails with JN_ESTATE.  Independent of the REINFORCE / supervised bridges: either order of backward calls. */
+int jn_detector_forward(jn_ctx* ctx, const float* patches_dev, int N, const float* targets_dev, int nb, int pass,
+                        int n_pass, float* metrics_dev, float* boxes_dev, int32_t* counts_dev, float* fpn0_dev,
+                        float* fpn1_dev, float* fpn2_dev, void* stream);
+int jn_detector_backward(jn_ctx* ctx, int pass, const float* dloss_dev, float scale, void* stream);
 /* AdamW + clip on one parameter group of the arena: group 0 = optim_gpt (everything but yolox.*,
  * src/models/gpt.py:552-557), group 1 = optim_yolox (yolox.*).  jn_optimizer_step == group 0. */
 int jn_optimizer_step_group(jn_ctx* ctx, int group, float lr, float weight_decay, float clip_value,

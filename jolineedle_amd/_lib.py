@@ -107,6 +107,9 @@ SIGNATURES = {
     "jn_last_timing": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "jn_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "jn_detector_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "jn_detector_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jn_detector_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p]),
     "jn_optimizer_step_group": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "jn_reinforce_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,
                                        C.POINTER(JnRolloutOut), C.c_void_p]),

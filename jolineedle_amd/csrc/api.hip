@@ -450,16 +450,27 @@ static int ensure_slots(jn_ctx* ctx, Net& net, int n_slots) {
   if ((rc = dev_alloc(ctx, &tab, (size_t)n_slots * 3 * net.tab_channels))) return rc;
   if ((rc = dev_alloc(ctx, &save, (size_t)n_slots * 2 * net.stat_channels))) return rc;
   if ((rc = dev_alloc(ctx, &stats, (size_t)n_slots * JN_NREP * 2 * net.stat_channels))) return rc;
-  // old (smaller) allocations stay owned by the context until jn_destroy; slots are grown once per config
+  // old (smaller) allocations stay owned by the context until jn_destroy; slots are grown once per config.  What the
+  // old slots hold moves along (a detector pass may need its slot AFTER a train-mode rollout filled the encoder's, and
+  // the rollout's backward still reads them: the reference's statement order, src/reinforce.py:326-341)
+  const int n_old = net.n_slots;
+  if (n_old > 0) {
+    JN_HIP(hipDeviceSynchronize());
+    JN_HIP(hipMemcpy(act, net.act, (size_t)n_old * net.per_image_floats * MB * act_esz(net), hipMemcpyDeviceToDevice));
+    JN_HIP(hipMemcpy(tab, net.tab, (size_t)n_old * 3 * net.tab_channels * sizeof(float), hipMemcpyDeviceToDevice));
+    JN_HIP(hipMemcpy(save, net.save, (size_t)n_old * 2 * net.stat_channels * sizeof(float), hipMemcpyDeviceToDevice));
+    JN_HIP(hipMemcpy(stats, net.stats, (size_t)n_old * JN_NREP * 2 * net.stat_channels * sizeof(double), hipMemcpyDeviceToDevice));
+  }
   net.act = act; net.tab = tab; net.save = save; net.stats = stats; net.n_slots = n_slots;
-  for (int sl = 0; sl < n_slots; ++sl) {
+  for (int sl = n_old; sl < n_slots; ++sl) {
     float* t = tab + (size_t)sl * 3 * net.tab_channels;
     const long long n = net.tab_channels;
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, t, 1.0f, n);
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, 0, t + n, 0.0f, 2 * n);
   }
   JN_HIP(hipGetLastError());
-  net.eval_tab_dirty = true;
+  JN_HIP(hipDeviceSynchronize());           // (the fills ran on the null stream; callers launch on theirs)
+  if (n_old == 0) net.eval_tab_dirty = true;
   return JN_OK;
 }
 
@@ -538,6 +549,7 @@ int jn_load_weights(jn_ctx* ctx, const jn_tensor* tensors, size_t n) {
       if (r) return r;
     }
     net.eval_tab_dirty = true;
+    net.x3_dirty = true;
     for (const Op& op : net.ops) {
       if (op.kind != OP_PRED) continue;
       const std::string k = std::to_string(op.level), hp = "yolox.head.";
@@ -658,6 +670,8 @@ struct StemSrc {
   const float* src; const int64_t* positions; long long sample_stride, chan_stride; int row_stride;
   int pos_stride = 2;
 };
+static inline int det_slot_base(const jn_ctx* ctx);   // first workspace slot of the detector's training passes (below)
+
 
 // Descriptors of the deferred BatchNorm tables (ChanTab): which (sum, sumsq) pair, BatchNorm weight / bias and pixel
 // count stand behind every table channel, and the reverse map for the one finalize launch per pass.  Only the depthwise
@@ -720,18 +734,26 @@ static int ensure_defer_tables(jn_ctx* ctx, Net& net) {
 // One pass of a PAFPN over N patches in workspace slot `slot`.  train != 0: batch-statistics
 // BatchNorm (stats accumulated by every conv, finalised per layer, running stats updated).
 static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int train, const int* skip_flag,
-                   int skip_when, hipStream_t s, bool with_head = false) {
+                   int skip_when, hipStream_t s, bool with_head = false, int first_op = 0) {
   Net& net = ctx->nets[ni];
   const int n_ops = (with_head || net.n_backbone_ops < 0) ? (int)net.ops.size() : net.n_backbone_ops;
   const int MB = ctx->cfg.max_batch;
   int rc;
   // the autograd bridges differentiate LATER what a forward left in the workspace: a pass over the same slots in
   // between makes that state stale (the backward entry points then fail with JN_ESTATE instead of computing garbage)
-  if (ni == ctx->enc_net) { if (slot == 0) ctx->sup_valid = false; else ctx->train_out_valid = false; }
+  // (slots: 0 = eval / supervised pass; 1 .. T = the glimpse steps of a train-mode rollout of the ENCODER net; from
+  // det_slot_base on = detector training passes)
+  if (ni == ctx->enc_net) {
+    if (slot == 0) ctx->sup_valid = false;
+    else if (ni != JN_NET_DETECTOR || slot < det_slot_base(ctx)) ctx->train_out_valid = false;
+  }
+  if (ni == JN_NET_DETECTOR && slot >= det_slot_base(ctx) && slot - det_slot_base(ctx) < (int)ctx->det_pass.size())
+    ctx->det_pass[slot - det_slot_base(ctx)].valid = false;
   if (!train && (rc = refresh_eval_table(ctx, net, s))) return rc;
-  // fp32 passes: the 1x1 weights of this net as three bf16 planes for pw_x3_kernel, from the CURRENT parameters (one
-  // launch over the net's slice of the arena, ~4 us: cheaper and safer than tracking every writer of the arena)
-  // (bf16 inference mode uses the h plane alone: pw_x1)
+  // fp32 passes: the 1x1 weights of this net as three bf16 planes for pw_x3_kernel (bf16 inference mode uses the h plane
+  // alone: pw_x1).  Split again only after something wrote the arena (jn_load_weights, jn_import_arena, an optimiser
+  // step: mark_params_written) — a rollout's T passes and every eval pass in between reuse the planes (ADVICE round 3:
+  // for yolox-s / -m detectors the split is tens of MB per pass)
   const bool x3 = ctx->params_x3 && !std::getenv("JN_NO_PW_X3");   // read per pass: tests flip it
   if (x3) {
     if (net.x3_hi == 0) {
@@ -745,8 +767,10 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
       }
       net.x3_lo = lo / 8 * 8; net.x3_hi = hi > lo ? (hi + 7) / 8 * 8 : 0;
     }
-    if (net.x3_hi > net.x3_lo)
+    if (net.x3_hi > net.x3_lo && net.x3_dirty) {
       launch_w_split3(ctx->params + net.x3_lo, ctx->params_x3 + 3 * net.x3_lo, (long long)(net.x3_hi - net.x3_lo), s);
+      net.x3_dirty = false;
+    }
   }
   double* stats = train ? slot_stats(net, slot) : nullptr;
   float* save = train ? slot_save(net, slot) : nullptr;
@@ -810,9 +834,9 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
   if (layer_profile) {
     lev.resize(n_ops + 1);
     for (auto& e : lev) (void)hipEventCreate(&e);
-    (void)hipEventRecord(lev[0], s);
+    (void)hipEventRecord(lev[first_op], s);
   }
-  for (int oi = 0; oi < n_ops; ++oi) {
+  for (int oi = first_op; oi < n_ops; ++oi) {
     const Op& op = net.ops[oi];
     switch (op.kind) {
       case OP_STEM: {
@@ -897,7 +921,7 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
     const double esz = (double)act_esz(net);
     double tot_us = 0, tot_b = 0;
     fprintf(stderr, "# layer profile: net %d, N=%d, train=%d, slot=%d\n", ni, N, train, slot);
-    for (int oi = 0; oi < n_ops; ++oi) {
+    for (int oi = first_op; oi < n_ops; ++oi) {
       const Op& op = net.ops[oi];
       float ms = 0;
       (void)hipEventElapsedTime(&ms, lev[oi], lev[oi + 1]);
@@ -1621,25 +1645,46 @@ __global__ void labels_to_cxcywh_kernel(const float* __restrict__ in, float* __r
   d[0] = s[0]; d[1] = 0.5f * (s[1] + s[3]); d[2] = 0.5f * (s[2] + s[4]); d[3] = s[3] - s[1]; d[4] = s[4] - s[2];
 }
 
-int jn_detector_step(jn_ctx* ctx, const float* patches_dev, int N, const float* targets_dev, int nb, float loss_scale,
-                     float* metrics_dev, void* stream) {
-  JN_CHECK(ctx && patches_dev && targets_dev && metrics_dev, JN_EINVAL, "jn_detector_step: null argument");
+// ---- detector training: NeedleYOLOX.forward(patches, targets) (src/models/yolox.py:24-91) in two halves ------------
+// A "pass" is one train-mode run of PAFPN + head over up to max_batch patches whose activations stay resident in a
+// workspace slot of their own until the backward: slot det_slot_base + pass.  With a separate patch encoder the
+// detector net's slot 0 is the eval workspace and the passes start at 1; when the detector's own PAFPN encodes the
+// patches (no gpt_backbone) a train-mode rollout owns slots 1 .. T <= block_size of the SAME net, so the passes start
+// behind them — the rollout's backward may then run after the detector pass, the reference's statement order
+// (src/reinforce.py:326-341).
+static inline int det_slot_base(const jn_ctx* ctx) { return ctx->enc_net == JN_NET_DETECTOR ? ctx->cfg.block_size + 1 : 1; }
+
+__global__ void det_scale_kernel(const float* __restrict__ fwd_scale, const float* __restrict__ dloss, float host_scale,
+                                 float* __restrict__ out) {
+  out[0] = fwd_scale[0] * (dloss ? dloss[0] : 1.0f) * host_scale;
+}
+
+static int detector_forward_impl(jn_ctx* ctx, const float* patches_dev, int N, const float* targets_dev, int nb, int pass,
+                                 int n_pass, float loss_scale, float* metrics_dev, hipStream_t s) {
+  JN_CHECK(ctx && patches_dev && targets_dev && metrics_dev, JN_EINVAL, "detector training pass: null argument");
   JN_CHECK(ctx->has_net[JN_NET_DETECTOR], JN_ESTATE, "context was created without a detector");
   JN_CHECK(ctx->weights_loaded, JN_ESTATE, "jn_load_weights has not been called");
   JN_CHECK(N >= 1 && N <= ctx->cfg.max_batch, JN_EINVAL, "N=%d exceeds max_batch=%d", N, ctx->cfg.max_batch);
   JN_CHECK(nb >= 1, JN_EINVAL, "targets need at least one (padding) row per patch");
+  JN_CHECK(n_pass >= 1 && n_pass <= 64 && pass >= 0 && pass < n_pass, JN_EINVAL, "detector pass %d of %d", pass, n_pass);
   JN_CHECK(ctx->cfg.act_dtype == JN_F32, JN_ESTATE, "training needs act_dtype = fp32 (bf16 is the inference mode)");
   JN_HIP(hipSetDevice(ctx->cfg.device));
-  hipStream_t s = (hipStream_t)stream;
   Net& net = ctx->nets[JN_NET_DETECTOR];
   const int MB = ctx->cfg.max_batch, A = net.n_anchors, P = ctx->cfg.patch_size;
+  const int slot = det_slot_base(ctx) + pass;
   int rc;
-  if ((rc = ensure_slots(ctx, net, 2))) return rc;               // slot 1 = the training pass
+  if ((rc = ensure_slots(ctx, net, det_slot_base(ctx) + n_pass))) return rc;
   if ((rc = ensure_train_state(ctx, ctx->enc_net == JN_NET_DETECTOR ? std::max(1, ctx->nets[ctx->enc_net].g_slots) : 1))) return rc;
   if (!ctx->det_logits) {
     if ((rc = dev_alloc(ctx, &ctx->det_logits, (size_t)MB * A * 6))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->det_dlogits, (size_t)MB * A * 6))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->det_acc, (size_t)16))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->det_bwd_scale, (size_t)4))) return rc;
+  }
+  if ((int)ctx->det_pass.size() < n_pass) ctx->det_pass.resize(n_pass);
+  jn_ctx::DetPass& dp = ctx->det_pass[pass];
+  dp.valid = false;
+  if (!dp.dlogits) {
+    if ((rc = dev_alloc(ctx, &dp.dlogits, (size_t)MB * A * 6))) return rc;
+    if ((rc = dev_alloc(ctx, &dp.acc, (size_t)16))) return rc;
   }
   if (!ctx->det_labels || ctx->det_labels_rows < (size_t)N * nb) {
     if ((rc = dev_alloc(ctx, &ctx->det_labels, (size_t)MB * nb * 5))) return rc;
@@ -1647,28 +1692,118 @@ int jn_detector_step(jn_ctx* ctx, const float* patches_dev, int N, const float* 
   }
   hipLaunchKernelGGL(labels_to_cxcywh_kernel, dim3((N * nb + 255) / 256), dim3(256), 0, s, targets_dev, ctx->det_labels, N * nb);
   StemSrc ss{patches_dev, nullptr, 3LL * P * P, (long long)P * P, P};
-  if ((rc = run_net(ctx, JN_NET_DETECTOR, N, ss, 1, 1, nullptr, 0, s, true))) return rc;
+  if ((rc = run_net(ctx, JN_NET_DETECTOR, N, ss, slot, 1, nullptr, 0, s, true))) return rc;
   DetGeom geo{};
   geo.A = A;
   for (const Op& op : net.ops) {
     if (op.kind != OP_PRED) continue;
     geo.a0[op.level] = op.anchor0; geo.H[op.level] = op.in.H; geo.W[op.level] = op.in.W; geo.stride[op.level] = op.stride;
   }
-  launch_yolox_loss(ctx->det_logits, ctx->det_labels, N, nb, geo, ctx->det_dlogits, ctx->det_acc, 1, loss_scale, metrics_dev,
-                    ctx->det_acc + 8, s);
+  launch_yolox_loss(ctx->det_logits, ctx->det_labels, N, nb, geo, dp.dlogits, dp.acc, 1, loss_scale, metrics_dev, dp.acc + 8, s);
+  JN_HIP(hipGetLastError());
+  dp.patches = patches_dev; dp.N = N; dp.valid = true;
+  return JN_OK;
+}
+
+// backward of pass `pass`: d loss / d raw (left by the forward, scaled by scale_dev[0]) through the predictors, the head
+// and the PAFPN; parameter gradients ACCUMULATE in the arena
+static int detector_backward_impl(jn_ctx* ctx, int pass, const float* scale_dev, hipStream_t s) {
+  JN_CHECK(pass >= 0 && pass < (int)ctx->det_pass.size() && ctx->det_pass[pass].valid, JN_ESTATE,
+           "detector backward: pass %d has no forward to differentiate (none ran, or a later pass overwrote its activations)", pass);
+  Net& net = ctx->nets[JN_NET_DETECTOR];
+  const jn_ctx::DetPass& dp = ctx->det_pass[pass];
+  const int MB = ctx->cfg.max_batch, A = net.n_anchors, P = ctx->cfg.patch_size, N = dp.N;
+  const int slot = det_slot_base(ctx) + pass;
+  int rc;
   for (const Op& op : net.ops) {
     if (op.kind != OP_PRED) continue;
     float* g_reg = net.gact + net.buf_off[op.in.buf] * (size_t)MB + op.in.coff;
     float* g_cls = net.gact + net.buf_off[op.res.buf] * (size_t)MB + op.res.coff;
-    rc = launch_head_pred_bwd(ctx->det_dlogits, ctx->det_acc + 8, view_ptr(net, 1, MB, op.in), net.bufs[op.in.buf].C,
-                              view_tab(net, 1, op.in), view_ptr(net, 1, MB, op.res), net.bufs[op.res.buf].C, view_tab(net, 1, op.res),
+    rc = launch_head_pred_bwd(dp.dlogits, scale_dev, view_ptr(net, slot, MB, op.in), net.bufs[op.in.buf].C,
+                              view_tab(net, slot, op.in), view_ptr(net, slot, MB, op.res), net.bufs[op.res.buf].C, view_tab(net, slot, op.res),
                               net.act_dtype, net.pred_w[op.level], g_reg, g_cls, grad_of(ctx, net.pred_w[op.level]),
                               grad_of(ctx, net.pred_b[op.level]), net.head_hid, op.in.H * op.in.W, A, op.anchor0, N, s);
     JN_CHECK(rc == 0, JN_ESTATE, "predictor backward: unsupported buffer type");
   }
-  if ((rc = run_net_backward(ctx, JN_NET_DETECTOR, N, ss, 1, s, 1, 0, true))) return rc;
+  StemSrc ss{dp.patches, nullptr, 3LL * P * P, (long long)P * P, P};
+  if ((rc = run_net_backward(ctx, JN_NET_DETECTOR, N, ss, slot, s, 1, 0, true))) return rc;
   JN_HIP(hipGetLastError());
   return JN_OK;
+}
+
+int jn_detector_step(jn_ctx* ctx, const float* patches_dev, int N, const float* targets_dev, int nb, float loss_scale,
+                     float* metrics_dev, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  int rc = detector_forward_impl(ctx, patches_dev, N, targets_dev, nb, 0, 1, loss_scale, metrics_dev, s);
+  if (rc) return rc;
+  rc = detector_backward_impl(ctx, 0, ctx->det_pass[0].acc + 8, s);
+  ctx->det_pass[0].valid = false;          // the gradient buffers of the head were consumed
+  return rc;
+}
+
+// The eval-mode head on the TRAIN-mode FPN maps of a pass (src/models/yolox.py:74-91: `self.eval(); outputs =
+// self.head(fpn_outs)` after the loss branch — fpn_outs were computed in the module's current mode, the head now uses
+// its running statistics as the train pass has just updated them): the three FPN views (raw z + their batch-statistics
+// table entries) are copied into the eval workspace (slot 0) and the head ops run there, so the pass's own head
+// activations stay intact for the backward.
+static int detector_eval_head(jn_ctx* ctx, int pass, float* boxes_dev, int32_t* counts_dev, hipStream_t s) {
+  Net& net = ctx->nets[JN_NET_DETECTOR];
+  const jn_ctx::DetPass& dp = ctx->det_pass[pass];
+  const int MB = ctx->cfg.max_batch, N = dp.N, slot = det_slot_base(ctx) + pass;
+  JN_CHECK(net.n_backbone_ops >= 0, JN_ESTATE, "detector without a head");
+  int rc;
+  if (!ctx->det_raw)
+    if ((rc = dev_alloc(ctx, &ctx->det_raw, (size_t)MB * net.n_anchors * 6))) return rc;
+  if ((rc = refresh_eval_table(ctx, net, s))) return rc;          // head tables from the running statistics (just updated)
+  for (int i = 0; i < 3; ++i) {
+    const View& f = net.fpn[i];
+    const int ld = net.bufs[f.buf].C;
+    launch_grad_copy((const float*)view_ptr(net, slot, MB, f), ld, (float*)view_ptr(net, 0, MB, f), ld, f.C, (long long)N * f.H * f.W, 0, s);
+    const ChanTab src = view_tab(net, slot, f), dst = view_tab(net, 0, f);
+    JN_HIP(hipMemcpyAsync(dst.sc, src.sc, f.C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    JN_HIP(hipMemcpyAsync(dst.sh, src.sh, f.C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    JN_HIP(hipMemcpyAsync(dst.fl, src.fl, f.C * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  StemSrc none{nullptr, nullptr, 0, 0, 0};
+  rc = run_net(ctx, JN_NET_DETECTOR, N, none, 0, 0, nullptr, 0, s, true, net.n_backbone_ops);
+  net.eval_tab_dirty = true;               // slot 0's FPN entries hold batch statistics now: rebuilt before the next eval pass
+  if (rc) return rc;
+  launch_postprocess(ctx->det_raw, net.n_anchors, N, ctx->cfg.det_conf_threshold, ctx->cfg.det_nms_threshold,
+                     (float)(ctx->cfg.patch_size - 1), boxes_dev, counts_dev, ctx->cfg.max_det_per_patch, s);
+  JN_HIP(hipGetLastError());
+  return JN_OK;
+}
+
+int jn_detector_forward(jn_ctx* ctx, const float* patches_dev, int N, const float* targets_dev, int nb, int pass, int n_pass,
+                        float* metrics_dev, float* boxes_dev, int32_t* counts_dev, float* fpn0_dev, float* fpn1_dev,
+                        float* fpn2_dev, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  int rc = detector_forward_impl(ctx, patches_dev, N, targets_dev, nb, pass, n_pass, 1.0f, metrics_dev, s);
+  if (rc) return rc;
+  Net& net = ctx->nets[JN_NET_DETECTOR];
+  const int MB = ctx->cfg.max_batch, slot = det_slot_base(ctx) + pass;
+  float* outs[3] = {fpn0_dev, fpn1_dev, fpn2_dev};
+  for (int i = 0; i < 3; ++i) {
+    if (!outs[i]) continue;
+    const View& f = net.fpn[i];
+    launch_nhwc_to_nchw(view_ptr(net, slot, MB, f), net.act_dtype, net.bufs[f.buf].C, view_tab(net, slot, f), outs[i], f.C, f.H * f.W, N, s);
+  }
+  if (boxes_dev && counts_dev && (rc = detector_eval_head(ctx, pass, boxes_dev, counts_dev, s))) return rc;
+  JN_HIP(hipGetLastError());
+  return JN_OK;
+}
+
+int jn_detector_backward(jn_ctx* ctx, int pass, const float* dloss_dev, float scale, void* stream) {
+  JN_CHECK(ctx, JN_EINVAL, "jn_detector_backward: null ctx");
+  JN_CHECK(ctx->has_net[JN_NET_DETECTOR], JN_ESTATE, "context was created without a detector");
+  JN_CHECK(pass >= 0 && pass < (int)ctx->det_pass.size() && ctx->det_pass[pass].valid, JN_ESTATE,
+           "jn_detector_backward: pass %d has no forward to differentiate (none ran, or a later pass overwrote its activations)", pass);
+  JN_HIP(hipSetDevice(ctx->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(det_scale_kernel, dim3(1), dim3(1), 0, s, ctx->det_pass[pass].acc + 8, dloss_dev, scale, ctx->det_bwd_scale);
+  int rc = detector_backward_impl(ctx, pass, ctx->det_bwd_scale, s);
+  ctx->det_pass[pass].valid = false;       // one backward per forward (retain_graph is not offered)
+  return rc;
 }
 
 // ---- environment ---------------------------------------------------------------------
@@ -1886,7 +2021,9 @@ static int rollout_impl(jn_ctx* ctx, int mode, const int64_t* forced_actions_dev
   int rc;
   if (train) {
     Net& tn = ctx->nets[ctx->enc_net];
-    if ((rc = ensure_slots(ctx, tn, T + 1))) return rc;
+    // (a shared detector / encoder net: the detector's training pass gets its slot behind the rollout's right away, so
+    // that no growth — and copy — happens between this rollout and its backward)
+    if ((rc = ensure_slots(ctx, tn, ctx->enc_net == JN_NET_DETECTOR ? c.block_size + 2 : T + 1))) return rc;
     int g_want = tn.g_slots;
     if (ctx->enc_net == JN_NET_DETECTOR) g_want = std::max(1, g_want);   // detached encoder: no conv-stack backward
     else if (g_want < T) {
@@ -2373,7 +2510,7 @@ int jn_optimizer_step_group(jn_ctx* ctx, int group, float lr, float weight_decay
   step += 1;
   launch_adamw(ctx->params + lo, ctx->grads + lo, ctx->adam_m + lo, ctx->adam_v + lo, (long long)(hi - lo), lr, 0.9f, 0.999f, 1e-8f,
                weight_decay, step, clip_value, grad_scale, (hipStream_t)stream);
-  for (int ni = 0; ni < 2; ++ni) if (ctx->has_net[ni]) ctx->nets[ni].eval_tab_dirty = true;   // BN affine moved
+  for (int ni = 0; ni < 2; ++ni) if (ctx->has_net[ni]) ctx->nets[ni].eval_tab_dirty = ctx->nets[ni].x3_dirty = true;   // BN affine, 1x1 weights moved
   JN_HIP(hipGetLastError());
   return JN_OK;
 }
@@ -2417,7 +2554,7 @@ static int arena_copy(jn_ctx* ctx, int what, float* ref_dev, size_t numel, int t
                     (hipStream_t)stream);
   JN_HIP(hipGetLastError());
   if (!to_ref && what == 0)
-    for (int ni = 0; ni < 2; ++ni) if (ctx->has_net[ni]) ctx->nets[ni].eval_tab_dirty = true;   // BN affine may have moved
+    for (int ni = 0; ni < 2; ++ni) if (ctx->has_net[ni]) ctx->nets[ni].eval_tab_dirty = ctx->nets[ni].x3_dirty = true;   // parameters may have moved
   return JN_OK;
 }
 

@@ -100,6 +100,7 @@ struct Net {
   View fpn[3];              // pan_out2, pan_out1, pan_out0
   int n_backbone_ops = -1;  // ops before the detection head (-1: no head, all ops)
   size_t x3_lo = 0, x3_hi = 0;   // arena range of the 1x1 weights (multiples of 8 floats; hi == 0: not computed yet)
+  bool x3_dirty = true;           // the bf16 planes of that range are older than the parameters (see mark_params_written)
   int n_anchors = 0, head_hid = 0;
   float* pred_w[3] = {nullptr, nullptr, nullptr};   // [6][hid] reg(4), obj, cls predictor rows
   float* pred_b[3] = {nullptr, nullptr, nullptr};   // [6]
@@ -208,9 +209,16 @@ struct jn_ctx {
   bool stats_prezeroed = false;   // run_net(train): the caller already zeroed the BN sums of the slots it walks
   int64_t* det_pos = nullptr; size_t det_pos_cap = 0;   // [T+1][B][2] per-step position snapshots for the detector stream
   float* det_raw = nullptr;       // [B][A][6] decoded head output
-  float* det_logits = nullptr;    // [B][A][6] raw predictor outputs of the training pass
-  float* det_dlogits = nullptr;   // [B][A][6] d loss / d raw (before the 1 / num_fg factor)
-  float* det_acc = nullptr;       // [8] loss accumulators, [8] scale
+  float* det_logits = nullptr;    // [B][A][6] raw predictor outputs of the training pass (consumed by the loss kernel)
+  // one entry per resident detector training pass (jn_detector_forward ... jn_detector_backward, api.hip)
+  struct DetPass {
+    float* dlogits = nullptr;     // [B][A][6] d loss / d raw (before the 1 / num_fg factor)
+    float* acc = nullptr;         // [8] loss accumulators, [8] scale (scale[0] = loss_scale / max(num_fg, 1))
+    const float* patches = nullptr; int N = 0;   // caller-owned input of the pass (the stem's weight gradient reads it)
+    bool valid = false;           // cleared by every pass over the same workspace slot and by the backward
+  };
+  std::vector<DetPass> det_pass;
+  float* det_bwd_scale = nullptr; // [1] scale of the backward in flight: forward scale x upstream d loss x chunk weight
   float* det_labels = nullptr;    // [B][nb][5] cxcywh labels of the training pass
   size_t det_labels_rows = 0;
   float* det_tmp_boxes = nullptr; int32_t* det_tmp_counts = nullptr;   // one step's detections before the scatter

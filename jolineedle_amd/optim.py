@@ -84,6 +84,11 @@ class EngineAdamW(torch.optim.Optimizer):
                         "exp_avg_sq": eas[sl].view(p.shape).cpu().clone()}
         g = {k: v for k, v in self.param_groups[0].items() if k != "params"}
         g.update(params=idx, amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None)
+        # which tensor stands behind every position: torch keys optimizer state by position in the parameter list, and this
+        # package's list order changed once (engine execution order -> the reference's module order, round 3); with the
+        # names in the file a reader can map by NAME whatever its own order is (torch >= 2.6 writes the same key for
+        # optimisers built from named_parameters(); torch.optim.AdamW.load_state_dict ignores it otherwise)
+        g["param_names"] = [names.get(id(p), "") for p in self.param_groups[0]["params"]]
         return {"state": state, "param_groups": [g]}
 
     def load_state_dict(self, sd):
@@ -96,9 +101,28 @@ class EngineAdamW(torch.optim.Optimizer):
         m.bind_flat()
         ea, eas = self._moments(2), self._moments(3)
         names = {id(p): n for n, p in m.named_parameters()}
+        # position -> entry of the file.  With "param_names" in the file the entries are matched by NAME (any list order:
+        # files of this package, of torch >= 2.6 optimisers built from named_parameters()).  Without it positions are all
+        # there is: they are read in the reference's module order — what torch.optim.AdamW of the reference wrote for
+        # GPT.configure_optimizers (src/models/gpt.py:547-562).  A file this package wrote BEFORE it carried names (rounds
+        # 1-2: engine execution order, conv2|conv1 pairs first) cannot be told from that by content — same shapes inside a
+        # CSP pair — so the untagged case is announced instead of silently trusted.
+        file_names = (sd.get("param_groups") or [{}])[0].get("param_names")
+        by_name = None
+        if file_names:
+            ids = (sd.get("param_groups") or [{}])[0].get("params", list(range(len(file_names))))
+            by_name = {n: sd["state"].get(i, sd["state"].get(str(i))) for n, i in zip(file_names, ids)}
+            unknown = sorted(n for n in by_name if n and n not in names.values() and by_name[n] is not None)
+            if unknown:
+                raise ValueError(f"optimizer state names tensors this model does not have: {unknown[:4]} ...")
+        else:
+            import warnings
+            warnings.warn("optimizer state without 'param_names': positions are read in the reference's parameter order "
+                          "(torch.optim.AdamW over GPT.named_parameters()); a file written by rounds 1-2 of this package "
+                          "(engine execution order) must be re-saved with names, its moments would land on the wrong tensors")
         step = 0
         for i, p in enumerate(self.param_groups[0]["params"]):
-            st = sd["state"].get(i, sd["state"].get(str(i)))
+            st = by_name.get(names.get(id(p))) if by_name is not None else sd["state"].get(i, sd["state"].get(str(i)))
             off = m._flat_offsets.get(names.get(id(p)))
             if st is None or off is None:
                 continue

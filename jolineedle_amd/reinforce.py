@@ -179,21 +179,18 @@ class ReinforceTrainer:
         metrics = self.compute_metrics(rollout)
         loss = metrics["loss"]
         ga = int(getattr(config, "gradient_accumulation", 1))
-        # (the policy loss is differentiated BEFORE the detector step: that step's loss is computed and differentiated
-        # inside the engine in one call and may reuse the workspace of the rollout's encoder when the detector's own PAFPN
-        # encodes the patches; the sum of the two gradients is the reference's `loss += total_loss; loss.backward()`)
-        (loss / ga).backward()
-        if getattr(config, "detection_enabled", False) and self.yolox_model() is not None:
+        if getattr(config, "detection_enabled", False) and self.yolox_model() is not None:      # src/reinforce.py:330-339
             patches_yolox, bboxes_yolox = env.get_detection_batch(int(getattr(config, "detection_sample_neg", 1)))
             if getattr(self, "detection_augment", None) is not None:
                 with torch.no_grad():
                     patches_yolox = self.detection_augment(patches_yolox)
-            # the engine computes the detector loss AND its backward in one call (gradients -> param.grad); the value joins
-            # the reported loss as a constant
-            _, _, yolo_loss = self.yolox_model()(patches_yolox, bboxes_yolox, loss_scale=1.0 / ga)
+            yolox = self.yolox_model()
+            _, _, yolo_loss = yolox(patches_yolox, bboxes_yolox, predict=False)      # (the loop discards outputs / fpn_outs)
             for k, v in yolo_loss.items():
-                metrics["yolo_" + k] = v
-            loss = loss + yolo_loss["total_loss"].detach()
+                metrics["yolo_" + k] = v.detach()
+            total_loss = yolo_loss["total_loss"]         # carries the detector's graph (yolox.py::_DetectorGraph)
+            loss = loss + total_loss
+        (loss / ga).backward()                           # :341 — ONE backward through the rollout node and the detector node
         if self.iter_num % ga == 0:
             opts = [o for o in (optim_gpt, optim_yolox) if o is not None]
             was = [getattr(o, "sync_gradients", False) for o in opts]
@@ -328,7 +325,7 @@ class ReinforceTrainer:
             patches_y, boxes_y = env.get_detection_batch(int(getattr(self.config, "detection_sample_neg", 1)))
             if getattr(self, "detection_augment", None) is not None:               # src/reinforce.py:332-333
                 patches_y = self.detection_augment(patches_y)
-            _, _, yolo_losses = self.yolox_model()(patches_y, boxes_y, loss_scale=1.0 / ga)
+            yolo_losses = self.yolox_model().loss_and_backward(patches_y, boxes_y, loss_scale=1.0 / ga)
         if optimizer_step and self.iter_num % ga == 0:
             # the ONE exchange step of the iteration: flat gradient all-reduce (RCCL over xGMI)
             from .dist import allreduce_gradients

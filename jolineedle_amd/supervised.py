@@ -88,7 +88,7 @@ class SupervisedTrainer:
         res = self.train_step(tr["patches"], cur, ref_actions, tr["positions"], masks, optimizer_step=False, classes=tr["class_id"])
         ga = int(getattr(cfg, "gradient_accumulation", 1))
         if detection:
-            _, _, yolo = self.model.yolox(tr["patches_yolox"], tr["bboxes_yolox"], loss_scale=1.0)
+            yolo = self.model.yolox.loss_and_backward(tr["patches_yolox"], tr["bboxes_yolox"], loss_scale=1.0)
             for k, v in yolo.items():
                 res["yolo_" + k] = v
             res["loss"] = res["loss"] + yolo["total_loss"].cpu()
@@ -148,9 +148,8 @@ class SupervisedTrainer:
         """The body of the reference's loop (src/supervised.py:834-902): trajectories -> [augmentation] ->
         ``model(patches, current_actions, classes, positions)`` -> reference actions -> detector loss -> compute_metrics
         -> ``loss.backward()`` -> every ga-th iteration ``optim.step()`` / ``zero_grad()`` (no clipping).  ``model`` is this
-        package's GPT in train mode: the logits carry a graph whose backward is the engine's; the detector's loss is
-        differentiated inside its own call (its value joins ``loss`` as a constant, its gradients are already in
-        ``param.grad``); the optimisers average the gradients over the ranks with ONE all-reduce of the flat buffer each
+        package's GPT in train mode: the logits carry a graph whose backward is the engine's, and so does the detector's
+        ``total_loss`` (``yolox.py::_DetectorGraph``): ONE ``loss.backward()`` runs both; the optimisers average the gradients over the ranks with ONE all-reduce of the flat buffer each
         (the job DDP's bucketed all-reduce does in the reference, src/supervised.py:815)."""
         cfg, model = self.config, self.model
         self.iter_num += 1
@@ -178,7 +177,7 @@ class SupervisedTrainer:
             if aug is not None:
                 with torch.no_grad():
                     patches_yolox = aug(patches_yolox)
-            _, _, yolo_loss = self.yolox_model()(patches_yolox, batch["bboxes_yolox"])
+            _, _, yolo_loss = self.yolox_model()(patches_yolox, batch["bboxes_yolox"], predict=False)   # :881-888; total_loss has a graph
         metrics = self.compute_metrics(action_logits, reference_actions, masks, yolo_loss)
         metrics["loss"].backward()
         if self.iter_num % int(getattr(cfg, "gradient_accumulation", 1)) == 0:
