@@ -377,6 +377,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if dist is not None and train:
+        trainer.allreduce_timing = []        # (start, end) CUDA events around the iteration's ONE gradient all-reduce
+
     import ctypes as C
     for _ in range(args.warmup):
         one_step()
@@ -393,15 +396,37 @@ def main():
         if train:
             eng.lib.jn_last_timing(eng.handle, 2, C.byref(ms))
             bwd_ms += ms.value
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0           # this rank's own K steps (before it waits for the others)
     sync()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed, float(patches)], device=dev, dtype=torch.float64)
+    multi = None
     if dist is not None:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed, total_patches = float(tmax[0]), float(tsum[1])
+        # diagnostics of the multi-rank run: every rank's own time per step and its all-reduce time per step (CUDA events
+        # on the launch stream: the time the stream spends in / waiting for the collective, i.e. RCCL itself plus the
+        # wait for the slowest rank's backward); the timed steps only
+        ar = trainer.allreduce_timing[-args.steps:] if train and getattr(trainer, "allreduce_timing", None) else []
+        ar_ms = sum(a.elapsed_time(b) for a, b in ar) / max(len(ar), 1)
+        mine = torch.tensor([own / args.steps * 1e3, ar_ms, conv_ms / max(glimpse_steps, 1), bwd_ms / max(glimpse_steps, 1)],
+                            device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        cols = torch.stack(allr).cpu()       # [world, 4]
+        r3 = lambda v: [round(float(x), 3) for x in v]
+        multi = {"rank_ms_per_step": {"min": round(float(cols[:, 0].min()), 3), "max": round(float(cols[:, 0].max()), 3),
+                                      "per_rank": r3(cols[:, 0])},
+                 "allreduce_ms": {"mean": round(float(cols[:, 1].mean()), 4), "max": round(float(cols[:, 1].max()), 4),
+                                  "per_rank": r3(cols[:, 1]), "bytes": int(model._optim_gpt_numel * 4) if train else 0,
+                                  "what": "CUDA events on the launch stream around the ONE flat-gradient all-reduce of an "
+                                          "iteration (collective + wait for the slowest rank); mean over the timed steps"},
+                 "forward_ms_per_pass_per_rank": r3(cols[:, 2]), "backward_ms_per_step_per_rank": r3(cols[:, 3]),
+                 "backend": os.environ.get("JN_BENCH_BACKEND", "nccl")}
     else:
         total_patches = float(patches)
 
@@ -469,6 +494,8 @@ def main():
                                           "glimpse steps over the iteration's wall time)",
                 "achieved": round(it_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(it_ach / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes_per_iteration": int(it_bytes / max(args.steps, 1))}
+        if multi is not None:
+            out["multi_rank"] = multi
         if args.detect:
             out["metric"] += " + yolox-s detection on every visited patch"
             out["config"]["phase"] += "; do_detection=True (yolox-s PAFPN + head + NMS per glimpse)"

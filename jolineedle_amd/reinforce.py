@@ -329,7 +329,8 @@ class ReinforceTrainer:
         if optimizer_step and self.iter_num % ga == 0:
             # the ONE exchange step of the iteration: flat gradient all-reduce (RCCL over xGMI)
             from .dist import allreduce_gradients
-            scale = allreduce_gradients(grads, grads.numel() if detection else self._optim_numel, process_group)
+            scale = allreduce_gradients(grads, grads.numel() if detection else self._optim_numel, process_group,
+                                        timing=getattr(self, "allreduce_timing", None))
             lr = float(getattr(self.config, "learning_rate", 1e-4))
             object.__setattr__(model, "_last_lr", (lr, float(getattr(self.config, "yolo_lr", lr))))     # save_checkpoint's default
             check(eng.lib.jn_optimizer_step(eng.handle, lr, 0.01, 1.0, scale, stream), "jn_optimizer_step")

@@ -1975,26 +1975,37 @@ def test_two_ranks_supervised_loop_averages_gradients(tmp_path):
     assert all(o["run_iters"] == 2 and o["run_loss_finite"] for o in out)
 
 
-def test_bench_two_rank_launch_reports_both_ranks():
-    """`bench.py --gpus 2` as a fresh child process (the parent has not touched the GPU; it starts one rank process per
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_multi_rank_launch_reports_every_rank(ranks):
+    """`bench.py --gpus N` as a fresh child process (the parent has not touched the GPU; it starts one rank process per
     GPU as main.py:428-433 spawns its ranks): rehearsed on ONE GPU over gloo (JN_BENCH_BACKEND / JN_BENCH_SAME_DEVICE).
-    Rank 0's JSON line carries both ranks: n_ranks_seen, the global batch, a finite whole-job value, max-over-ranks time."""
+    Rank 0's JSON line carries every rank: n_ranks_seen, the global batch, a finite whole-job value over the slowest rank's
+    time, and the diagnostics a first real multi-GPU run will be read by: each rank's own time per
+    step, its all-reduce time (events around the ONE collective of an iteration), forward / backward section times.
+    (N = 8 is not rehearsed here: the GPU box allows 6 processes on its card, this one included.)"""
     import json
     import os
     import subprocess
     env = dict(os.environ, JN_BENCH_BACKEND="gloo", JN_BENCH_SAME_DEVICE="1")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None)
     root = Path(__file__).resolve().parent.parent
-    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "8",
-                        "--grid", "3", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    per_rank = 16 // ranks
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--batch",
+                        str(per_rank), "--grid", "3", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["config"]["global_batch"] == 16
+    assert out["n_gpus"] == ranks and out["n_ranks_seen"] == ranks and out["config"]["global_batch"] == 16
     assert out["scaling"] == "weak" and np.isfinite(out["value"]) and out["value"] > 0
-    # whole-job value = patches of BOTH ranks over the slowest rank's time
+    # whole-job value = patches of ALL ranks over the slowest rank's time
     assert abs(out["value"] - 16 * 20 / (out["ms_per_step"] * 1e-3)) < 0.02 * out["value"]
+    mr = out["multi_rank"]
+    assert len(mr["rank_ms_per_step"]["per_rank"]) == ranks and len(mr["allreduce_ms"]["per_rank"]) == ranks
+    assert 0 < mr["rank_ms_per_step"]["min"] <= mr["rank_ms_per_step"]["max"] <= out["ms_per_step"] * 1.001
+    assert all(0 < v < out["ms_per_step"] for v in mr["allreduce_ms"]["per_rank"])
+    assert 5_000_000 < mr["allreduce_ms"]["bytes"] < 6_500_000      # the 1.37 M floats of SURVEY §8e (padded arena)
+    assert all(v > 0 for v in mr["forward_ms_per_pass_per_rank"] + mr["backward_ms_per_step_per_rank"])
 
 
 # --------------------------------------------------------------------------------------
