@@ -1132,7 +1132,7 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
       const int hmask = red_half.count(op.wslot) ? red_half[op.wslot] : 0;
       if (hmask && !cw.prefix2.empty() && net.act_dtype == JN_F32) {
         // merged pair with at least one half reduced by its consumer: the other half (if any) gets its own pass, and the
-        // constants are formed per half (consumer-made sums carry the RAW second moment)
+        // constants are formed per half (consumer-made sums carry the moment against y, see bn_bwd_consts)
         const int h = cw.cout / 2;
         for (int half = 0; half < 2; ++half) {
           const int c0 = half * h;
@@ -1141,14 +1141,14 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
           if (!(hmask & (1 << half)))
             launch_bn_bwd_reduce(gp_out + c0, gld_out, (const float*)ptr(op.out) + c0, net.act_dtype, ld(op.out), ot,
                                  save + 2 * (cw.stat_off + c0), h, M, red + 2 * c0, rep_stride, s, sb);
-          launch_bn_bwd_consts(red + 2 * c0, rep_stride, (double)M, cw.gamma_dev + c0, save + 2 * (cw.stat_off + c0), consts + 3 * c0,
+          launch_bn_bwd_consts(red + 2 * c0, rep_stride, (double)M, cw.gamma_dev + c0, cw.beta_dev + c0, save + 2 * (cw.stat_off + c0), consts + 3 * c0,
                                grad_of(ctx, cw.gamma_dev) + c0, grad_of(ctx, cw.beta_dev) + c0, h, s, sb, (hmask >> half) & 1);
         }
       } else {
         if (!red_done.count(op.wslot))
           launch_bn_bwd_reduce(gp_out, gld_out, ptr(op.out), net.act_dtype, ld(op.out), tab(op.out), save + 2 * cw.stat_off, cw.cout,
                                M, red, rep_stride, s, sb);
-        launch_bn_bwd_consts(red, rep_stride, (double)M, cw.gamma_dev, save + 2 * cw.stat_off, consts,
+        launch_bn_bwd_consts(red, rep_stride, (double)M, cw.gamma_dev, cw.beta_dev, save + 2 * cw.stat_off, consts,
                              grad_of(ctx, cw.gamma_dev), grad_of(ctx, cw.beta_dev), cw.cout, s, sb, red_done.count(op.wslot) ? 1 : 0);
       }
       float* gw = grad_of(ctx, cw.w_dev);

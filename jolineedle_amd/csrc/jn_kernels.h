@@ -174,9 +174,10 @@ int launch_head_pred_bwd(const float* d_raw, const float* scale, const void* reg
 int launch_bn_bwd_reduce(const float* g, int g_ld, const void* z, int z_dtype, int z_ld, ChanTab t, const float* save,
                          int C, long long M, double* red_out, long long rep_stride, hipStream_t s,
                          const SlotBatch& sb = SlotBatch{});
-// sums the replicas -> consts[c] = {sum_gy/n, sum_gy_zhat/n, gamma*invstd}; dgamma/dbeta += totals
-int launch_bn_bwd_consts(const double* red, long long rep_stride, double count, const float* gamma, const float* save,
-                         float* consts, float* g_gamma, float* g_beta, int C, hipStream_t s,
+// sums the replicas -> consts[c] = {sum_gy/n, sum_gy_zhat/n, gamma*invstd}; dgamma/dbeta += totals.  raw_moment: the second
+// sum is sum gy * y (y = gamma * zhat + beta, formed by a consumer's fused kernel) and is converted here
+int launch_bn_bwd_consts(const double* red, long long rep_stride, double count, const float* gamma, const float* beta,
+                         const float* save, float* consts, float* g_gamma, float* g_beta, int C, hipStream_t s,
                          const SlotBatch& sb = SlotBatch{}, int raw_moment = 0);
 int launch_bn_bwd_gz(float* g, int g_ld, const void* z, int z_dtype, int z_ld, ChanTab t, const float* save,
                      const float* consts, int C, long long M, hipStream_t s, const SlotBatch& sb = SlotBatch{});

@@ -112,7 +112,7 @@ int launch_bn_bwd_reduce(const float* g, int g_ld, const void* z, int z_dtype, i
 
 // ---- 2. per-channel constants, then g_a -> g_z in place --------------------------------------
 __global__ void bn_bwd_consts_kernel(const double* __restrict__ red, long long rep_stride, double count,
-                                     const float* __restrict__ gamma, const float* __restrict__ save,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ save,
                                      float* __restrict__ consts, float* __restrict__ g_gamma,
                                      float* __restrict__ g_beta, int C, SlotBatch sb, int raw_moment) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -123,8 +123,15 @@ __global__ void bn_bwd_consts_kernel(const double* __restrict__ red, long long r
   float* cs = consts + sl * sb.consts;
   double s1 = 0.0, s2 = 0.0;
   for (int r = 0; r < JN_NREP; ++r) { s1 += rd[r * rep_stride + 2 * c]; s2 += rd[r * rep_stride + 2 * c + 1]; }
-  // sums formed by a consumer's fused kernel carry sum gy * z: sum gy * zhat = invstd * (sum gy * z - mean * sum gy)
-  if (raw_moment) s2 = (double)sv[2 * c + 1] * (s2 - (double)sv[2 * c] * s1);
+  // sums formed by a consumer's fused kernel carry sum gy * y with y = gamma * zhat + beta (the BatchNorm output the
+  // kernel evaluates anyway): sum gy * zhat = (sum gy * y - beta * sum gy) / gamma.  The subtraction cancels by |beta| / |gamma|
+  // (O(1) for a BatchNorm affine), not by |mean| / std of the conv output as the raw moment sum gy * z did.  gamma == 0: the
+  // layer's output is the constant beta, zhat cannot be recovered from y — d gamma of such a channel is reported as 0
+  // (its data gradient is exactly 0 either way: k = gamma * invstd).
+  if (raw_moment) {
+    const double gm = (double)gamma[c];
+    s2 = gm != 0.0 ? (s2 - (double)beta[c] * s1) / gm : 0.0;
+  }
   cs[3 * c] = (float)(s1 / count);
   cs[3 * c + 1] = (float)(s2 / count);
   cs[3 * c + 2] = gamma[c] * sv[2 * c + 1];
@@ -132,10 +139,10 @@ __global__ void bn_bwd_consts_kernel(const double* __restrict__ red, long long r
   else { atomicAdd(&g_beta[c], (float)s1); atomicAdd(&g_gamma[c], (float)s2); }
 }
 
-int launch_bn_bwd_consts(const double* red, long long rep_stride, double count, const float* gamma, const float* save,
-                         float* consts, float* g_gamma, float* g_beta, int C, hipStream_t s, const SlotBatch& sb,
+int launch_bn_bwd_consts(const double* red, long long rep_stride, double count, const float* gamma, const float* beta,
+                         const float* save, float* consts, float* g_gamma, float* g_beta, int C, hipStream_t s, const SlotBatch& sb,
                          int raw_moment) {
-  hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((C + 63) / 64, sb.n), dim3(64), 0, s, red, rep_stride, count, gamma, save,
+  hipLaunchKernelGGL(bn_bwd_consts_kernel, dim3((C + 63) / 64, sb.n), dim3(64), 0, s, red, rep_stride, count, gamma, beta, save,
                      consts, g_gamma, g_beta, C, sb, raw_moment);
   return 0;
 }
@@ -652,9 +659,13 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
           const f32x4 i_sc = *reinterpret_cast<const f32x4*>(Cs + 7 * N + ch), i_sh = *reinterpret_cast<const f32x4*>(Cs + 7 * N + K + ch);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float gy = m < M ? acc[b][q] * dsilu_(fmaf(zv[q], i_sc[q], i_sh[q])) : 0.0f;
+            const float yv = fmaf(zv[q], i_sc[q], i_sh[q]);
+            const float gy = m < M ? acc[b][q] * dsilu_(yv) : 0.0f;
             const float a1 = row16_sum(gy);
-            const float a2 = row16_sum(gy * zv[q]);      // raw second moment: bn_bwd_consts turns it into sum gy * zhat (fp64)
+            // second moment against the NORMALISED value y = gamma * zhat + beta (bn_bwd_consts turns it into sum gy * zhat):
+            // the raw moment sum gy * z cancels against mean * sum gy there, and its fp32 rounding comes back amplified by
+            // |mean| / std of the producer's output — 1e2 .. 1e3 on the near-constant maps of a fresh network
+            const float a2 = row16_sum(gy * yv);
             if (lm == 0) { rslot[2 * (ch + q)] += a1; rslot[2 * (ch + q) + 1] += a2; }
           }
         }
@@ -1029,9 +1040,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void d
     const f32x4 i_sc = JN_C4(7), i_sh = JN_C4(8);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float gy = dx[k] * dsilu_(fmaf(zv[k], i_sc[k], i_sh[k]));
+      const float yv = fmaf(zv[k], i_sc[k], i_sh[k]);
+      const float gy = dx[k] * dsilu_(yv);
       r1[k] += gy;
-      r2[k] += gy * zv[k];          // raw second moment: bn_bwd_consts turns it into sum gy * zhat (fp64)
+      r2[k] += gy * yv;             // moment against y = gamma * zhat + beta: bn_bwd_consts turns it into sum gy * zhat (fp64)
     }
   };
   const int xx = (tid / Q) % DF_TW, grp = tid / (Q * DF_TW), j0 = grp * RPG;
