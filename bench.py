@@ -365,7 +365,8 @@ def main():
     def one_step():
         env = ja.NeedleGeneralEnv(images, bboxes, P, T, 1, True, engine=eng)
         if train:
-            m = trainer.train_iteration(env, forced_actions=forced, start_positions=start, sample_actions=True)
+            m = trainer.train_iteration(env, forced_actions=forced, start_positions=start, sample_actions=True,
+                                        stop_early=not os.environ.get("JN_BENCH_NO_STOP_EARLY"))   # (measuring aid: no skip flags)
             return m["steps"], m["loss"]
         ro = trainer.rollout(env, forced_actions=forced, start_positions=start, keep_patches=False,
                              do_detection=args.detect, sample_actions=True)

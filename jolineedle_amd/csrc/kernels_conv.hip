@@ -1186,14 +1186,21 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long r
                                    float* __restrict__ run_var, float* __restrict__ save, ChanTab t0, ChanTab t1,
                                    int C, float eps, float momentum, const int* __restrict__ skip_flag,
                                    int skip_when) {
-  if (skip_flag && *skip_flag >= skip_when) return;
-  // 8 lanes per channel, 4 replicas each (independent loads), then three DPP-free xor steps inside the octet
+  // 8 lanes per channel, 4 replicas each (independent loads), then three DPP-free xor steps inside the octet.  Every
+  // load of the kernel — the skip flag, the sums, the affine — is requested before the first one is waited for: the
+  // kernel is three dependent round trips long otherwise (flag -> sums -> gamma / beta), and it runs 26 times per pass
   const int sub = threadIdx.x & 7;
   const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
   const int cc = c < C ? c : C - 1;
+  const int flag = skip_flag ? *skip_flag : skip_when - 1;
+  const float gm = gamma[cc], bt = beta[cc];
+  double v1[JN_NREP / 8], v2[JN_NREP / 8];
+#pragma unroll
+  for (int k = 0; k < JN_NREP / 8; ++k) { v1[k] = stats[(sub + 8 * k) * rep_stride + 2 * cc]; v2[k] = stats[(sub + 8 * k) * rep_stride + 2 * cc + 1]; }
+  if (flag >= skip_when) return;
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-  for (int r = sub; r < JN_NREP; r += 8) { s1 += stats[r * rep_stride + 2 * cc]; s2 += stats[r * rep_stride + 2 * cc + 1]; }
+  for (int k = 0; k < JN_NREP / 8; ++k) { s1 += v1[k]; s2 += v2[k]; }
 #pragma unroll
   for (int off = 1; off < 8; off <<= 1) { s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); }
   if (sub != 0 || c >= C) return;
@@ -1201,8 +1208,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long r
   double var = s2 / count - mean * mean;
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float sc = gamma[c] * invstd;
-  const float sh = beta[c] - (float)mean * sc;
+  const float sc = gm * invstd;
+  const float sh = bt - (float)mean * sc;
   t0.sc[c] = sc; t0.sh[c] = sh; t0.fl[c] = 1.0f;
   if (t1.sc) { t1.sc[c] = sc; t1.sh[c] = sh; t1.fl[c] = 1.0f; }
   if (save) { save[2 * c] = (float)mean; save[2 * c + 1] = invstd; }
