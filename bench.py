@@ -465,7 +465,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(algo_bytes),
                          "timing": "HIP events around the conv section of every glimpse step, on the launch stream "
                                    "(jn_set_profiling / jn_last_timing); rocprofv3 kernel stats of the same command: "
-                                   "profiles/r03_*_train_iteration_kernel_stats.csv"},
+                                   "profiles/r04_*_train_iteration_kernel_stats.csv"},
         }
         if train and args.config == "c3":
             # second entry: the step-batched conv-stack backward (embed_fpn + PAFPN), priced at its ALGORITHMIC traffic:
@@ -485,7 +485,7 @@ def main():
                 "note": "algorithmic = 2 (in + out) elements per layer; the labelled second figure adds one re-read of g_out and "
                         "z_out per layer (what a separate BatchNorm-backward reduction pass costs) and is not a roofline claim",
                 "timing": "HIP events around the conv-stack backward of the iteration (jn_last_timing(2)); per-op table: "
-                          "profiles/r03_*_backward_table_f32.txt"}
+                          "profiles/r04_*_backward_table_f32.txt"}
             # third entry: the whole iteration against the same roof — forward + backward algorithmic bytes of every
             # executed glimpse step over the wall time of the iteration (everything else included in the time)
             it_bytes = (algo_bytes + bwd_bytes) * glimpse_steps

@@ -1001,10 +1001,12 @@ static inline bool views_overlap(const View& a, const View& b) {
 // Backward fusion of a producer's BN reduce into its consumer: returns the index of the ONE BatchNorm conv whose
 // output view is exactly ops[obi].in, provided ops[obi] is the only reader of that view, nothing else writes into it
 // and no gradient arrives from outside the network (FPN outputs); -1 otherwise.
-static int sole_producer(const Net& net, int obi) {
+// fpn_zero: bit i set = NO gradient arrives in net.fpn[i] from outside the network in this backward (the REINFORCE /
+// supervised backward only feeds fpn[2]); such a view is an ordinary single-consumer output.
+static int sole_producer(const Net& net, int obi, int fpn_zero = 0) {
   const View& v = net.ops[obi].in;
   for (int i = 0; i < 3; ++i)
-    if (views_overlap(v, net.fpn[i])) return -1;
+    if (!((fpn_zero >> i) & 1) && views_overlap(v, net.fpn[i])) return -1;
   int prod = -1;
   for (int j = 0; j < (int)net.ops.size(); ++j) {
     const Op& o = net.ops[j];
@@ -1029,10 +1031,10 @@ static int sole_producer(const Net& net, int obi) {
 // kernel has absorbed).  The reader then holds the FINAL gradient of the segment and can form that layer's BN-backward
 // sums in its epilogue.
 struct RedRun { int wslot = -1; int half = -1; };     // half -1: whole conv
-static bool red_segment(const Net& net, int reader, int buf, int coff, int C, int folded_addact, RedRun& out) {
+static bool red_segment(const Net& net, int reader, int buf, int coff, int C, int folded_addact, RedRun& out, int fpn_zero = 0) {
   View seg; seg.buf = buf; seg.coff = coff; seg.C = C;
   for (int i = 0; i < 3; ++i)
-    if (views_overlap(seg, net.fpn[i])) return false;
+    if (!((fpn_zero >> i) & 1) && views_overlap(seg, net.fpn[i])) return false;
   int prod = -1;
   for (int j = 0; j < (int)net.ops.size(); ++j) {
     const Op& o = net.ops[j];
@@ -1065,7 +1067,7 @@ static bool red_segment(const Net& net, int reader, int buf, int coff, int C, in
 // costs the launches of one pass.  g[fpn views] must hold the incoming gradients; parameter gradients are
 // accumulated into ctx->grads.  ss.positions belongs to the first pass, pos_slot_stride int64s separate passes.
 static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, hipStream_t s, int nsl = 1,
-                            long long pos_slot_stride = 0, bool with_head = false) {
+                            long long pos_slot_stride = 0, bool with_head = false, int fpn_zero = 0) {
   Net& net = ctx->nets[ni];
   const int MB = ctx->cfg.max_batch;
   JN_CHECK(nsl >= 1 && nsl <= net.g_slots && slot + nsl <= net.n_slots, JN_ESTATE, "backward over %d slots from %d: not allocated", nsl, slot);
@@ -1126,10 +1128,16 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
       double* red = net.bred + 2 * cw.stat_off;
       float* consts = net.bconsts + 3 * cw.stat_off;
       static const bool dbg_plan = std::getenv("JN_DBG_BWD_PLAN") != nullptr;
-      if (dbg_plan)
-        std::fprintf(stderr, "[bwd-plan] %-28s kind %d cout %4d cin %4d M/patch %6lld stride %d acc_in %d reduce %s\n", op.name.c_str(), (int)op.kind,
-                     cw.cout, cw.cin, M / N, op.stride, (int)op.acc_in, red_done.count(op.wslot) ? "fused" : "SEPARATE");
       const int hmask = red_half.count(op.wslot) ? red_half[op.wslot] : 0;
+      if (dbg_plan) {
+        // elements per patch that a separate bn_bwd_reduce pass re-reads (g and z: 8 bytes each); merged pairs per half
+        const bool pair_halves = hmask && !cw.prefix2.empty() && net.act_dtype == JN_F32;
+        const long long sep = red_done.count(op.wslot) ? 0 : pair_halves ? (M / N) * (cw.cout / 2) * (2 - ((hmask & 1) + ((hmask >> 1) & 1)))
+                                                                         : (M / N) * cw.cout;
+        std::fprintf(stderr, "[bwd-plan] %-34s kind %d cout %4d cin %4d M/patch %6lld stride %d acc_in %d separate-reduce elements/patch %8lld%s\n",
+                     op.name.c_str(), (int)op.kind, cw.cout, cw.cin, M / N, op.stride, (int)op.acc_in, sep,
+                     pair_halves ? (hmask == 3 ? " (both halves by their consumers)" : " (one half by its consumer)") : "");
+      }
       if (hmask && !cw.prefix2.empty() && net.act_dtype == JN_F32) {
         // merged pair with at least one half reduced by its consumer: the other half (if any) gets its own pass, and the
         // constants are formed per half (consumer-made sums carry the moment against y, see bn_bwd_consts)
@@ -1217,14 +1225,23 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
         fa.gin = gptr(op.in); fa.gin_ld = ld(op.in); fa.accumulate = op.acc_in ? 1 : 0; fa.gw = gw; fa.wpart = ctx->wpart;
         fa.C = cw.cout; fa.H = op.in.H; fa.W = op.in.W; fa.OH = op.out.H; fa.OW = op.out.W; fa.N = N; fa.stride = op.stride;
         fa.sb = sb;
-        // stride 1 only: the stride-2 kernel (one thread = a 2 x 2 input block) loses more to the extra loads than the
-        // separate reduce pass costs (measured on the stem output: +2.0 ms against 1.6 ms saved)
-        if (!op.acc_in && !no_red_fusion && op.stride == 1) {
-          const int prod = sole_producer(net, obi);
-          if (prod >= 0) {
-            const ConvW& pcw = net.convs[net.ops[prod].wslot];
-            fa.red_in = net.bred + 2 * pcw.stat_off; fa.red_rep_stride = rep_stride;
-            red_done.insert(net.ops[prod].wslot);
+        // stride 2 (round 4): the owner-staged variant of the kernel (every thread stages the 2 x 2 input block it
+        // differentiates and keeps the raw values); round 3's variant re-read the input inside the gradient loop and lost
+        // more than the separate pass costs.  A view that only the network's outside could also write (an FPN output) and
+        // that gets no outside gradient in this backward (fpn_zero) is an ordinary single-consumer output: this kernel
+        // then WRITES its gradient (the buffer holds zeros) and forms the producer's sums like for any other.
+        static const bool no_s2_red = std::getenv("JN_NO_S2_RED") != nullptr;
+        if (!no_red_fusion && (op.stride == 1 || !no_s2_red)) {
+          bool ext_zero = false;
+          for (int i = 0; i < 3; ++i) ext_zero = ext_zero || (((fpn_zero >> i) & 1) && views_overlap(op.in, net.fpn[i]));
+          if (!op.acc_in || ext_zero) {
+            const int prod = sole_producer(net, obi, fpn_zero);
+            if (prod >= 0) {
+              const ConvW& pcw = net.convs[net.ops[prod].wslot];
+              fa.red_in = net.bred + 2 * pcw.stat_off; fa.red_rep_stride = rep_stride;
+              fa.accumulate = 0;                      // sole reader: nothing but the (zero) outside seed was there before
+              red_done.insert(net.ops[prod].wslot);
+            }
           }
         }
         launch_dw_bwd_fused(fa, s);
@@ -2314,7 +2331,8 @@ static int reinforce_backward_impl(jn_ctx* ctx, const jn_rollout_out* out, int S
     }
     StemSrc ss{e.images, out->positions_dev + 2 * t0, 3LL * e.H * e.W, (long long)e.H * e.W, e.W};
     ss.pos_stride = 2 * (T + 1);
-    if ((rc = run_net_backward(ctx, ctx->enc_net, B, ss, t0 + 1, s, g_n, 2))) return rc;
+    // (only fpn[2] carries a gradient from outside the encoder: embed_fpn; the other two FPN views were zeroed above)
+    if ((rc = run_net_backward(ctx, ctx->enc_net, B, ss, t0 + 1, s, g_n, 2, false, 0x3))) return rc;
   }
   if (ctx->profiling && ctx->ev[3]) { JN_HIP(hipEventRecord(ctx->ev[3], s)); ctx->bwd_timed = true; }
   (void)P;
@@ -2449,7 +2467,7 @@ static int supervised_backward_impl(jn_ctx* ctx, hipStream_t s) {
     const View& f = net.fpn[i];
     JN_HIP(hipMemsetAsync(net.gact + net.buf_off[f.buf] * (size_t)MB + f.coff, 0, (size_t)N * f.H * f.W * f.C * sizeof(float), s));
   }
-  if ((rc = run_net_backward(ctx, ctx->enc_net, N, ss, 0, s))) return rc;
+  if ((rc = run_net_backward(ctx, ctx->enc_net, N, ss, 0, s, 1, 0, false, 0x3))) return rc;
   JN_HIP(hipGetLastError());
   return JN_OK;
 }

@@ -103,6 +103,7 @@ struct DwPwArgs {
 bool dwpw_supported(int C, int cout, int stride);
 int launch_dwpw(const DwPwArgs& a, hipStream_t s);
 int launch_stem(const StemArgs& a, hipStream_t s);
+bool stem_rows_aligned(const StemArgs& a);        // the stem kernels may fetch the image tile with 16-byte loads
 int launch_dw(const ConvArgs& a, hipStream_t s);
 int launch_pw(const ConvArgs& a, hipStream_t s);
 bool pw_res_supported(const ConvArgs& a);              // kernels_pwres.hip: shapes the resident-weight 1x1 kernels take (K, N >= 64)

@@ -1048,6 +1048,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void d
   };
   const int xx = (tid / Q) % DF_TW, grp = tid / (Q * DF_TW), j0 = grp * RPG;
   const int wg = blockIdx.x / ncb, n_wg = gridDim.x / ncb;
+  // stride 2 with RED (round 4): every input pixel of the tile outside its first row / column belongs to the 2 x 2 block
+  // of exactly ONE thread — the thread that forms its data gradient.  That thread stages it (raw value kept in registers,
+  // activated value to LDS), so the reduction epilogue needs no second read of the input; the first version of this variant
+  // re-read the raw input from global memory inside the gradient loop and lost more than the separate pass costs.
+  constexpr bool OWNER = S == 2 && RED;
+  static_assert(!OWNER || RPG == 1, "owner staging: one output pixel per thread and tile");
+  f32x4 zraw[OWNER ? 4 : 1];
   for (int tile = wg; tile < n_tiles; tile += n_wg) {
     const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const int oy0 = ty * DF_TH, ox0 = tx * DF_TW;
@@ -1073,13 +1080,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void d
       }
       *reinterpret_cast<f32x4*>(Gs + p * PS + 4 * q) = v;
     }
-    for (int i = tid; i < AH * AW * Q; i += 256) {
-      const int p = i / Q, r = p / AW, cx = p - r * AW;
-      const int iy = ay0 + r, ix = ax0 + cx;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-        v = tf4_(*reinterpret_cast<const f32x4*>(x + (((long long)n * H + iy) * W + ix) * x_ld + c), JN_C4(7), JN_C4(8), JN_C4(9));
-      *reinterpret_cast<f32x4*>(As + p * PS + 4 * q) = v;
+    if constexpr (OWNER) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {                 // the thread's own 2 x 2 block: tile rows 2 j0 + 1 (+ 1), columns 2 xx + 1 (+ 1)
+        const int r = 2 * j0 + 1 + (d >> 1), cx = 2 * xx + 1 + (d & 1);
+        const int iy = ay0 + r, ix = ax0 + cx;      // >= 0 by construction
+        zraw[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy < H && ix < W) {
+          zraw[d] = *reinterpret_cast<const f32x4*>(x + (((long long)n * H + iy) * W + ix) * x_ld + c);
+          v = tf4_(zraw[d], JN_C4(7), JN_C4(8), JN_C4(9));
+        }
+        *reinterpret_cast<f32x4*>(As + (r * AW + cx) * PS + 4 * q) = v;
+      }
+      for (int i = tid; i < (AW + AH - 1) * Q; i += 256) {     // the halo: row 0, then column 0 of the rows below
+        const int p = i / Q, r = p < AW ? 0 : p - AW + 1, cx = p < AW ? p : 0;
+        const int iy = ay0 + r, ix = ax0 + cx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+          v = tf4_(*reinterpret_cast<const f32x4*>(x + (((long long)n * H + iy) * W + ix) * x_ld + c), JN_C4(7), JN_C4(8), JN_C4(9));
+        *reinterpret_cast<f32x4*>(As + (r * AW + cx) * PS + 4 * q) = v;
+      }
+    } else {
+      for (int i = tid; i < AH * AW * Q; i += 256) {
+        const int p = i / Q, r = p / AW, cx = p - r * AW;
+        const int iy = ay0 + r, ix = ax0 + cx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+          v = tf4_(*reinterpret_cast<const f32x4*>(x + (((long long)n * H + iy) * W + ix) * x_ld + c), JN_C4(7), JN_C4(8), JN_C4(9));
+        *reinterpret_cast<f32x4*>(As + p * PS + 4 * q) = v;
+      }
     }
     __syncthreads();
 #pragma unroll 1
@@ -1116,19 +1146,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void d
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx)
             dw[ky * 3 + kx] += g00 * *reinterpret_cast<const f32x4*>(As + ((2 * y + ky) * AW + 2 * xx + kx) * PS + 4 * q);
-        // the 2 x 2 input block (2y + dy, 2xx + dx): taps with (dy + 1 - ky), (dx + 1 - kx) even
-        f32x4 r[4];
-        r[0] = g00 * JN_C4(14);                                                      // (even, even): ky = kx = 1
-        r[1] = g01 * JN_C4(13) + g00 * JN_C4(15);                                    // (even, odd): ky = 1, kx = 0 | 2
-        r[2] = g10 * JN_C4(11) + g00 * JN_C4(17);                                    // (odd, even): kx = 1, ky = 0 | 2
-        r[3] = g11 * JN_C4(10) + g10 * JN_C4(12) + g01 * JN_C4(16) + g00 * JN_C4(18);   // (odd, odd)
+        // the 2 x 2 input block (2y + dy, 2xx + dx): taps with (dy + 1 - ky), (dx + 1 - kx) even; one block pixel at a
+        // time (formed, reduced, stored) so that only one of the four gradients is live
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           const int iy = 2 * (oy0 + y) + (d >> 1), ix = 2 * (ox0 + xx) + (d & 1);
           if (iy < H && ix < W) {
             float* op = gin + (((long long)n * H + iy) * W + ix) * gin_ld + c;
-            f32x4 v = r[d];
-            if (RED) reduce_in(*reinterpret_cast<const f32x4*>(x + (((long long)n * H + iy) * W + ix) * x_ld + c), v);
+            f32x4 v;
+            if (d == 0) v = g00 * JN_C4(14);                                                              // (even, even): ky = kx = 1
+            else if (d == 1) v = g01 * JN_C4(13) + g00 * JN_C4(15);                                       // (even, odd): ky = 1, kx = 0 | 2
+            else if (d == 2) v = g10 * JN_C4(11) + g00 * JN_C4(17);                                       // (odd, even): kx = 1, ky = 0 | 2
+            else v = g11 * JN_C4(10) + g10 * JN_C4(12) + g01 * JN_C4(16) + g00 * JN_C4(18);               // (odd, odd)
+            if constexpr (OWNER) reduce_in(zraw[d], v);
             if (accumulate) v += *reinterpret_cast<const f32x4*>(op);
             *reinterpret_cast<f32x4*>(op) = v;
           }
@@ -1205,6 +1235,8 @@ constexpr int SB_TY = 8, SB_TX = 32, SB_IH = 2 * SB_TY + 4, SB_IW = 2 * SB_TX + 
 // k-slots of an MFMA take pixels 8 apart (16 banks apart); g_z rows of 8 pixels are padded by 16 floats per slot group
 constexpr int SB_IWP = 70, SB_GZG = 8 * 16 + 16, SB_GZROW = 4 * SB_GZG;
 
+constexpr int SB_W4 = SB_IW / 4 + 1;     // float4 groups per row of the aligned window (see stem_mfma_kernel, VEC)
+template <bool VEC>
 __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
     const float* __restrict__ src, const long long* __restrict__ pos, int pos_stride, long long sample_stride,
     long long chan_stride, int row_stride, int P, const float* __restrict__ gz, int g_ld, int cout, int ocg,
@@ -1248,21 +1280,36 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
   // persistent over (image, tile): the partial dW stays in registers, ONE set of atomics per workgroup; the next
   // tile's image values and gradients are fetched into registers while the MFMAs of the current one run
   constexpr int NI = (3 * SB_IH * SB_IW + 255) / 256, NG = SB_TY * SB_TX * 4 / 256;
-  float pim[NI];
+  constexpr int NI4 = (3 * SB_IH * SB_W4 + 255) / 256;
+  float pim[VEC ? 1 : NI];
+  f32x4 pim4[VEC ? NI4 : 1];
   f32x4 pg[NG], pz[NG];
   auto fetch = [&](int tl) {
     const int n = tl / (tiles_x * tiles_y), tr = tl % (tiles_x * tiles_y);
     const int oy0 = (tr / tiles_x) * SB_TY, ox0 = (tr % tiles_x) * SB_TX;
     const float* base = src + (long long)n * sample_stride;
     if (pos) base += pos[(long long)pos_stride * n] * (long long)P * row_stride + pos[(long long)pos_stride * n + 1] * (long long)P;
+    if constexpr (VEC) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int i = tid + 256 * j;
-      const int c = i / (SB_IH * SB_IW), r = (i / SB_IW) % SB_IH, q = i % SB_IW;
-      const int iy = 2 * oy0 - 2 + r, ix = 2 * ox0 - 2 + q;
-      float v = 0.0f;
-      if (i < 3 * SB_IH * SB_IW && iy >= 0 && iy < P && ix >= 0 && ix < P) v = base[c * chan_stride + (long long)iy * row_stride + ix];
-      pim[j] = v;
+      for (int j = 0; j < NI4; ++j) {
+        const int i = tid + 256 * j;
+        const int c = i / (SB_IH * SB_W4), r = (i / SB_W4) % SB_IH, q4 = i % SB_W4;
+        const int iy = 2 * oy0 - 2 + r, ix = 2 * ox0 - 4 + 4 * q4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (i < 3 * SB_IH * SB_W4 && iy >= 0 && iy < P && ix >= 0 && ix < P)
+          v = *reinterpret_cast<const f32x4*>(base + c * chan_stride + (long long)iy * row_stride + ix);
+        pim4[j] = v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int i = tid + 256 * j;
+        const int c = i / (SB_IH * SB_IW), r = (i / SB_IW) % SB_IH, q = i % SB_IW;
+        const int iy = 2 * oy0 - 2 + r, ix = 2 * ox0 - 2 + q;
+        float v = 0.0f;
+        if (i < 3 * SB_IH * SB_IW && iy >= 0 && iy < P && ix >= 0 && ix < P) v = base[c * chan_stride + (long long)iy * row_stride + ix];
+        pim[j] = v;
+      }
     }
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
@@ -1280,10 +1327,23 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(
   if (tl < n_tiles) fetch(tl);
   for (; tl < n_tiles; tl += gridDim.x) {
     __syncthreads();
+    if constexpr (VEC) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int i = tid + 256 * j;
-      if (i < 3 * SB_IH * SB_IW) tile[(i / SB_IW) * SB_IWP + i % SB_IW] = pim[j];
+      for (int j = 0; j < NI4; ++j) {
+        const int i = tid + 256 * j;
+        if (i < 3 * SB_IH * SB_W4) {
+          const int q4 = i % SB_W4;
+          float* d = tile + (i / SB_W4) * SB_IWP + 4 * q4 - 2;               // 8-byte aligned (row = 280 bytes)
+          if (q4 > 0) *reinterpret_cast<float2*>(d) = float2{pim4[j].x, pim4[j].y};
+          if (q4 < SB_W4 - 1) *reinterpret_cast<float2*>(d + 2) = float2{pim4[j].z, pim4[j].w};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int i = tid + 256 * j;
+        if (i < 3 * SB_IH * SB_IW) tile[(i / SB_IW) * SB_IWP + i % SB_IW] = pim[j];
+      }
     }
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
@@ -1358,9 +1418,12 @@ int launch_stem_bwd_weight(const StemArgs& a, const float* gz, int g_ld, float* 
   const int n_tiles = tiles_x * tiles_y * a.N;
   const int cap = sb.n >= 4 ? 256 : 1024 / sb.n;
   dim3 grid(n_tiles < cap ? n_tiles : cap, ocg, sb.n);
-  hipLaunchKernelGGL(stem_bwd_weight_kernel, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.pos_stride,
-                     a.sample_stride, a.chan_stride, a.row_stride, a.P, gz, g_ld, a.cout, ocg, tiles_x, tiles_y, n_tiles,
-                     wpart, sb.pos, sb.grad, z, z_ld, ot, save, consts, sb);
+#define JN_STEMB(V_)                                                                                                      \
+  hipLaunchKernelGGL(stem_bwd_weight_kernel<V_>, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.pos_stride, \
+                     a.sample_stride, a.chan_stride, a.row_stride, a.P, gz, g_ld, a.cout, ocg, tiles_x, tiles_y, n_tiles,  \
+                     wpart, sb.pos, sb.grad, z, z_ld, ot, save, consts, sb)
+  if (stem_rows_aligned(a)) JN_STEMB(true); else JN_STEMB(false);
+#undef JN_STEMB
   launch_wpart_reduce(gw, wpart, 108 * a.cout, s);
   return 0;
 }

@@ -64,8 +64,16 @@ constexpr int ST_KS = 27;                                     // 108 / 4 k-steps
 // values of the NEXT tile are fetched into registers while the MFMAs of the current one run (the per-tile
 // load -> LDS -> MFMA sequence left the matrix pipe idle two thirds of the time).
 constexpr int ST_NL = (3 * ST_IH * ST_IW + 255) / 256;        // image values per thread per tile
+// VEC: the image tile is fetched with 16-byte loads.  The tile's row window [2 ox0 - 2, 2 ox0 + 66) starts 8 bytes off
+// a 16-byte boundary, so the fetch takes the ALIGNED window [2 ox0 - 4, 2 ox0 + 68): 18 float4 per row, of which the
+// outer halves of the first and last are dropped when the row is written to LDS.  With 4-byte loads the image read was
+// bound by the number of load instructions, not by bytes: 2.3 - 2.5 TB/s whatever the segment length, against 4.1 - 6.2
+// TB/s for the same tiles with 16-byte loads (tools/imgreadbench.hip, profiles/r04_imgreadbench.txt).  Needs 16-byte
+// aligned rows (base pointer, strides and the patch size multiples of four floats: checked by the launcher).
+constexpr int ST_W4 = ST_IW / 4 + 1;                            // float4 groups per row of the aligned window
+constexpr int ST_NL4 = (3 * ST_IH * ST_W4 + 255) / 256;
 
-template <typename OT>
+template <typename OT, bool VEC>
 __global__ __launch_bounds__(256) void stem_mfma_kernel(
     const float* __restrict__ src, const long long* __restrict__ pos, int pos_stride, long long sample_stride,
     long long chan_stride, int row_stride, int P, const float* __restrict__ w, OT* __restrict__ out,
@@ -88,20 +96,34 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(
     const int c = k / 36, dy = (k % 36) / 6, dx = k % 6;
     koff[s] = (c * ST_IH + dy) * ST_IW + dx;
   }
-  float pre[ST_NL];
+  float pre[VEC ? 1 : ST_NL];
+  f32x4 pre4[VEC ? ST_NL4 : 1];
   auto fetch = [&](int tl) {
     const int n = tl / (tiles_x * tiles_y), tr = tl - n * (tiles_x * tiles_y);
     const int oy0 = (tr / tiles_x) * ST_TY, ox0 = (tr % tiles_x) * ST_TX;
     const float* base = src + (long long)n * sample_stride;
     if (pos) base += pos[(long long)pos_stride * n] * (long long)P * row_stride + pos[(long long)pos_stride * n + 1] * (long long)P;
+    if constexpr (VEC) {
 #pragma unroll
-    for (int j = 0; j < ST_NL; ++j) {
-      const int i = tid + 256 * j;
-      const int c = i / (ST_IH * ST_IW), r = (i / ST_IW) % ST_IH, q = i % ST_IW;
-      const int iy = 2 * oy0 - 2 + r, ix = 2 * ox0 - 2 + q;
-      float v = 0.0f;
-      if (i < 3 * ST_IH * ST_IW && iy >= 0 && iy < P && ix >= 0 && ix < P) v = base[c * chan_stride + (long long)iy * row_stride + ix];
-      pre[j] = v;
+      for (int j = 0; j < ST_NL4; ++j) {
+        const int i = tid + 256 * j;
+        const int c = i / (ST_IH * ST_W4), r = (i / ST_W4) % ST_IH, q4 = i % ST_W4;
+        const int iy = 2 * oy0 - 2 + r, ix = 2 * ox0 - 4 + 4 * q4;          // P % 4 == 0: a group is inside the patch or outside
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (i < 3 * ST_IH * ST_W4 && iy >= 0 && iy < P && ix >= 0 && ix < P)
+          v = *reinterpret_cast<const f32x4*>(base + c * chan_stride + (long long)iy * row_stride + ix);
+        pre4[j] = v;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < ST_NL; ++j) {
+        const int i = tid + 256 * j;
+        const int c = i / (ST_IH * ST_IW), r = (i / ST_IW) % ST_IH, q = i % ST_IW;
+        const int iy = 2 * oy0 - 2 + r, ix = 2 * ox0 - 2 + q;
+        float v = 0.0f;
+        if (i < 3 * ST_IH * ST_IW && iy >= 0 && iy < P && ix >= 0 && ix < P) v = base[c * chan_stride + (long long)iy * row_stride + ix];
+        pre[j] = v;
+      }
     }
   };
   f32x4 s1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, s2[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -111,10 +133,23 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(
     const int n = tl / (tiles_x * tiles_y), tr = tl - n * (tiles_x * tiles_y);
     const int oy0 = (tr / tiles_x) * ST_TY, ox0 = (tr % tiles_x) * ST_TX;
     __syncthreads();                                   // the previous tile's MFMAs have read their operands
+    if constexpr (VEC) {
 #pragma unroll
-    for (int j = 0; j < ST_NL; ++j) {
-      const int i = tid + 256 * j;
-      if (i < 3 * ST_IH * ST_IW) tile[i] = pre[j];
+      for (int j = 0; j < ST_NL4; ++j) {
+        const int i = tid + 256 * j;
+        if (i < 3 * ST_IH * ST_W4) {
+          const int q4 = i % ST_W4;
+          float* d = tile + (i / ST_W4) * ST_IW + 4 * q4 - 2;                // 8-byte aligned (row = 272 bytes)
+          if (q4 > 0) *reinterpret_cast<float2*>(d) = float2{pre4[j].x, pre4[j].y};
+          if (q4 < ST_W4 - 1) *reinterpret_cast<float2*>(d + 2) = float2{pre4[j].z, pre4[j].w};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < ST_NL; ++j) {
+        const int i = tid + 256 * j;
+        if (i < 3 * ST_IH * ST_IW) tile[i] = pre[j];
+      }
     }
     __syncthreads();
     if (tl + (int)gridDim.x < n_tiles) fetch(tl + gridDim.x);
@@ -147,6 +182,12 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(
   }
 }
 
+// 16-byte loads of image rows: base pointer, every stride and the patch size must be multiples of four floats
+bool stem_rows_aligned(const StemArgs& a) {
+  return (reinterpret_cast<uintptr_t>(a.src) & 15) == 0 && a.sample_stride % 4 == 0 && a.chan_stride % 4 == 0 &&
+         a.row_stride % 4 == 0 && a.P % 4 == 0;
+}
+
 int launch_stem(const StemArgs& a, hipStream_t s) {
   const int OH = a.P / 2;
   const int ocg = a.cout / 16;
@@ -156,14 +197,14 @@ int launch_stem(const StemArgs& a, hipStream_t s) {
   if (nwg > n_tiles) nwg = n_tiles;
   dim3 grid(nwg, ocg);
   const int nrep = a.stats_nrep > 0 ? a.stats_nrep : JN_NREP;
-  if (a.out_dtype == JN_BF16)
-    hipLaunchKernelGGL(stem_mfma_kernel<bf16_t>, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.pos_stride,
-                       a.sample_stride, a.chan_stride, a.row_stride, a.P, a.w, (bf16_t*)a.out, a.out_ld, a.cout, tiles_x,
-                       tiles_y, n_tiles, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when, nrep);
-  else
-    hipLaunchKernelGGL(stem_mfma_kernel<float>, grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.pos_stride,
-                       a.sample_stride, a.chan_stride, a.row_stride, a.P, a.w, (float*)a.out, a.out_ld, a.cout, tiles_x,
-                       tiles_y, n_tiles, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when, nrep);
+  const bool vec = stem_rows_aligned(a);
+#define JN_STEM(OT_, V_)                                                                                                       \
+  hipLaunchKernelGGL((stem_mfma_kernel<OT_, V_>), grid, dim3(256), 0, s, a.src, (const long long*)a.positions, a.pos_stride, \
+                     a.sample_stride, a.chan_stride, a.row_stride, a.P, a.w, (OT_*)a.out, a.out_ld, a.cout, tiles_x,         \
+                     tiles_y, n_tiles, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when, nrep)
+  if (a.out_dtype == JN_BF16) { if (vec) JN_STEM(bf16_t, true); else JN_STEM(bf16_t, false); }
+  else { if (vec) JN_STEM(float, true); else JN_STEM(float, false); }
+#undef JN_STEM
   return 0;
 }
 
@@ -791,6 +832,11 @@ __global__ __launch_bounds__(256) void pw_mfma_kernel(
 // compute, then all store.  This variant is persistent over pixel tiles: the weight tile is staged ONCE, the next
 // tile's pixels are fetched into registers while the MFMAs and stores of the current one run, the per-thread table
 // quad sits in registers and the BatchNorm sums stay in registers across tiles (one set of fp64 atomics per workgroup).
+// LDS row padding (floats): rows of K + 8 floats are 32 x odd bytes for K = 16 / 32 / 64, the stride at which the
+// ds_read_b128 fragment reads of a 16-lane group cover the 64 banks exactly once (MI355X_MICROARCH.md, LDS)
+#ifndef PWN_PAD
+#define PWN_PAD 8
+#endif
 template <int CT, int KC>
 __global__ __launch_bounds__(256) void pw_narrow_kernel(
     const float* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, float* __restrict__ out, int out_ld,
@@ -800,7 +846,7 @@ __global__ __launch_bounds__(256) void pw_narrow_kernel(
   // waves along the pixel dimension: 2 (64-pixel tiles, wave pairs split the channel tiles) or, for a single channel
   // tile, 4 (128-pixel tiles)
   constexpr int WMW = (CT % 2 == 0) ? 2 : 4;
-  constexpr int LD = KC + 4, BM = 32 * WMW, CTW = CT * WMW / 4, Q4 = KC / 4, NX = BM * Q4 / 256, NW = (16 * CT * Q4 + 255) / 256;
+  constexpr int LD = KC + PWN_PAD, BM = 32 * WMW, CTW = CT * WMW / 4, Q4 = KC / 4, NX = BM * Q4 / 256, NW = (16 * CT * Q4 + 255) / 256;
   static_assert(CTW >= 1 && NX >= 1, "pw_narrow tile mapping");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* Xs = reinterpret_cast<float*>(smem_raw);     // [BM][LD]
@@ -919,13 +965,13 @@ static void launch_pw_narrow_t(const ConvArgs& a, long long M, hipStream_t s) {
   static int cap = 0;
   if (!cap) {
     int per_cu = 0;
-    const size_t sm = (size_t)(BM + 16 * CT) * (KC + 4) * sizeof(float) + (BM / 32) * 32 * CT * sizeof(float);
+    const size_t sm = (size_t)(BM + 16 * CT) * (KC + PWN_PAD) * sizeof(float) + (BM / 32) * 32 * CT * sizeof(float);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&pw_narrow_kernel<CT, KC>), 256, sm) != hipSuccess || per_cu < 1) per_cu = 4;
     cap = per_cu * 256;
   }
   const unsigned gx = (unsigned)std::min<long long>(n_tiles, cap);
   dim3 grid(gx, (unsigned)((a.cout + 16 * CT - 1) / (16 * CT)));
-  const size_t smem = (size_t)(BM + 16 * CT) * (KC + 4) * sizeof(float) + (BM / 32) * 32 * CT * sizeof(float);
+  const size_t smem = (size_t)(BM + 16 * CT) * (KC + PWN_PAD) * sizeof(float) + (BM / 32) * 32 * CT * sizeof(float);
   hipLaunchKernelGGL((pw_narrow_kernel<CT, KC>), grid, dim3(256), smem, s, (const float*)a.in, a.in_ld, a.itab, a.w,
                      (float*)a.out, a.out_ld, M, a.cout, a.stats, a.stats_rep_stride, a.skip_flag, a.skip_when,
                      a.stats_nrep > 0 ? a.stats_nrep : JN_NREP);
