@@ -819,7 +819,7 @@ static void launch_pw_bwd_fused_t(const PwBwdFusedArgs& a, hipStream_t s) {
   launch_pw_bwd_fused_r<CTN, CTK, false>(a, s);
 }
 
-bool pw_bwd_fused_reduces_input(int cout, int cin) { return pw_bwd_fused_supported(cout, cin) && cin <= 64; }
+bool pw_bwd_fused_reduces_input(int cout, int cin) { return pw_bwd_fused_supported(cout, cin) && cin <= 64; }   // (cin = 128 measured: the epilogue of the one-workgroup-per-CU kernels costs more than the 28x28 passes it saves, profiles/r04_ab_red128.txt)
 
 bool pw_bwd_fused_supported(int cout, int cin) {
   if (cout % 16 || cin % 16) return false;
