@@ -836,6 +836,7 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
     for (auto& e : lev) (void)hipEventCreate(&e);
     (void)hipEventRecord(lev[first_op], s);
   }
+  std::set<int> fused_ups;                  // upsample ops whose copy the producing 1x1 kernel wrote
   for (int oi = first_op; oi < n_ops; ++oi) {
     const Op& op = net.ops[oi];
     switch (op.kind) {
@@ -891,7 +892,18 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
         a.stats_rep_stride = rep_stride;
         a.stats_nrep = deferred(op) ? JN_NREP_DEFER : JN_NREP;
         a.skip_flag = skip_flag; a.skip_when = skip_when;
-        if (op.kind == OP_PW) launch_pw(a, s); else if (op.kind == OP_DW) launch_dw(a, s); else launch_conv3(a, s);
+        if (op.kind == OP_PW && net.act_dtype == JN_F32) {
+          // the source of a nearest x2 upsample: the producing kernel writes the upsampled copy itself where its route can
+          for (int uj = oi + 1; uj < n_ops; ++uj) {
+            const Op& up = net.ops[uj];
+            if (up.kind == OP_UPSAMPLE && up.in.buf == op.out.buf && up.in.coff == op.out.coff && up.in.C == op.out.C) {
+              if (pw_fused_upsample_supported(a)) { a.up_out = ptr(up.out); a.up_ld = ld(up.out); fused_ups.insert(uj); }
+              break;
+            }
+          }
+        }
+        if (op.kind == OP_PW) { JN_CHECK(launch_pw(a, s) == 0, JN_ESTATE, "1x1 conv %s: no kernel for this shape", op.name.c_str()); }
+        else if (op.kind == OP_DW) launch_dw(a, s); else launch_conv3(a, s);
         finalize(op, cw);
         break;
       }
@@ -900,8 +912,9 @@ static int run_net(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int slot, int 
                    tab(op.in), skip_flag, skip_when, s);
         break;
       case OP_UPSAMPLE:
-        launch_upsample(ptr(op.in), ld(op.in), ptr(op.out), ld(op.out), net.act_dtype, op.in.C, op.in.H, op.in.W, N, skip_flag,
-                        skip_when, s);
+        if (!fused_ups.count(oi))
+          launch_upsample(ptr(op.in), ld(op.in), ptr(op.out), ld(op.out), net.act_dtype, op.in.C, op.in.H, op.in.W, N, skip_flag,
+                          skip_when, s);
         break;
       case OP_ADDACT:
         launch_addact(ptr(op.in), ld(op.in), tab(op.in), ptr(op.res), ld(op.res), tab(op.res), ptr(op.out), ld(op.out),

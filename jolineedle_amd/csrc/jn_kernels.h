@@ -90,6 +90,8 @@ struct ConvArgs {
   int n_slots;                           // pw: gridDim.z slots, pointers advance by the strides below (0 -> 1 slot)
   long long in_slot_stride, out_slot_stride, tab_slot_stride;
   const void* w_x3;                      // 1x1, fp32: the weights split into three bf16 planes (launch_w_split3), or null
+  void* up_out; int up_ld;               // 1x1, fp32: also store the output nearest-x2 upsampled here (pixel stride up_ld floats), see
+                                         // pw_fused_upsample_supported; null: no
 };
 
 // eval-mode DWConv (depthwise 3x3 -> BN + SiLU -> pointwise 1x1) in one kernel; mtab = table of the depthwise output
@@ -106,6 +108,7 @@ int launch_stem(const StemArgs& a, hipStream_t s);
 bool stem_rows_aligned(const StemArgs& a);        // the stem kernels may fetch the image tile with 16-byte loads
 int launch_dw(const ConvArgs& a, hipStream_t s);
 int launch_pw(const ConvArgs& a, hipStream_t s);
+bool pw_fused_upsample_supported(const ConvArgs& a);   // launch_pw(a) with a.up_out set will take a route that writes the upsampled copy
 bool pw_res_supported(const ConvArgs& a);              // kernels_pwres.hip: shapes the resident-weight 1x1 kernels take (K, N >= 64)
 int launch_pw_dir(const ConvArgs& a, int ctw, int split, hipStream_t s);
 int launch_pw_wide(const ConvArgs& a, hipStream_t s);   // production route: 0 when taken

@@ -1070,8 +1070,20 @@ static int launch_pw_small_maps(const ConvArgs& a, hipStream_t s) {
   return launch_pw_xs(a, 0, s);
 }
 
+// The two layers whose output feeds a nearest x2 upsample (lateral_conv0 256 -> 128, reduce_conv1 128 -> 64) on the
+// small-map routes of the headline batch: their kernel can store the upsampled copy itself (a.up_out).  Mirrors the
+// route choice of launch_pw_small_maps; any other shape / route keeps the separate upsample launch.
+bool pw_fused_upsample_supported(const ConvArgs& a) {
+  static const bool off = std::getenv("JN_NO_PW_XS") != nullptr || std::getenv("JN_NO_FUSED_UPSAMPLE") != nullptr;
+  static const long long max_m = std::getenv("JN_XS_MAX_M") ? std::atoll(std::getenv("JN_XS_MAX_M")) : 262144;
+  if (off || (long long)a.N * a.H * a.W > max_m || !pw_xs_supported(a)) return false;
+  if (a.cin == 128 && a.cout == 64) return pw_x3_preferred(a);          // pw_x3_kernel<128, 1, 2, 4>
+  return a.cin == 256 && a.cout == 128;                                  // pw_xs_kernel<256, 2, 2, 4>
+}
+
 int launch_pw(const ConvArgs& a, hipStream_t s) {
   if (launch_pw_small_maps(a, s) == 0) return 0;           // small maps, forward: pixel-stationary kernel (kernels_pwxs.hip)
+  if (a.up_out) return -1;                                 // (the caller asked pw_fused_upsample_supported first)
   if (launch_pw_wide(a, s) == 0) return 0;                // K, N >= 64: weight-stationary kernel (kernels_pwres.hip)
   if (launch_pw_narrow(a, s)) return 0;
   if (!a.bf16_mfma) {

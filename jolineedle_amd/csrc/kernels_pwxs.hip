@@ -33,11 +33,29 @@
 
 namespace jnr {
 
-template <int K, int CTW, int PT, int D>
+// UPS (round 4): the layer's output is also the source of a nearest x2 upsample into a concat slice of the next stage
+// (lateral_conv0, reduce_conv1): the kernel stores every output quad to its four places in that slice as well, and the
+// upsample launch — a read of the map it has just written and a 4x write — disappears.  Own instantiation, two shapes.
+struct UpsDst { float* out; int ld; int W; int HW; };     // destination slice (pixel stride ld floats), source map W x (HW / W)
+template <bool UPS>
+__device__ __forceinline__ void ups_store(const UpsDst& u, long long m, int n, const f32x4& v) {
+  if constexpr (UPS) {
+    const long long img = m / u.HW;
+    const int rem = (int)(m - img * u.HW), y = rem / u.W, x = rem - y * u.W;
+    float* d = u.out + ((img * 2 * (u.HW / u.W) + 2 * y) * (2LL * u.W) + 2 * x) * u.ld + n;
+    *reinterpret_cast<f32x4*>(d) = v;
+    *reinterpret_cast<f32x4*>(d + u.ld) = v;
+    d += 2LL * u.W * u.ld;
+    *reinterpret_cast<f32x4*>(d) = v;
+    *reinterpret_cast<f32x4*>(d + u.ld) = v;
+  }
+}
+
+template <int K, int CTW, int PT, int D, bool UPS = false>
 __global__ __launch_bounds__(256, (K <= 64 ? 3 : (K <= 128 || (K == 256 && CTW <= 2)) ? 2 : 1)) void pw_xs_kernel(
     const float* __restrict__ x, int x_ld, ChanTab it, const float* __restrict__ w, float* __restrict__ out, int out_ld,
     long long M, double* __restrict__ stats, long long rep_stride, int nrep, const int* __restrict__ skip_flag,
-    int skip_when) {
+    int skip_when, UpsDst ups) {
   if (skip_flag && *skip_flag >= skip_when) return;
   constexpr int BM = 16 * PT, LDX = K + 8, KQ = K / 4, NJ = K / 16, N = 64 * CTW;
   constexpr int NX = BM * KQ / 256;                    // float4 of the operand tile per thread
@@ -149,7 +167,7 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : (K <= 128 || (K == 256 && CTW <
       for (int p = 0; p < PT; ++p) {
         const long long m = m0 + 16 * p + lm;
         const f32x4 v = acc[c][p];
-        if (m < M) *reinterpret_cast<f32x4*>(out + m * out_ld + n) = v;
+        if (m < M) { *reinterpret_cast<f32x4*>(out + m * out_ld + n) = v; ups_store<UPS>(ups, m, n, v); }
         s1[c] += v; s2[c] += v * v;                       // rows past the end are exact zeros
       }
     }
@@ -178,11 +196,11 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : (K <= 128 || (K == 256 && CTW <
   }
 }
 
-template <int K, int CTW, int PT, int D>
+template <int K, int CTW, int PT, int D, bool UPS = false>
 static void launch_pw_xs_t(const ConvArgs& a, long long M, int wg_per_cu, hipStream_t s) {
   constexpr int BM = 16 * PT;
   const size_t smem = ((size_t)BM * (K + 8) + 3 * K) * sizeof(float);
-  auto kern = pw_xs_kernel<K, CTW, PT, D>;
+  auto kern = pw_xs_kernel<K, CTW, PT, D, UPS>;
   static int places = 0;
   if (!places) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -197,7 +215,7 @@ static void launch_pw_xs_t(const ConvArgs& a, long long M, int wg_per_cu, hipStr
   const long long gx = std::min<long long>(n_tiles, 256LL * per_cu);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), smem, s, (const float*)a.in, a.in_ld, a.itab, a.w, (float*)a.out,
                      a.out_ld, M, a.stats, a.stats_rep_stride, a.stats_nrep > 0 ? a.stats_nrep : JN_NREP, a.skip_flag,
-                     a.skip_when);
+                     a.skip_when, UpsDst{(float*)a.up_out, a.up_ld, a.W, a.H * a.W});
 }
 
 // Shapes the kernel takes: fp32 forward (no bias / activation epilogue, weight [N][K] not transposed, one slot),
@@ -225,6 +243,11 @@ int launch_pw_xs(const ConvArgs& a, int pt, hipStream_t s, int wg_per_cu) {
     const bool big = K == 512 || (K == 64 && ctw == 2);
     pt = big ? 4 : 2;
     if (wg_per_cu == 0) wg_per_cu = big ? 1 : 2;
+  }
+  if (a.up_out) {                       // fused x2 upsample of the output: the one shape that needs it on this route
+    if (!(K == 256 && ctw == 2 && pt == 2)) return -1;
+    launch_pw_xs_t<256, 2, 2, 4, true>(a, M, wg_per_cu, s);
+    return 0;
   }
 #define JN_XS(K_, C_, D_)                                                          \
   if (K == K_ && ctw == C_) {                                                      \
@@ -279,11 +302,11 @@ void launch_w_split3(const float* w, void* w3, long long n_floats, hipStream_t s
 
 // NP = 3, XT = float: the fp32 route.  NP = 1, XT = bf16: the bf16 inference mode on the same kernel — bf16 activations in
 // and out, ONE plane (the operand rounded to bf16, as that mode defines its products), the weights' h plane.
-template <int K, int CTW, int PT, int D, int NP, typename XT>
+template <int K, int CTW, int PT, int D, int NP, typename XT, bool UPS = false>
 __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_kernel(
     const XT* __restrict__ x, int x_ld, ChanTab it, const bf16_t* __restrict__ w3, XT* __restrict__ out, int out_ld,
     long long M, double* __restrict__ stats, long long rep_stride, int nrep, const int* __restrict__ skip_flag,
-    int skip_when) {
+    int skip_when, UpsDst ups) {
   if (skip_flag && *skip_flag >= skip_when) return;
   // LDK: row stride 2 K + 32 bytes = 32 x odd: the 16-lane groups of a ds_read_b128 ({0-3, 12-15, 20-27}, ...: rows lm at
   // 16 g bytes) then cover the 64 banks exactly once (with K + 8 the planes read at 37 - 39 % conflict cycles, PMC)
@@ -405,7 +428,7 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
       for (int p = 0; p < PT; ++p) {
         const long long m = m0 + 16 * p + lm;
         const f32x4 v = acc[c][p];
-        if (m < M) st4(out + m * out_ld + n, v);
+        if (m < M) { st4(out + m * out_ld + n, v); ups_store<UPS>(ups, m, n, v); }
         s1[c] += v; s2[c] += v * v;
       }
     }
@@ -431,11 +454,11 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
   }
 }
 
-template <int K, int CTW, int PT, int D, int NP, typename XT>
+template <int K, int CTW, int PT, int D, int NP, typename XT, bool UPS = false>
 static void launch_pw_x3_t(const ConvArgs& a, long long M, int wg_per_cu, hipStream_t s) {
   constexpr int BM = 16 * PT;
   const size_t smem = (size_t)NP * BM * (K + 16) * sizeof(bf16_t) + 3 * K * sizeof(float);
-  auto kern = pw_x3_kernel<K, CTW, PT, D, NP, XT>;
+  auto kern = pw_x3_kernel<K, CTW, PT, D, NP, XT, UPS>;
   static int places = 0;
   if (!places) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -448,7 +471,7 @@ static void launch_pw_x3_t(const ConvArgs& a, long long M, int wg_per_cu, hipStr
   const long long gx = std::min<long long>(n_tiles, 256LL * per_cu);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), smem, s, (const XT*)a.in, a.in_ld, a.itab, (const bf16_t*)a.w_x3,
                      (XT*)a.out, a.out_ld, M, a.stats, a.stats_rep_stride, a.stats_nrep > 0 ? a.stats_nrep : JN_NREP,
-                     a.skip_flag, a.skip_when);
+                     a.skip_flag, a.skip_when, UpsDst{(float*)a.up_out, a.up_ld, a.W, a.H * a.W});
 }
 
 // Shapes the x3 kernel is built for — the ones where it beats pw_xs_kernel (tools/pwxsbench.hip, profiles/r03_x3bench.txt:
@@ -492,6 +515,11 @@ int launch_pw_x3(const ConvArgs& a, int pt, hipStream_t s, int wg_per_cu) {
     // per workgroup anyway, or for 64 -> 128); 256 -> 256: 64-pixel tiles halve the weight stream
     pt = K == 256 ? 4 : 2;
     if (wg_per_cu == 0) wg_per_cu = (K == 256 || (K == 64 && ctw == 2) || (K == 128 && ctw == 2 && M <= 16384)) ? 1 : 2;
+  }
+  if (a.up_out) {                       // fused x2 upsample of the output: the one shape that needs it on this route
+    if (!(K == 128 && ctw == 1 && pt == 2)) return -1;
+    launch_pw_x3_t<128, 1, 2, 4, 3, float, true>(a, M, wg_per_cu, s);
+    return 0;
   }
 #define JN_X3(K_, C_, P_, D_) if (K == K_ && ctw == C_ && pt == P_) { launch_pw_x3_t<K_, C_, P_, D_, 3, float>(a, M, wg_per_cu, s); return 0; }
   JN_X3(64, 1, 2, 2) JN_X3(64, 2, 2, 2) JN_X3(128, 1, 2, 4) JN_X3(128, 2, 2, 4) JN_X3(256, 4, 4, 2)
