@@ -1075,6 +1075,48 @@ static bool red_segment(const Net& net, int reader, int buf, int coff, int C, in
   return true;
 }
 
+// RED2 (round 3): segment [coff, coff + C) of `buf` is a materialised shortcut sum (the output of an OP_ADDACT) read only by
+// op `reader` (and, as residual, by the shortcut add `folded_addact` whose gradient copy the reader's kernel absorbs): the
+// reader writes the FINAL gradient of the sum, which is also the gradient of the activation of the add's `in` operand —
+// the bottleneck's last pointwise conv.  Returns that conv's op index (BatchNorm, whole output == the add's `in`, no other
+// reader) and the add's index, or -1.
+static int shortcut_sum_conv(const Net& net, int reader, int buf, int coff, int C, int folded_addact, int* addact_out) {
+  View seg; seg.buf = buf; seg.coff = coff; seg.C = C;
+  for (int i = 0; i < 3; ++i)
+    if (views_overlap(seg, net.fpn[i])) return -1;
+  int add = -1;
+  for (int j = 0; j < (int)net.ops.size(); ++j) {
+    const Op& o = net.ops[j];
+    if (j != reader && views_overlap(o.in, seg)) return -1;
+    if (j != reader && j != folded_addact && views_overlap(o.res, seg)) return -1;
+    if (o.kind == OP_SPP && o.out.buf == buf) return -1;
+    if (views_overlap(o.out, seg) || views_overlap(o.alias, seg)) {
+      if (add >= 0 || j >= reader) return -1;
+      add = j;
+    }
+  }
+  if (add < 0 || net.ops[add].kind != OP_ADDACT) return -1;
+  const Op& ao = net.ops[add];
+  if (ao.out.coff != coff || ao.out.C != C || ao.in.C != C) return -1;
+  int conv = -1;
+  for (int j = 0; j < (int)net.ops.size(); ++j) {
+    const Op& o = net.ops[j];
+    if (j != add && (views_overlap(o.in, ao.in) || views_overlap(o.res, ao.in))) return -1;
+    if (j == add && views_overlap(o.res, ao.in)) return -1;
+    if (views_overlap(o.out, ao.in) || views_overlap(o.alias, ao.in)) {
+      if (conv >= 0 || j >= add) return -1;
+      conv = j;
+    }
+  }
+  if (conv < 0) return -1;
+  const Op& co = net.ops[conv];
+  if (co.wslot < 0 || co.kind != OP_PW || views_overlap(co.alias, ao.in)) return -1;
+  const ConvW& cw = net.convs[co.wslot];
+  if (!cw.has_bn || !cw.prefix2.empty() || co.out.buf != ao.in.buf || co.out.coff != ao.in.coff || co.out.C != C || cw.cout != C) return -1;
+  *addact_out = add;
+  return conv;
+}
+
 // Backward of `nsl` train-mode PAFPN passes (workspace slots slot .. slot + nsl - 1, N patches each; gradient
 // slots 0 .. nsl - 1): every kernel is launched ONCE for all the passes (SlotBatch), so a 20-step trajectory
 // costs the launches of one pass.  g[fpn views] must hold the incoming gradients; parameter gradients are
@@ -1208,12 +1250,33 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
               if (r.half < 0) red_done.insert(r.wslot); else red_half[r.wslot] |= 1 << r.half;
             };
             RedRun r0, r1;
+            static const bool no_red2 = std::getenv("JN_NO_RED2") != nullptr;
+            // RED2: a run that is a shortcut sum -> sums of the conv behind it (its raw output and table instead of the input's)
+            auto red2 = [&](int coff, int C, int fidx) {
+              if (no_red2) return false;
+              int add = -1;
+              const int conv = shortcut_sum_conv(net, obi, op.in.buf, coff, C, fidx, &add);
+              if (conv < 0) return false;
+              const Op& co = net.ops[conv];
+              const ConvW& pcw = net.convs[co.wslot];
+              const ChanTab zt = tab(co.out);
+              fa.red2_z = (const float*)ptr(co.out); fa.red2_ld = ld(co.out); fa.red2_sc = zt.sc; fa.red2_sh = zt.sh;
+              fa.red_in = net.bred + 2 * pcw.stat_off; fa.red_rep_stride = rep_stride;
+              red_done.insert(co.wslot);
+              return true;
+            };
             if (red_segment(net, obi, op.in.buf, op.in.coff, op.in.C, fa_idx, r0) && (r0.half < 0 || !no_half)) {
               fa.red_in = base_of(r0); fa.red_rep_stride = rep_stride; mark(r0);
+            } else if (red2(op.in.coff, op.in.C, fa_idx)) {
+              fa.red_split = op.in.C;
             } else if (!no_half && op.in.C % 32 == 0 && !folded) {
               const int hC = op.in.C / 2;
-              const bool ok0 = red_segment(net, obi, op.in.buf, op.in.coff, hC, -1, r0);
+              bool ok0 = red_segment(net, obi, op.in.buf, op.in.coff, hC, -1, r0);
               const bool ok1 = red_segment(net, obi, op.in.buf, op.in.coff + hC, hC, -1, r1);
+              if (!ok0 && red2(op.in.coff, hC, -1)) {        // [shortcut sum | conv2 half]: the input of a CSP's conv3
+                fa.red_split = hC;
+                if (ok1) { fa.red_in2 = base_of(r1); mark(r1); }
+              } else
               if (ok0 || ok1) {
                 fa.red_rep_stride = rep_stride; fa.red_split = hC;
                 if (ok0) { fa.red_in = base_of(r0); mark(r0); }

@@ -209,6 +209,10 @@ struct PwBwdFusedArgs {
   // optional: a second gradient of the layer input, added while gx is written (the shortcut branch of a bottleneck:
   // g[input] = W^T g_z + g[sum]); same pixel indexing as gx
   const float* gadd; int gadd_ld;
+  // optional ("RED2"): the run [0, red_split or cin) of the input is a materialised shortcut sum silu(bn(z2)) + res — the
+  // sums formed for it belong to the BatchNorm of z2's conv (the bottleneck's last pointwise conv): z2 / its table replace
+  // the raw input tile and the input table in that run's silu' and second moment
+  const float* red2_z; int red2_ld; const float* red2_sc; const float* red2_sh;
 };
 struct DwBwdFusedArgs {                  // the depthwise counterpart (3x3, pad 1, stride 1 / 2)
   const float* g; int g_ld; const float* z; int z_ld; ChanTab ot; const float* save; const float* consts;

@@ -492,13 +492,18 @@ int launch_pw_bwd_weight(const float* gz, int g_ld, const void* x, int x_dtype, 
 // RED: the layer input is the output of ONE BatchNorm conv with no other consumer: the per-channel sums of ITS backward
 // (bn_bwd_reduce: sum g_a*silu'(y), sum g_a*silu'(y)*zhat) are accumulated here from the data gradient still in the
 // MFMA accumulators (z of the input tile is re-read, L2-hot), so that layer's reduce pass over (g, z) never runs.
-template <int CTN, int CTK, bool RED>
+// RED2 (round 4; round 3 had it inside every RED instantiation, where its operands cost all of them a wave of occupancy:
+// now its own instantiation): the first run of the input is a materialised shortcut sum silu(bn(z2)) + res; the kernel
+// writes the sum's FINAL gradient, which is also the gradient of the activation of z2 — the bottleneck's last pointwise
+// conv — so the sums of that run are formed with z2 / its table and go to THAT conv's BatchNorm.
+template <int CTN, int CTK, bool RED, bool RED2 = false>
 __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
     const float* __restrict__ g, int g_ld, const float* __restrict__ z, int z_ld, ChanTab ot,
     const float* __restrict__ save, const float* __restrict__ consts, const float* __restrict__ x, int x_ld,
     ChanTab it, const float* __restrict__ w, float* __restrict__ gx, int gx_ld, int accumulate,
     float* __restrict__ gw, int rep, long long M, SlotBatch sb, double* __restrict__ red_in, long long red_rep_stride,
-    const float* __restrict__ gadd, int gadd_ld, double* __restrict__ red_in2, int red_split) {
+    const float* __restrict__ gadd, int gadd_ld, double* __restrict__ red_in2, int red_split,
+    const float* __restrict__ red2_z, int red2_ld, const float* __restrict__ red2_sc, const float* __restrict__ red2_sh) {
   constexpr int N = 16 * CTN, K = 16 * CTK;          // output / input channels
   constexpr int LDG = N + 4, LDA = K + 4, LDW = N + 4;
   constexpr int NG = 64 * (N / 4) / 256, NA = 64 * (K / 4) / 256;     // f32x4 per thread per tile (may be 0 -> 1)
@@ -515,6 +520,7 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
     save += sl * sb.save; consts += sl * sb.consts;
     if (RED) { if (red_in) red_in += sl * sb.red; if (red_in2) red_in2 += sl * sb.red; }
     if (gadd) gadd += sl * sb.grad;
+    if constexpr (RED2) { red2_z += sl * sb.act; red2_sc += sl * sb.tab; red2_sh += sl * sb.tab; }
     ot.sc += sl * sb.tab; ot.sh += sl * sb.tab;
     it.sc += sl * sb.tab; it.sh += sl * sb.tab; it.fl += sl * sb.tab;
   }
@@ -533,8 +539,14 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
     Cs[4 * N + c] = consts[3 * c]; Cs[5 * N + c] = consts[3 * c + 1]; Cs[6 * N + c] = consts[3 * c + 2];
   }
   for (int c = tid; c < K; c += 256) { Cs[7 * N + c] = it.sc[c]; Cs[7 * N + K + c] = it.sh[c]; Cs[7 * N + 2 * K + c] = it.fl[c]; }
-  if (RED)
+  if (RED) {
     for (int c = tid; c < 8 * K; c += 256) Cs[7 * N + 3 * K + c] = 0.0f;       // [4 waves][K][2] input-layer BN sums
+    if constexpr (RED2)                                                         // table of the BatchNorm behind the shortcut sum
+      for (int c = tid; c < K; c += 256) {
+        const bool in = c < red_split;
+        Cs[7 * N + 11 * K + c] = in ? red2_sc[c] : 1.0f; Cs[7 * N + 12 * K + c] = in ? red2_sh[c] : 0.0f;
+      }
+  }
   // weight-gradient tiles of this wave: all of them (fp32 form) or one half, split along cin when CTK is even, else cout
 #ifdef JN_FUSED_DW_EXACT
   constexpr bool DW_SPLIT = false;
@@ -623,6 +635,17 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
       f32x4 acc[CTK];
 #pragma unroll
       for (int b = 0; b < CTK; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // RED2: the raw output of the conv behind the shortcut sum, in the layout of the accumulators (this lane's pixel,
+      // channels 16 b + 4 gq), requested BEFORE the matrix loop that hides its latency
+      f32x4 z2v[RED2 ? CTK : 1];
+      if constexpr (RED2) {
+        const long long mz = m0 + wave * 16 + lm;
+#pragma unroll
+        for (int b = 0; b < CTK; ++b) {
+          z2v[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (16 * b < red_split && mz < M) z2v[b] = *reinterpret_cast<const f32x4*>(red2_z + mz * red2_ld + 16 * b + 4 * gq);
+        }
+      }
       const float* grow = Gs + (wave * 16 + lm) * LDG + 4 * gq;
       const float* wrow = Wt + lm * LDW + 4 * gq;
 #pragma unroll
@@ -655,8 +678,12 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
 #pragma unroll
         for (int b = 0; b < CTK; ++b) {
           const int ch = 16 * b + 4 * gq;
-          const f32x4 zv = *reinterpret_cast<const f32x4*>(As + (wave * 16 + lm) * LDA + ch);      // raw z of this pixel
-          const f32x4 i_sc = *reinterpret_cast<const f32x4*>(Cs + 7 * N + ch), i_sh = *reinterpret_cast<const f32x4*>(Cs + 7 * N + K + ch);
+          f32x4 zv = *reinterpret_cast<const f32x4*>(As + (wave * 16 + lm) * LDA + ch);      // raw z of this pixel
+          f32x4 i_sc = *reinterpret_cast<const f32x4*>(Cs + 7 * N + ch), i_sh = *reinterpret_cast<const f32x4*>(Cs + 7 * N + K + ch);
+          if constexpr (RED2) if (16 * b < red_split) {  // (uniform) the sums of this run go to the conv behind the shortcut sum
+            zv = z2v[b];
+            i_sc = *reinterpret_cast<const f32x4*>(Cs + 7 * N + 11 * K + ch); i_sh = *reinterpret_cast<const f32x4*>(Cs + 7 * N + 12 * K + ch);
+          }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float yv = fmaf(zv[q], i_sc[q], i_sh[q]);
@@ -777,15 +804,15 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
   for (int i = tid; i < N * K; i += 256) atomicAdd(&dst[i], Ts[i]);
 }
 
-template <int CTN, int CTK, bool RED>
+template <int CTN, int CTK, bool RED, bool RED2 = false>
 static void launch_pw_bwd_fused_r(const PwBwdFusedArgs& a, hipStream_t s) {
   constexpr int N = 16 * CTN, K = 16 * CTK;
-  size_t smem = ((size_t)64 * (N + 4) + 64 * (K + 4) + (size_t)K * (N + 4) + 7 * N + 3 * K + (RED ? 8 * K : 0)) * sizeof(float);
+  size_t smem = ((size_t)64 * (N + 4) + 64 * (K + 4) + (size_t)K * (N + 4) + 7 * N + 3 * K + (RED ? (RED2 ? 10 : 8) * K : 0)) * sizeof(float);
   if (smem < (size_t)N * K * sizeof(float)) smem = (size_t)N * K * sizeof(float);
   if (smem > 64 * 1024) {
     static bool raised = false;       // per instantiation
     if (!raised) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_fused_kernel<CTN, CTK, RED>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_bwd_fused_kernel<CTN, CTK, RED, RED2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       raised = true;
     }
@@ -796,7 +823,7 @@ static void launch_pw_bwd_fused_r(const PwBwdFusedArgs& a, hipStream_t s) {
   static int places = 0;
   if (!places) {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&pw_bwd_fused_kernel<CTN, CTK, RED>), 256, smem) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&pw_bwd_fused_kernel<CTN, CTK, RED, RED2>), 256, smem) != hipSuccess || per_cu < 1) per_cu = 2;
     places = per_cu * 256;
   }
   const int rounds = std::max(1, (1024 + places / 2) / places);
@@ -804,16 +831,17 @@ static void launch_pw_bwd_fused_r(const PwBwdFusedArgs& a, hipStream_t s) {
   if (bx < 1) bx = 1;
   if (bx > n_tiles) bx = n_tiles;
   const int rep = (a.wpart && N * K <= JN_WPART_MAX) ? 1 : 0;
-  hipLaunchKernelGGL((pw_bwd_fused_kernel<CTN, CTK, RED>), dim3((unsigned)bx, a.sb.n), dim3(256), smem, s, a.g, a.g_ld, a.z,
+  hipLaunchKernelGGL((pw_bwd_fused_kernel<CTN, CTK, RED, RED2>), dim3((unsigned)bx, a.sb.n), dim3(256), smem, s, a.g, a.g_ld, a.z,
                      a.z_ld, a.ot, a.save, a.consts, a.x, a.x_ld, a.it, a.w, a.gx, a.gx_ld, a.accumulate,
                      rep ? a.wpart : a.gw, rep, a.M, a.sb, a.red_in, a.red_rep_stride, a.gadd, a.gadd_ld, a.red_in2,
-                     a.red_split > 0 ? a.red_split : K);
+                     a.red_split > 0 ? a.red_split : K, a.red2_z, a.red2_ld, a.red2_sc, a.red2_sh);
   if (rep) launch_wpart_reduce(a.gw, a.wpart, N * K, s);
 }
 
 template <int CTN, int CTK>
 static void launch_pw_bwd_fused_t(const PwBwdFusedArgs& a, hipStream_t s) {
   if constexpr (CTK <= 4) {
+    if (a.red2_z) { launch_pw_bwd_fused_r<CTN, CTK, true, true>(a, s); return; }
     if (a.red_in || a.red_in2) { launch_pw_bwd_fused_r<CTN, CTK, true>(a, s); return; }
   }
   launch_pw_bwd_fused_r<CTN, CTK, false>(a, s);

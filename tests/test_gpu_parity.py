@@ -743,7 +743,7 @@ def _check_grads(grads, oracle, skip_prefix=("yolox",), tag="", ref64=None, prob
     return checked
 
 
-def _check_grads_probed(grads, oracle, run, ref64, eps, tag, max_draws=12, **kw):
+def _check_grads_probed(grads, oracle, run, ref64, eps, tag, max_draws=16, **kw):
     """_check_grads with the conditioning probe drawn ON DEMAND (round 4).  What the CPU experiments of this round showed
     (scratch of the round): for a fixed input the encoder gradients of a train-mode REINFORCE / supervised step
     sit in one of a few discrete STATES — evaluations of the same algorithm that differ by one ulp somewhere in the forward
@@ -979,7 +979,7 @@ def test_config5_training_at_its_patch_size_vs_oracle():
     y0, x0 = start[:, 0], start[:, 1]
     patches0 = torch.stack([images[b, :, y0[b] * P:(y0[b] + 1) * P, x0[b] * P:(x0[b] + 1) * P] for b in range(B)])
     eps = _measured_probe_eps(product, oracle, patches0)
-    n_checked, draws = _check_grads_probed(grads, oracle, run, ref64, eps, tag=f"reinforce c5 P={P} T={Tn} gpt-mini + yolox-s", max_draws=8)
+    n_checked, draws = _check_grads_probed(grads, oracle, run, ref64, eps, tag=f"reinforce c5 P={P} T={Tn} gpt-mini + yolox-s", max_draws=16)
     assert n_checked > 150
 
 
@@ -1773,7 +1773,7 @@ def test_supervised_step_vs_oracle(B, T, P, stop_w):
         # come on demand (_check_grads_probed)
         eps = _measured_probe_eps(product, oracle, patches.flatten(0, 1))
         n, draws = _check_grads_probed(grads, oracle, lambda o: run_oracle(o, torch.float32), ref64, eps, skip_prefix=(),
-                                       tag=f"supervised B={B} T={T} P={P}", max_draws=8)
+                                       tag=f"supervised B={B} T={T} P={P}", max_draws=12)
     assert n > 150
 
 
