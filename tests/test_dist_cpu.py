@@ -28,7 +28,9 @@ def _worker(rank, world, port, ret):
     n_total, n_opt = 1000, 800                           # arena: [optim_gpt | yolox]
     flat = torch.randn(n_total)
     mine = flat.clone()
-    scale = allreduce_gradients(flat, n_opt)
+    timing = []
+    scale = allreduce_gradients(flat, n_opt, timing=timing)
+    assert timing == []                                  # event pairs are recorded for device tensors only (bench.py --gpus N)
     gathered = [torch.zeros(n_total) for _ in range(world)]
     dist.all_gather(gathered, mine)
     want = sum(g[:n_opt] for g in gathered)

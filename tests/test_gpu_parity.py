@@ -947,6 +947,43 @@ def test_headline_shape_backward_does_not_depend_on_the_step_batching(monkeypatc
     assert checked > 150
 
 
+def test_config5_training_at_its_sequence_length_does_not_depend_on_the_step_batching(monkeypatch):
+    """configs[4] TRAINING at its sequence length (gpt-mini + yolox-s dense-3x3 encoder, 640 px, T = 32; B = 2): the oracle's
+    autograd over 64 patches of 640 px is minutes of CPU time, so the full length is covered by a size-independent property
+    of the engine — the step-batched backward over all 32 glimpse steps (grid.z = 32, the 33-token teacher-forced GPT
+    backward) against the same iteration differentiated in chunks of 8 steps: loss and every gradient agree to the order of
+    the atomics.  (Values at this topology are checked against the oracle at T = 2, rollouts at T = 32: the tests around.)"""
+    P, Tn, B, G = 640, 32, 2, 3
+    images = torch.rand((B, 3, G * P, G * P), device=DEV, generator=torch.Generator(device=DEV).manual_seed(7))
+    _, bboxes, start = synth_batch(B, G, G, 64, seed=43)
+    bboxes = bboxes * (P // 64)
+    forced = torch.randint(0, 8, (B, Tn), generator=torch.Generator().manual_seed(4))
+    grads, losses = [], []
+    for slots in (None, 8):
+        if slots:
+            monkeypatch.setenv("JN_GRAD_SLOTS", str(slots))
+        product, _ = make_pair(5, bn_seed=None, patch_size=P, block_size=Tn, model_type="gpt-mini", gpt_backbone="yolox-s",
+                               with_detector=False, image_processor=None, max_batch=B)
+        tr = ja.ReinforceTrainer(_cfg(T=Tn, learning_rate=1e-3, gradient_accumulation=1), product)
+        env = ja.NeedleGeneralEnv(images, bboxes, P, Tn, 1, True)
+        m = tr.train_iteration(env, forced_actions=forced, start_positions=start, optimizer_step=False)
+        assert m["steps"] == Tn and np.isfinite(float(m["loss"]))
+        losses.append(float(m["loss"]))
+        grads.append(product.engine_grads())
+        del product, tr, env
+        torch.cuda.empty_cache()
+    assert abs(losses[0] - losses[1]) < 1e-5
+    checked = 0
+    for k, a in grads[0].items():
+        b = grads[1][k]
+        if float(a.abs().max()) < 1e-12:
+            continue
+        assert float((a - b).norm() / a.norm()) < 5e-5, (k, float((a - b).norm() / a.norm()))
+        assert float((a - b).abs().max() / a.abs().max()) < 5e-4, k
+        checked += 1
+    assert checked > 150
+
+
 def test_config5_training_at_its_patch_size_vs_oracle():
     """BASELINE configs[4] topology at its REAL patch size: gpt-mini + yolox-s (dense 3x3) encoder, 640 px — B = 2, T = 2
     REINFORCE iteration (train-mode BatchNorm per glimpse step), logits, losses and every gradient against torch autograd
