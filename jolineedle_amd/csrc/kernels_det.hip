@@ -827,9 +827,166 @@ __global__ __launch_bounds__(256) void conv3_bwd_data_s2_kernel(const float* __r
   }
 }
 
+// The same data gradient on the bf16 matrix pipe with three-way split operands (round 4) — the scheme of conv3_x3_kernel<WT>
+// applied per parity class: the input pixels of class (py, px) over a 32 x 32 input tile form a 16 x 16 grid that maps 1:1
+// onto g_z pixels (a, b) (+1 for the odd taps), i.e. a STRIDE-1 problem over the g_z tile with 1 / 2 / 2 / 4 of the nine
+// taps.  g_z chunk (17 x 17 pixels x 32 output channels) split once into three bf16 planes; the class's weight taps go
+// through LDS one tap ROW at a time (at most two taps), transposed on the way in; next phase's operands in registers under
+// the matrix loop; eight waves, two rows per wave, 64 input channels per workgroup.  blockIdx.z = class + 4 * slot.
+template <int PR, int NW>
+__global__ __launch_bounds__(64 * NW) void conv3_x3_bwd_data_s2_kernel(const float* __restrict__ gz, int g_ld,
+                                                                    const float* __restrict__ w, float* __restrict__ gin,
+                                                                    int gin_ld, int H, int W, int OH, int OW, int Co, int Ci,
+                                                                    int tiles_x, int tiles_y, int accumulate, long long g_slot) {
+  constexpr int NT = 64 * NW, TH = NW * PR, IH = TH + 1, IW = C3_TW + 1, NP = IH * IW;
+  constexpr int XPL = NP * C3X_LD, WPL = 2 * C3_BN * C3X_LD;      // elements per plane: g_z tile, two taps of weights
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_x3b[];
+  bf16_t* Xp = reinterpret_cast<bf16_t*>(smem_x3b);                // [3 planes][NP][C3X_LD]
+  bf16_t* Wp = Xp + 3 * XPL;                                       // [3 planes][2 taps][C3_BN][C3X_LD]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, g = lane >> 4;
+  const int cls = blockIdx.z & 3, py = cls >> 1, px = cls & 1;
+  const long long sl = blockIdx.z >> 2;
+  gz += sl * g_slot; gin += sl * g_slot;
+  const int tile = blockIdx.x % (tiles_x * tiles_y), n_img = blockIdx.x / (tiles_x * tiles_y);
+  const int a0 = (tile / tiles_x) * TH, b0 = (tile % tiles_x) * C3_TW;     // g_z-space origin of the tile
+  const int n0 = blockIdx.y * C3_BN;                                       // input-channel block
+  const int nky = py ? 2 : 1, nkx = px ? 2 : 1;
+  // tap slot -> kernel index and g_z offset: even coordinate: k = 1 (offset 0); odd: slot 0 = k 0 (offset + 1), slot 1 = k 2 (offset 0)
+  auto tap_k = [](int odd, int slot) { return odd ? 2 * slot : 1; };
+  const float* gb = gz + (long long)n_img * OH * OW * g_ld;
+  f32x4 acc[PR][4];
+#pragma unroll
+  for (int p = 0; p < PR; ++p)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int NXR = (NP * 8 + NT - 1) / NT;            // f32x4 of the g_z tile per thread (8 quads per pixel)
+  constexpr int NWR = 2 * C3_BN * 8 / NT;                // f32x4 of one tap row's weight chunk per thread (two taps at most)
+  f32x4 xr[NXR], wr[NWR];
+  auto fetch_x = [&](int k0) {
+    const int kq = k0 + 4 * (tid & 7);
+#pragma unroll
+    for (int j = 0; j < NXR; ++j) {
+      const int i = tid + NT * j, pix = i >> 3;
+      const int oy = a0 + pix / IW, ox = b0 + pix % IW;
+      xr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < NP * 8 && oy < OH && ox < OW && kq < Co) xr[j] = *reinterpret_cast<const f32x4*>(gb + ((long long)oy * OW + ox) * g_ld + kq);
+    }
+  };
+  auto fetch_w = [&](int k0, int sy) {
+    const int ky = tap_k(py, sy);
+#pragma unroll
+    for (int j = 0; j < NWR; ++j) {
+      const int i = tid + NT * j, q = i & 7, r = (i >> 3) % C3_BN, sx = i / (8 * C3_BN);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (sx < nkx && n0 + r < Ci && k0 + 4 * q < Co) {
+        const float* wp = w + ((long long)(ky * 3 + tap_k(px, sx)) * Co + k0 + 4 * q) * Ci + n0 + r;      // w[tap][o][k]
+        v = f32x4{wp[0], wp[Ci], wp[2 * Ci], wp[3 * Ci]};
+      }
+      wr[j] = v;
+    }
+  };
+  auto split3 = [](bf16_t* dst, int plane_stride, f32x4 v) {
+    const bf16x4 h = __builtin_convertvector(v, bf16x4);
+    const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
+    const bf16x4 m = __builtin_convertvector(r1, bf16x4);
+    const bf16x4 l = __builtin_convertvector(r1 - __builtin_convertvector(m, f32x4), bf16x4);
+    *reinterpret_cast<bf16x4*>(dst) = h;
+    *reinterpret_cast<bf16x4*>(dst + plane_stride) = m;
+    *reinterpret_cast<bf16x4*>(dst + 2 * plane_stride) = l;
+  };
+  fetch_x(0);
+  fetch_w(0, 0);
+  for (int k0 = 0; k0 < Co; k0 += C3X_KC) {
+#pragma unroll 1
+    for (int sy = 0; sy < nky; ++sy) {
+      __syncthreads();                                 // the previous phase's readers are done
+      if (sy == 0) {
+#pragma unroll
+        for (int j = 0; j < NXR; ++j) {
+          const int i = tid + NT * j, pix = i >> 3, q = i & 7;
+          if (i < NP * 8) split3(Xp + pix * C3X_LD + 4 * q, XPL, xr[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NWR; ++j) {
+        const int i = tid + NT * j, q = i & 7, r = (i >> 3) % C3_BN, sx = i / (8 * C3_BN);
+        split3(Wp + (sx * C3_BN + r) * C3X_LD + 4 * q, WPL, wr[j]);
+      }
+      __syncthreads();
+      if (sy + 1 < nky) fetch_w(k0, sy + 1);
+      else if (k0 + C3X_KC < Co) { fetch_w(k0 + C3X_KC, 0); fetch_x(k0 + C3X_KC); }
+      const int dy = (py && sy == 0) ? 1 : 0;          // (iy + 1 - ky) / 2 - a
+      for (int sx = 0; sx < nkx; ++sx) {
+        const int dx = (px && sx == 0) ? 1 : 0;
+        bf16x8 xv[PR][3];
+#pragma unroll
+        for (int p = 0; p < PR; ++p)
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            xv[p][t] = *reinterpret_cast<const bf16x8*>(Xp + t * XPL + ((PR * wave + p + dy) * IW + lm + dx) * C3X_LD + 8 * g);
+#pragma unroll
+        for (int c2 = 0; c2 < 4; c2 += 2) {
+          bf16x8 wa[2][3];
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+              wa[cc][t] = *reinterpret_cast<const bf16x8*>(Wp + t * WPL + (sx * C3_BN + 16 * (c2 + cc) + lm) * C3X_LD + 8 * g);
+          constexpr int TW[6] = {2, 0, 1, 1, 0, 0}, TX[6] = {0, 2, 1, 0, 1, 0};     // (w, x): l h, h l, m m, m h, h m, h h
+#pragma unroll
+          for (int e = 0; e < 6; ++e)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+              for (int p = 0; p < PR; ++p)
+                acc[p][c2 + cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[cc][TW[e]], xv[p][TX[e]], acc[p][c2 + cc], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < PR; ++p) {
+    const int iy = 2 * (a0 + PR * wave + p) + py, ix = 2 * (b0 + lm) + px;
+    if (iy >= H || ix >= W) continue;
+    float* op = gin + (((long long)n_img * H + iy) * W + ix) * gin_ld;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int n = n0 + 16 * c + 4 * g;
+      if (n < Ci) {
+        f32x4 v = acc[p][c];
+        if (accumulate) v += *reinterpret_cast<const f32x4*>(op + n);
+        *reinterpret_cast<f32x4*>(op + n) = v;
+      }
+    }
+  }
+}
+
 int launch_conv3_bwd_data_s2(const float* gz, int g_ld, const float* w, float* gin, int gin_ld, int H, int W, int OH,
                              int OW, int Co, int Ci, int N, int accumulate, hipStream_t s, const SlotBatch& sb) {
   if (Co % 4 || Ci % 4) return -1;
+  // bf16 matrix pipe (three-way split operands): whole 16 x 16 class tiles on a CU of their own against the fp32 kernel's
+  // 8 x 16 tiles, two per CU — chosen like the forward routes, by rounds of workgroups x time per round
+  if (!std::getenv("JN_NO_CONV3_X3") && !std::getenv("JN_NO_CONV3_X3S2") && !std::getenv("JN_NO_CONV3_X3S2_BWD") && Co % 32 == 0 && g_ld % 4 == 0 &&
+      gin_ld % 4 == 0) {
+    constexpr int PR = 2, NW = 8, TH = PR * NW;
+    const int txs = (OW + C3_TW - 1) / C3_TW, tys = (OH + TH - 1) / TH;
+    const long long nbi = (Ci + C3_BN - 1) / C3_BN;
+    const long long wg_x3 = (long long)txs * tys * N * nbi * 4 * sb.n, wg_f32 = (long long)txs * ((OH + C3_TH - 1) / C3_TH) * N * nbi * 4 * sb.n;
+    const double cost_f32 = (double)((wg_f32 + 511) / 512), cost_x3 = 0.65 * (double)((wg_x3 + 255) / 256);
+    if (cost_x3 < cost_f32) {
+      const size_t smem = ((size_t)3 * (TH + 1) * (C3_TW + 1) * C3X_LD + (size_t)3 * 2 * C3_BN * C3X_LD) * sizeof(bf16_t);
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_x3_bwd_data_s2_kernel<PR, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+      }
+      dim3 grid((unsigned)(txs * tys * N), (unsigned)nbi, 4 * sb.n);
+      hipLaunchKernelGGL((conv3_x3_bwd_data_s2_kernel<PR, NW>), grid, dim3(64 * NW), smem, s, gz, g_ld, w, gin, gin_ld, H, W, OH, OW,
+                         Co, Ci, txs, tys, accumulate, sb.grad);
+      return 0;
+    }
+  }
   const int tiles_x = (OW + C3_TW - 1) / C3_TW, tiles_y = (OH + C3_TH - 1) / C3_TH;
   dim3 grid(tiles_x * tiles_y * N, (Ci + C3_BN - 1) / C3_BN, 4 * sb.n);
   const size_t smem = ((size_t)(C3_TH + 1) * (C3_TW + 1) + 4 * C3_BN) * C3S2_LD * sizeof(float);
