@@ -322,6 +322,9 @@ struct GptStepArgs {
   const int* skip_flag; int skip_when;
 };
 int launch_gpt_step(const GptStepArgs& a, hipStream_t s);
+// kernels_gptmfma.hip: the same step for n_embd % 64 == 0, 4 or 16 agents per workgroup, Linears on fp32 MFMA; opt-in
+// (JN_GPT_MFMA=1: measured slower, see its header); false = not taken
+bool launch_gpt_step_mfma(const GptStepArgs& a, hipStream_t s);
 
 // ---- training of the decision side (kernels_train.hip) ------------------------------------
 struct LossArgs {

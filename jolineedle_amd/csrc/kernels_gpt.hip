@@ -18,6 +18,10 @@ namespace jnr {
 // 256 for n_embd <= 64 (gpt-nano: its largest Linear is 48 x 192, the 1024-thread form only made every barrier and block
 // reduction four times as wide: 95.7 -> 119.4 us per step between rounds 1 and 2, back to the 256-thread form in round 3).
 
+#ifndef JN_LINEAR_UNROLL
+#define JN_LINEAR_UNROLL 4
+#endif
+
 template <int NT>
 __device__ __forceinline__ float block_sum(float v, float* red) {
   constexpr int GPT_WAVES = NT / 64;
@@ -49,7 +53,7 @@ __device__ __forceinline__ void linear_t(float* y, const float* x, const float* 
     if (sl < slices) {
       f4 acc = {0.f, 0.f, 0.f, 0.f};
       const float* wp = wt + 4 * q;
-#pragma unroll 4
+#pragma unroll JN_LINEAR_UNROLL
       for (int k = sl; k < K; k += slices) acc += x[k] * *reinterpret_cast<const f4*>(wp + (long long)k * N);
       *reinterpret_cast<f4*>(part + sl * N + 4 * q) = acc;
     }
@@ -317,6 +321,7 @@ __global__ __launch_bounds__(NT) void gpt_step_kernel(GptStepArgs a) {
 }
 
 int launch_gpt_step(const GptStepArgs& a, hipStream_t s) {
+  if (launch_gpt_step_mfma(a, s)) return 0;             // wide models: 16 agents per workgroup on the matrix pipe
   const int nt = a.C <= 64 ? 256 : 1024;
   const size_t smem = (size_t)(9 * a.C + a.n_head * a.Tmax + nt / 64 + 16 + 4 + 4 * nt) * sizeof(float);
   if (nt == 256) hipLaunchKernelGGL(gpt_step_kernel<256>, dim3(a.B), dim3(256), smem, s, a);

@@ -231,8 +231,14 @@ def test_gpt_forward_full_and_recurrent_golden(golden):
 @pytest.mark.parametrize("kw", [dict(concat_emb=False), dict(decoder_pos_encoding=False, nclasses=8),
                                 dict(use_pos_emb=False), dict(model_type="gpt-mini"),
                                 dict(model_type="gpt-mini", gpt_backbone="yolox-s"),     # BASELINE config 5 topology
-                                dict(gpt_backbone=None, image_processor="yolox-nano")])
-def test_gpt_forward_variants_vs_oracle(kw):
+                                dict(gpt_backbone=None, image_processor="yolox-nano"),
+                                # the opt-in agent-batched MFMA step (kernels_gptmfma.hip), 4 and 16 agents per workgroup
+                                dict(model_type="gpt-mini", _env=dict(JN_GPT_MFMA="1")),
+                                dict(model_type="gpt-mini", concat_emb=False, _env=dict(JN_GPT_MFMA="1", JN_GPT_MFMA_AGENTS="16"))])
+def test_gpt_forward_variants_vs_oracle(kw, monkeypatch):
+    kw = dict(kw)
+    for k, v in kw.pop("_env", {}).items():
+        monkeypatch.setenv(k, v)
     base = dict(patch_size=64, block_size=5, image_processor="yolox-nano", gpt_backbone="yolox-nano")
     base.update(kw)
     product, oracle = make_pair(7, **base)
@@ -320,7 +326,7 @@ def test_rollout_forced_vs_oracle(stop, B, P, Tn):
     assert torch.equal(ro["patches"].cpu(), ref["patches"])       # bit exact gather inside the loop
 
 
-def test_rollout_config5_sizes_vs_oracle():
+def test_rollout_config5_sizes_vs_oracle(monkeypatch):
     """BASELINE configs[4] at its real sizes on a small batch: gpt-mini (6 layers, 6 heads, C = 192) + yolox-s dense-3x3
     encoder, 640-px patches (20 x 20 deepest map), forced rollout against the CPU oracle."""
     from oracle import env_ref, rollout_ref
@@ -339,6 +345,16 @@ def test_rollout_config5_sizes_vs_oracle():
     assert torch.equal(ro["rewards"].cpu(), ref["rewards"])
     for k in ("returns", "logprobs", "entropies", "logits"):
         assert (ro[k].cpu() - ref[k]).abs().max() < 1e-3, k              # north-star bound
+    # the opt-in MFMA step kernel (kernels_gptmfma.hip) walks the same trajectory: env-step mode of that kernel
+    for agents in ("4", "16"):
+        monkeypatch.setenv("JN_GPT_MFMA", "1")
+        monkeypatch.setenv("JN_GPT_MFMA_AGENTS", agents)
+        env = ja.NeedleGeneralEnv(images.to(DEV), bboxes, P, Tn, 1, True)
+        rm = ja.ReinforceTrainer(_cfg(T=Tn), product).rollout(env, forced_actions=forced, start_positions=start)
+        for k in ("masks", "positions", "actions", "rewards"):
+            assert torch.equal(rm[k], ro[k]), k
+        for k in ("logprobs", "entropies", "logits"):
+            assert (rm[k] - ro[k]).abs().max() < 1e-5, k
 
 
 def test_rollout_early_stop_and_full_length():
