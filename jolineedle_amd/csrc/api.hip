@@ -537,6 +537,7 @@ int jn_load_weights(jn_ctx* ctx, const jn_tensor* tensors, size_t n) {
     if ((rc = dev_alloc(ctx, &ctx->params, total))) return rc;
     JN_HIP(hipMemset(ctx->params, 0, total * sizeof(float)));
     if ((rc = dev_alloc(ctx, &ctx->params_x3, 3 * total))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->params_x3t, 3 * total))) return rc;
   }
   const jn_config& c = ctx->cfg;
   const int C = c.n_embd, nA = c.n_actions;
@@ -1347,7 +1348,15 @@ static int run_net_backward(jn_ctx* ctx, int ni, int N, const StemSrc& ss, int s
           ws = ctx->aux_stream;
           aux_used = true;
         }
-        launch_pw(a, s);
+        // wide layers, fp32: the data gradient on the bf16 pipe at fp32 accuracy (pw_x3_kernel over the slots, transposed
+        // weight split on the way: kernels_pwxs.hip); JN_NO_PW_X3_BWD=1 keeps pw_dir_kernel<WT> on the fp32 pipe
+        const bool no_x3_bwd = std::getenv("JN_NO_PW_X3_BWD") != nullptr;     // read per launch: a test flips it
+        bool x3_done = false;
+        if (!no_x3_bwd && net.act_dtype == JN_F32 && !op.acc_in && ctx->params_x3t && pw_x3_bwd_data_supported(cw.cout, cw.cin) &&
+            (cw.w_dev - ctx->params) % 8 == 0) {
+          x3_done = launch_pw_x3_bwd_data(a, cw.w_dev, ctx->params_x3t + 3 * (cw.w_dev - ctx->params), s) == 0;
+        }
+        if (!x3_done) launch_pw(a, s);
         launch_pw_bwd_weight(gp_out, gld_out, ptr(op.in), net.act_dtype, ld(op.in), tab(op.in), gw, ctx->wpart, M, cw.cout,
                              cw.cin, ws, sb);
       } else if (op.kind == OP_DW) {

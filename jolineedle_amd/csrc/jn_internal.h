@@ -177,6 +177,7 @@ struct jn_ctx {
   // flat trainable-parameter arena + gradient / AdamW mirrors
   float* params = nullptr; float* grads = nullptr; float* adam_m = nullptr; float* adam_v = nullptr;
   uint16_t* params_x3 = nullptr;   // 3 bf16 per arena float: the 1x1 weights split for pw_x3_kernel (refreshed at the start of every fp32 pass)
+  uint16_t* params_x3t = nullptr;  // the TRANSPOSED 1x1 weights of the wide layers as three bf16 planes (data gradient, split per backward)
   size_t arena_size = 0, arena_used = 0, gpt_arena_end = 0;   // [0, gpt_arena_end) = optim_gpt parameters
   int adam_step = 0, adam_step_yolox = 0;
   bool freeze_det_backbone = false;   // --freeze-image-processor: yolox.backbone.* keep their values (src/models/gpt.py:264-268)

@@ -116,6 +116,9 @@ bool pw_xs_supported(const ConvArgs& a);               // kernels_pwxs.hip: pixe
 int launch_pw_xs(const ConvArgs& a, int pt, hipStream_t s, int wg_per_cu = 0);   // pt: pixel tiles per workgroup (0 = default)
 int launch_pw_x3(const ConvArgs& a, int pt, hipStream_t s, int wg_per_cu = 0);   // the same on the bf16 pipe (three-way split operands); needs a.w_x3
 bool pw_x3_preferred(const ConvArgs& a);
+// the data gradient of a wide 1x1 layer on pw_x3_kernel (transposed split weight made on the way); -1: shape not taken
+bool pw_x3_bwd_data_supported(int cout, int cin);
+int launch_pw_x3_bwd_data(const ConvArgs& a, const float* w, void* w3t, hipStream_t s);
 bool pw_x1_supported(const ConvArgs& a);               // bf16 inference mode: single-plane form of the same kernel
 int launch_pw_x1(const ConvArgs& a, hipStream_t s);               // shapes on which the x3 kernel is the faster one
 void launch_w_split3(const float* w, void* w3, long long n_floats, hipStream_t s);   // w3: 6 bytes per weight

@@ -302,11 +302,19 @@ void launch_w_split3(const float* w, void* w3, long long n_floats, hipStream_t s
 
 // NP = 3, XT = float: the fp32 route.  NP = 1, XT = bf16: the bf16 inference mode on the same kernel — bf16 activations in
 // and out, ONE plane (the operand rounded to bf16, as that mode defines its products), the weights' h plane.
-template <int K, int CTW, int PT, int D, int NP, typename XT, bool UPS = false>
+// SLOTS (round 4, the data gradient of the wide layers in the step-batched backward): the operand is n_slots maps of M pixels
+// each, `sl.in` / `sl.out` elements apart (the workspace slots of the glimpse steps); a tile never straddles two slots.
+struct SlotSpan { int n_slots; long long in, out; };
+// With SLOTS the split weights come in FRAGMENT ORDER: block ((c16 * K / 32 + j) * 3 + plane) of 64 lanes x 8 bf16, lane
+// (g, lm) holding w[16 c16 + lm][32 j + 8 g .. + 7] — a wave's load of one fragment is 1 KB contiguous (8 cache lines).  The
+// [row][k / 8][h | m | l] order of the forward planes makes the same load 64 pieces of 16 bytes in 32 lines, three times over
+// for the three planes: with K = 256 the weights are streamed per tile and the L1 tag rate, not the matrix pipe, set the pace
+// (383 us per 250 880-pixel launch against 79 us of matrix time).
+template <int K, int CTW, int PT, int D, int NP, typename XT, bool UPS = false, bool SLOTS = false>
 __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_kernel(
     const XT* __restrict__ x, int x_ld, ChanTab it, const bf16_t* __restrict__ w3, XT* __restrict__ out, int out_ld,
     long long M, double* __restrict__ stats, long long rep_stride, int nrep, const int* __restrict__ skip_flag,
-    int skip_when, UpsDst ups) {
+    int skip_when, UpsDst ups, SlotSpan sl) {
   if (skip_flag && *skip_flag >= skip_when) return;
   // LDK: row stride 2 K + 32 bytes = 32 x odd: the 16-lane groups of a ds_read_b128 ({0-3, 12-15, 20-27}, ...: rows lm at
   // 16 g bytes) then cover the 64 banks exactly once (with K + 8 the planes read at 37 - 39 % conflict cycles, PMC)
@@ -319,33 +327,53 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
   float* Tb = reinterpret_cast<float*>(Xp + NP * BM * LDK);      // [3][K], later [N][2] statistics
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, g = lane >> 4;
-  const long long n_tiles = (M + BM - 1) / BM;
+  const long long tiles_per_slot = (M + BM - 1) / BM;
+  const long long n_tiles = SLOTS ? tiles_per_slot * sl.n_slots : tiles_per_slot;
 
   // weight fragments of k step j, channel tile c: 3 x bf16x8 at wrow[c] + 96 j (elements)
   const bf16_t* wrow[CTW];
 #pragma unroll
-  for (int c = 0; c < CTW; ++c) wrow[c] = w3 + ((long long)((wave * CTW + c) * 16 + lm) * (K / 8) + g) * 24;
+  for (int c = 0; c < CTW; ++c)
+    wrow[c] = SLOTS ? w3 + (long long)(wave * CTW + c) * (K / 32) * 3 * 512 + lane * 8
+                    : w3 + ((long long)((wave * CTW + c) * 16 + lm) * (K / 8) + g) * 24;
+  // fragment (k step j, plane t) of channel tile c
+  auto wfrag = [&](int c, int j, int t) -> bf16x8 {
+    if constexpr (SLOTS) return *reinterpret_cast<const bf16x8*>(wrow[c] + (j * 3 + t) * 512);
+    else return *reinterpret_cast<const bf16x8*>(wrow[c] + 96 * j + 8 * t);
+  };
   bf16x8 wr[D][CTW][NP];
 #pragma unroll
   for (int u = 0; u < D; ++u)
 #pragma unroll
     for (int c = 0; c < CTW; ++c)
 #pragma unroll
-      for (int t = 0; t < NP; ++t) wr[u][c][t] = *reinterpret_cast<const bf16x8*>(wrow[c] + 96 * u + 8 * t);
+      for (int t = 0; t < NP; ++t) wr[u][c][t] = wfrag(c, u, t);
 
   const int q = tid % KQ, r0 = tid / KQ;
   constexpr int RS = 256 / KQ;
   f32x4 xr[NXB];
+  const XT* xs = x;                                    // SLOTS: the slot of the tile being fetched
   auto fetch = [&](long long m0, int b) {
 #pragma unroll
     for (int u = 0; u < NXB; ++u) {
       long long m = m0 + r0 + (long long)(b * NXB + u) * RS;
       m = m < M ? m : M - 1;
-      xr[u] = ld4(x + m * x_ld + 4 * q);
+      xr[u] = ld4(xs + m * x_ld + 4 * q);
+    }
+  };
+  // tile index -> first pixel inside its slot (and the slot's operand base)
+  auto locate = [&](long long t) -> long long {
+    if constexpr (SLOTS) {
+      const long long slot = t / tiles_per_slot;
+      xs = x + slot * sl.in;
+      return (t - slot * tiles_per_slot) * BM;
+    } else {
+      return t * BM;
     }
   };
   long long tile = blockIdx.x;
-  fetch(tile * BM, 0);
+  long long m0 = locate(tile);
+  fetch(m0, 0);
   tab_to_lds(Tb, K, K, it, tid, 256);
   __syncthreads();
   const f32x4 sc = *reinterpret_cast<const f32x4*>(Tb + 4 * q), sh = *reinterpret_cast<const f32x4*>(Tb + K + 4 * q),
@@ -356,7 +384,8 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
 
 #pragma unroll 1
   for (; tile < n_tiles; tile += gridDim.x) {
-    const long long m0 = tile * BM;
+    XT* outs = out;
+    if constexpr (SLOTS) outs = out + (tile / tiles_per_slot) * sl.out;
 #pragma unroll
     for (int b = 0; b < NX / NXB; ++b) {
       if (b > 0) fetch(m0, b);
@@ -379,7 +408,8 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
       }
     }
     __syncthreads();
-    if (tile + gridDim.x < n_tiles) fetch((tile + gridDim.x) * BM, 0);
+    const long long m0_this = m0;
+    if (tile + gridDim.x < n_tiles) { m0 = locate(tile + gridDim.x); fetch(m0, 0); }
 
     f32x4 acc[CTW][PT];
 #pragma unroll
@@ -406,7 +436,7 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
 #pragma unroll
           for (int c = 0; c < CTW; ++c)
 #pragma unroll
-            for (int t = 0; t < NP; ++t) wr[u][c][t] = *reinterpret_cast<const bf16x8*>(wrow[c] + 96 * jn + 8 * t);
+            for (int t = 0; t < NP; ++t) wr[u][c][t] = wfrag(c, jn, t);
           __builtin_amdgcn_sched_barrier(0);
         }
         // six products, the small ones first: (w, x) = (l, h) (h, l) (m, m) (m, h) (h, m) (h, h)
@@ -426,9 +456,9 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
       const int n = (wave * CTW + c) * 16 + 4 * g;
 #pragma unroll
       for (int p = 0; p < PT; ++p) {
-        const long long m = m0 + 16 * p + lm;
+        const long long m = m0_this + 16 * p + lm;
         const f32x4 v = acc[c][p];
-        if (m < M) { st4(out + m * out_ld + n, v); ups_store<UPS>(ups, m, n, v); }
+        if (m < M) { st4(outs + m * out_ld + n, v); ups_store<UPS>(ups, m, n, v); }
         s1[c] += v; s2[c] += v * v;
       }
     }
@@ -454,11 +484,11 @@ __global__ __launch_bounds__(256, (K <= 64 ? 3 : CTW <= 2 ? 2 : 1)) void pw_x3_k
   }
 }
 
-template <int K, int CTW, int PT, int D, int NP, typename XT, bool UPS = false>
+template <int K, int CTW, int PT, int D, int NP, typename XT, bool UPS = false, bool SLOTS = false>
 static void launch_pw_x3_t(const ConvArgs& a, long long M, int wg_per_cu, hipStream_t s) {
   constexpr int BM = 16 * PT;
   const size_t smem = (size_t)NP * BM * (K + 16) * sizeof(bf16_t) + 3 * K * sizeof(float);
-  auto kern = pw_x3_kernel<K, CTW, PT, D, NP, XT, UPS>;
+  auto kern = pw_x3_kernel<K, CTW, PT, D, NP, XT, UPS, SLOTS>;
   static int places = 0;
   if (!places) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -466,12 +496,14 @@ static void launch_pw_x3_t(const ConvArgs& a, long long M, int wg_per_cu, hipStr
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, smem) != hipSuccess || per_cu < 1) per_cu = 1;
     places = per_cu;
   }
-  const long long n_tiles = (M + BM - 1) / BM;
+  const int n_slots = SLOTS ? std::max(1, a.n_slots) : 1;
+  const long long n_tiles = (M + BM - 1) / BM * n_slots;
   const int per_cu = std::max(1, std::min(places, wg_per_cu > 0 ? wg_per_cu : 2));
   const long long gx = std::min<long long>(n_tiles, 256LL * per_cu);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), smem, s, (const XT*)a.in, a.in_ld, a.itab, (const bf16_t*)a.w_x3,
                      (XT*)a.out, a.out_ld, M, a.stats, a.stats_rep_stride, a.stats_nrep > 0 ? a.stats_nrep : JN_NREP,
-                     a.skip_flag, a.skip_when, UpsDst{(float*)a.up_out, a.up_ld, a.W, a.H * a.W});
+                     a.skip_flag, a.skip_when, UpsDst{(float*)a.up_out, a.up_ld, a.W, a.H * a.W},
+                     SlotSpan{n_slots, a.in_slot_stride, a.out_slot_stride});
 }
 
 // Shapes the x3 kernel is built for — the ones where it beats pw_xs_kernel (tools/pwxsbench.hip, profiles/r03_x3bench.txt:
@@ -529,6 +561,63 @@ int launch_pw_x3(const ConvArgs& a, int pt, hipStream_t s, int wg_per_cu) {
 #endif
 #undef JN_X3
   return -1;
+}
+
+// ---- the data gradient of the WIDE 1x1 layers on the same kernel (round 4) ---------------------------------------------
+// g_x[m][k] = sum_n g_z[m][n] w[n][k] is the 1x1 conv of g_z with the transposed weight.  In the step-batched backward its
+// M is 20 x the forward's and pw_dir_kernel<.., WT> runs it at 0.74 matrix-pipe busy on the fp32 pipe
+// (profiles/r04_z_pmc_lds_mfma_train_iteration.txt): matrix-bound, the one regime where the three-way bf16 split pays in
+// full (3 cycles per k instead of 8).  The transposed weight is split per layer at the start of its backward
+// (w_split3_t_kernel, in the fragment order pw_x3_kernel<.., SLOTS> streams); 512 input channels: two
+// launches of 256 output columns each.
+__global__ __launch_bounds__(256) void w_split3_t_kernel(const float* __restrict__ w, bf16_t* __restrict__ w3t, int cout, int cin) {
+  const int i = blockIdx.x * 256 + threadIdx.x;        // (row n' = input channel, group of 8 output channels)
+  const int groups = cout / 8;
+  if (i >= cin * groups) return;
+  const int n = i % cin, gq = i / cin;                 // consecutive threads: consecutive columns of w (coalesced reads)
+  const int NJ = cout / 32, j = gq >> 2, g = gq & 3;   // fragment order (pw_x3_kernel, SLOTS): k step j, lane group g
+  bf16x8 h, m, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float v = w[(long long)(8 * gq + e) * cin + n];
+    const bf16_t vh = (bf16_t)v;
+    const float r1 = v - (float)vh;
+    const bf16_t vm = (bf16_t)r1;
+    const float r2 = r1 - (float)vm;
+    h[e] = vh; m[e] = vm; l[e] = (bf16_t)r2;
+  }
+  bf16_t* o = w3t + ((long long)((n >> 4) * NJ + j) * 3 * 64 + g * 16 + (n & 15)) * 8;
+  *reinterpret_cast<bf16x8*>(o) = h;
+  *reinterpret_cast<bf16x8*>(o + 512) = m;
+  *reinterpret_cast<bf16x8*>(o + 1024) = l;
+}
+
+// shapes (cout = the gradient's K, cin = its N) this route takes
+bool pw_x3_bwd_data_supported(int cout, int cin) {
+  return (cout == 256 && (cin == 128 || cin == 256 || cin == 512)) || (cout == 128 && cin == 256);
+}
+
+// a: the ConvArgs of the gradient conv as api.hip builds them for launch_pw (in = g_z, out = g_x, cin = layer's cout,
+// cout = layer's cin, slots); w = the layer's [cout][cin] weight, w3t = 3 * cout * cin bf16 of scratch owned by the layer
+int launch_pw_x3_bwd_data(const ConvArgs& a, const float* w, void* w3t, hipStream_t s) {
+  const int K = a.cin, N = a.cout;                      // of the gradient conv
+  if (!pw_x3_bwd_data_supported(K, N) || a.accumulate || a.in_dtype != JN_F32 || a.out_dtype != JN_F32 || a.bias ||
+      a.act != ACT_NONE || a.in_ld % 4 != 0 || a.out_ld % 4 != 0 || a.stats)
+    return -1;
+  hipLaunchKernelGGL(w_split3_t_kernel, dim3((unsigned)((N * (K / 8) + 255) / 256)), dim3(256), 0, s, w, (bf16_t*)w3t, K, N);
+  const long long M = (long long)a.N * a.H * a.W;
+  ConvArgs b = a;
+  b.w_x3 = w3t; b.up_out = nullptr;
+  // tilings: the best of tools/x3bwdbench.hip (profiles/r04_x3bwdbench.txt) — 32-pixel tiles everywhere (more tiles to
+  // balance over the persistent grid), K = 128: all weight fragments in registers (D = K / 32)
+  if (K == 256 && N == 128) { launch_pw_x3_t<256, 2, 2, 2, 3, float, false, true>(b, M, 2, s); return 0; }
+  if (K == 128 && N == 256) { launch_pw_x3_t<128, 4, 2, 4, 3, float, false, true>(b, M, 2, s); return 0; }
+  for (int n0 = 0; n0 < N; n0 += 256) {                 // 256 -> 256, and 256 -> 512 as two column halves
+    b.w_x3 = (const bf16_t*)w3t + (long long)n0 * K * 3;
+    b.out = (float*)a.out + n0;
+    launch_pw_x3_t<256, 4, 2, 2, 3, float, false, true>(b, M, 2, s);
+  }
+  return 0;
 }
 
 }  // namespace jnr

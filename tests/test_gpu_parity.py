@@ -194,6 +194,32 @@ def test_nano_backbone_backward_vs_autograd(P, N, bb):
             assert torch.allclose(got2[k], 2 * got[k], rtol=1e-3, atol=1e-3 * got[k].abs().max().item())
 
 
+def test_wide_data_gradient_on_the_bf16_pipe_matches_the_fp32_pipe(monkeypatch):
+    """The data gradient of the wide 1x1 layers (256 / 512 channels: dark5, lateral_conv0, C3_p4 / C3_n4) runs on pw_x3_kernel
+    (three bf16 planes per operand, transposed split weight) since round 4: every gradient of the encoder must stay where the
+    fp32 matrix pipe (JN_NO_PW_X3_BWD=1, pw_dir_kernel<WT>) puts it — the layers below the wide ones see its output."""
+    product, _ = make_pair(3, patch_size=64, block_size=6, with_detector=False, image_processor=None, gpt_backbone="yolox-nano")
+    g = torch.Generator().manual_seed(23)
+    x = torch.rand((6, 3, 64, 64), generator=g)
+    R = [torch.randn(o.shape, generator=g) for o in product.backbone_features(x, train=True)]
+    grads = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("JN_NO_PW_X3_BWD", "1")
+        product.engine_zero_grad()
+        product.backbone_features(x, train=True)
+        product.backbone_backward(x, R)
+        grads.append({k: v.clone() for k, v in product.engine_grads("gpt_backbone.").items()})
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k, a in grads[0].items():
+        b = grads[1][k]
+        rel = ((a - b).norm() / (b.norm() + 1e-12)).item()
+        worst = max(worst, rel)
+        assert rel < 2e-5, (k, rel)
+    assert worst > 0.0            # the two routes are different kernels: identical bits would mean the switch did nothing
+
+
 def test_backbone_golden_and_patch_embedding(golden):
     g = golden("g3_gpt_forward.npz")
     product, oracle = make_pair(int(g["seed"]), int(g["bn_seed"]), patch_size=64, block_size=6,
