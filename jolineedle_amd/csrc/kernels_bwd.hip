@@ -1529,8 +1529,119 @@ __global__ __launch_bounds__(256) void spp_bwd_kernel(const AT* __restrict__ cat
   for (int e = tid; e < HW * cb; e += 256) gbase[(long long)(e / cb) * ld + (e % cb)] += G[e];
 }
 
+// fp32, 16-byte form (round 4): a thread owns channel quads (16-byte loads of the activation and of the three pooled
+// gradients, one 16-byte read-modify-write of g0), the four channels of a quad are routed independently; the tie rule and
+// the separable arg-max are those of spp_bwd_kernel.  16 channels per workgroup.
+template <int CBQ>
+__global__ __launch_bounds__(256) void spp4_bwd_kernel(const float* __restrict__ cat, float* __restrict__ gcat, int ld, int h, int H,
+                                                       int W, ChanTab it, SlotBatch sb) {
+  using i32x4 = __attribute__((ext_vector_type(4))) int;
+  extern __shared__ __attribute__((aligned(16))) float sp[];
+  {
+    const long long sl = blockIdx.z;
+    cat += sl * sb.act; gcat += sl * sb.grad;
+    it.sc += sl * sb.tab; it.sh += sl * sb.tab; it.fl += sl * sb.tab;
+  }
+  constexpr int NI = 8;
+  const int HW = H * W, NEL = HW * CBQ;
+  f32x4* A = reinterpret_cast<f32x4*>(sp);             // activation of slice 0
+  float* G = sp + 4 * NEL;                             // gradient accumulator for slice 0 (LDS atomics per channel)
+  f32x4* Rv = reinterpret_cast<f32x4*>(sp + 8 * NEL);  // row pass: max of the horizontal window ...
+  i32x4* Rx = reinterpret_cast<i32x4*>(sp + 12 * NEL); // ... and the column it sits in (leftmost on ties)
+  const int n = blockIdx.y, c0 = blockIdx.x * 4 * CBQ;
+  const float* base = cat + (long long)n * HW * ld + c0;
+  float* gbase = gcat + (long long)n * HW * ld + c0;
+  const int tid = threadIdx.x, q = tid % CBQ;
+  f32x4 sc, sh, fl;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { sc[k] = it.sc[c0 + 4 * q + k]; sh[k] = it.sh[c0 + 4 * q + k]; fl[k] = it.fl[c0 + 4 * q + k]; }
+  int py[NI], px[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int e = tid + 256 * i, p = e / CBQ;
+    py[i] = p / W; px[i] = p - py[i] * W;
+    if (e < NEL) {
+      const f32x4 z = *reinterpret_cast<const f32x4*>(base + (long long)p * ld + 4 * q);
+      f32x4 a;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] = fl[k] != 0.0f ? silu_(fmaf(z[k], sc[k], sh[k])) : z[k];
+      A[e] = a;
+      *reinterpret_cast<f32x4*>(G + 4 * e) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __syncthreads();
+  auto route = [&](auto rad_c, int stage) {
+    constexpr int RAD = decltype(rad_c)::value;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int e = tid + 256 * i;
+      if (e < NEL) {
+        const int x = px[i];
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        i32x4 bx = {x, x, x, x};
+#pragma unroll
+        for (int d = -RAD; d <= RAD; ++d) {
+          const int xx = x + d;
+          if (xx >= 0 && xx < W) {
+            const f32x4 v = A[e + d * CBQ];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (v[k] > best[k]) { best[k] = v[k]; bx[k] = xx; }
+          }
+        }
+        Rv[e] = best; Rx[e] = bx;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int e = tid + 256 * i;
+      if (e < NEL) {
+        const int y = py[i], x = px[i];
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        i32x4 by = {y, y, y, y};
+#pragma unroll
+        for (int d = -RAD; d <= RAD; ++d) {
+          const int yy = y + d;
+          if (yy >= 0 && yy < H) {
+            const f32x4 v = Rv[e + d * W * CBQ];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (v[k] > best[k]) { best[k] = v[k]; by[k] = yy; }
+          }
+        }
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gbase + (long long)(e / CBQ) * ld + stage * h + 4 * q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int src = (by[k] * W + x) * CBQ + q;
+          const int bi = by[k] * W + reinterpret_cast<const int*>(Rx + src)[k];
+          atomicAdd(&G[(bi * CBQ + q) * 4 + k], g[k]);
+        }
+      }
+    }
+    __syncthreads();
+  };
+  route(std::integral_constant<int, 2>{}, 1);
+  route(std::integral_constant<int, 4>{}, 2);
+  route(std::integral_constant<int, 6>{}, 3);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int e = tid + 256 * i;
+    if (e < NEL) {
+      f32x4* gp = reinterpret_cast<f32x4*>(gbase + (long long)(e / CBQ) * ld + 4 * q);
+      *gp += *reinterpret_cast<const f32x4*>(G + 4 * e);
+    }
+  }
+}
+
 int launch_spp_bwd(const void* cat, int dtype, float* gcat, int ld, int h, int H, int W, int N, ChanTab it,
                    hipStream_t s, const SlotBatch& sb) {
+  static const bool no_v4 = std::getenv("JN_NO_SPP_V4") != nullptr;
+  if (dtype == JN_F32 && !no_v4 && h % 16 == 0 && ld % 4 == 0 && H * W * 4 <= 2048) {
+    hipLaunchKernelGGL(spp4_bwd_kernel<4>, dim3(h / 16, N, sb.n), dim3(256), (size_t)H * W * 4 * 16 * sizeof(float), s, (const float*)cat,
+                       gcat, ld, h, H, W, it, sb);
+    return 0;
+  }
   const int cb0 = 8;   // channels per workgroup, measured at B = 64, 20 steps: 16: 1068 us, 8: 847 us, 4: 888 us
   int cb = cb0;
   while (cb > 4 && (size_t)H * W * cb * 4 * sizeof(float) > 60 * 1024) cb >>= 1;
