@@ -16,7 +16,7 @@ import re
 import sys
 
 CONV = ("stem_mfma_kernel", "dw3x3", "dwpw_eval_kernel", "pw_mfma_kernel", "pw_narrow_kernel", "pw_dir_kernel", "pw_res_kernel", "pw_xs_kernel", "pw_x3_kernel", "w_split3_kernel", "addact_kernel",
-        "spp_kernel", "upsample_kernel", "conv3_mfma", "bn_finalize_all_kernel")
+        "spp_kernel", "spp4_kernel", "upsample_kernel", "conv3_mfma", "bn_finalize_all_kernel")
 
 
 def short(name):
@@ -27,11 +27,13 @@ def short(name):
 
 TRAIN = False
 BACKWARD = False
-BWD = ("bn_bwd_", "pw_bwd_", "dw_bwd_", "stem_bwd_", "spp_bwd", "upsample_bwd", "grad_copy", "wpart_reduce", "conv3_bwd_")
+BWD = ("bn_bwd_", "pw_bwd_", "dw_bwd_", "stem_bwd_", "spp_bwd", "spp4_bwd", "upsample_bwd", "grad_copy", "wpart_reduce", "conv3_bwd_", "w_split3_t")
 
 
 def is_data_gradient(k):
-    return (k.startswith("pw_mfma_kernel") and ", true," in k) or bool(re.match(r"pw_(dir|res)_kernel<\d+(, \d+, \d+, \d+)?, true", k))
+    # (pw_x3_kernel<.., SLOTS = true>: the wide layers' data gradient over the step slots, round 4)
+    return ((k.startswith("pw_mfma_kernel") and ", true," in k) or bool(re.match(r"pw_(dir|res)_kernel<\d+(, \d+, \d+, \d+)?, true", k))
+            or (k.startswith("pw_x3_kernel") and k.rstrip().endswith(", true>")))
 
 
 def load(path, counter):
@@ -50,7 +52,7 @@ def load(path, counter):
             continue
         if TRAIN and k.startswith("pw_mfma_kernel") and ", true," in k:
             continue
-        if TRAIN and re.match(r"pw_(dir|res)_kernel<\d+(, \d+, \d+, \d+)?, true", k):      # WT = true: data gradients
+        if TRAIN and is_data_gradient(k):      # WT = true / SLOTS = true: data gradients
             continue
         tot[k] += float(r["Counter_Value"])
         calls[k] += 1
