@@ -592,12 +592,16 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
                       o_mean = *reinterpret_cast<const f32x4*>(Cs + 2 * N + 4 * nq), o_istd = *reinterpret_cast<const f32x4*>(Cs + 3 * N + 4 * nq),
                       o_c1 = *reinterpret_cast<const f32x4*>(Cs + 4 * N + 4 * nq), o_c2 = *reinterpret_cast<const f32x4*>(Cs + 5 * N + 4 * nq),
                       o_k = *reinterpret_cast<const f32x4*>(Cs + 6 * N + 4 * nq);
+#ifdef JN_DBG_NO_STAGE_MATH            // (JN_DBG_*: attribution builds of tools/bwd_attrib.sh, never in the product library)
+          v = rg[j] + rz[j] * o_k + o_sc + o_sh + o_mean + o_istd + o_c1 + o_c2;
+#else
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float zh = (rz[j][q] - o_mean[q]) * o_istd[q];
             const float gy = rg[j][q] * dsilu_(fmaf(rz[j][q], o_sc[q], o_sh[q]));
             v[q] = o_k[q] * (gy - o_c1[q] - zh * o_c2[q]);
           }
+#endif
         }
         *reinterpret_cast<f32x4*>(Gs + r * LDG + 4 * nq) = v;
       }
@@ -648,6 +652,7 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
       }
       const float* grow = Gs + (wave * 16 + lm) * LDG + 4 * gq;
       const float* wrow = Wt + lm * LDW + 4 * gq;
+#ifndef JN_DBG_NO_P2
 #pragma unroll
       for (int kk = 0; kk < N; kk += 16) {
         const f32x4 gb = *reinterpret_cast<const f32x4*>(grow + kk);
@@ -658,6 +663,9 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
           for (int j = 0; j < 4; ++j) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], gb[j], acc[b], 0, 0, 0);
         }
       }
+#else
+      acc[0][0] = grow[0] + wrow[0];
+#endif
       const long long m = m0 + wave * 16 + lm;
       if (m < M) {
 #pragma unroll
@@ -671,7 +679,11 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
           acc[b] = v;                                  // RED below sums the FINAL gradient of the input
         }
       }
+#ifdef JN_DBG_NO_RED
+      if constexpr (false) {
+#else
       if constexpr (RED) {
+#endif
         // this wave's 16 pixels: row sums by DPP, accumulated in the wave's own LDS slots (plain read-modify-write by
         // the row leaders) -- per-lane sums held in registers across the tiles cost a wave of occupancy
         float* rslot = Cs + 7 * N + 3 * K + wave * 2 * K;
@@ -699,7 +711,12 @@ __global__ __launch_bounds__(256) void pw_bwd_fused_kernel(
       }
     }
     // ---- phase 3: dW[cout][cin] += sum_pixel g_z[pixel][cout] * a[pixel][cin]
+#ifdef JN_DBG_NO_P3
+    if constexpr (true) {
+    } else if constexpr (DW_SPLIT) {
+#else
     if constexpr (DW_SPLIT) {
+#endif
       // split-bf16 products (a weight gradient is a leaf, see pw_bwd_weight_wide_kernel): one 32-pixel k-step per wave —
       // waves 0, 1 take pixels 0..31, waves 2, 3 pixels 32..63 — and half of the output tiles each, so a wave holds
       // HALF the accumulators of the fp32 form.  Lane group gq, element e -> pixel 4 gq + (e & 3) + 16 (e >> 2).
