@@ -1,6 +1,9 @@
 #!/bin/bash
 # Per-op backward tables (single stream) with debug builds of the library that leave out one part of pw_bwd_fused_kernel each
 # (scratch/dbg/<variant>/libjnroll.so, built with -DJN_DBG_<variant>): where the fused 1x1 backward spends its time.
+# Build them HERE first (no GPU needed), one per variant NO_P3 NO_RED NO_P2 NO_STAGE_MATH and ALL (= all four flags):
+#   touch jolineedle_amd/csrc/kernels_bwd.hip; JN_EXTRA_FLAGS=-DJN_DBG_NO_P3 JN_LIB_OUT=$PWD/scratch/dbg/NO_P3 bash jolineedle_amd/csrc/build.sh
+# and rebuild the product library afterwards (touch + build.sh without flags).  Result of round 4: profiles/r04_bwd_attrib.txt.
 OUT=$PWD/gpurun_out
 for v in BASE NO_P3 NO_RED NO_P2 NO_STAGE_MATH ALL; do
   lib=""; [ $v != BASE ] && lib="JNROLL_LIB=$PWD/scratch/dbg/$v/libjnroll.so"
