@@ -1655,8 +1655,13 @@ int launch_spp_bwd(const void* cat, int dtype, float* gcat, int ld, int h, int H
                    hipStream_t s, const SlotBatch& sb) {
   static const bool no_v4 = std::getenv("JN_NO_SPP_V4") != nullptr;
   if (dtype == JN_F32 && !no_v4 && h % 16 == 0 && ld % 4 == 0 && H * W * 4 <= 2048) {
-    hipLaunchKernelGGL(spp4_bwd_kernel<4>, dim3(h / 16, N, sb.n), dim3(256), (size_t)H * W * 4 * 16 * sizeof(float), s, (const float*)cat,
-                       gcat, ld, h, H, W, it, sb);
+    const size_t smem4 = (size_t)H * W * 4 * 16 * sizeof(float);        // at most 128 KB (H * W <= 512)
+    static bool raised = false;
+    if (!raised && smem4 > 64 * 1024) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spp4_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      raised = true;
+    }
+    hipLaunchKernelGGL(spp4_bwd_kernel<4>, dim3(h / 16, N, sb.n), dim3(256), smem4, s, (const float*)cat, gcat, ld, h, H, W, it, sb);
     return 0;
   }
   const int cb0 = 8;   // channels per workgroup, measured at B = 64, 20 steps: 16: 1068 us, 8: 847 us, 4: 888 us
